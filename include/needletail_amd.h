@@ -1,0 +1,185 @@
+/*
+ * needletail_amd.h — C ABI of the MI355X-native k-mer extraction engine.
+ *
+ * Drop-in boundary for ONE hot path of onecodex/needletail (v0.7.3): the per-sequence chain
+ *     normalize -> reverse_complement -> canonical_kmers      (byte path)
+ *     strip_returns -> bit_kmers / BitNuclKmer                (2-bit path)
+ * behind the reference's `Sequence` trait (reference src/sequence.rs:156-253).  Plain pointers and
+ * sizes only; no C++/torch types.  Every entry point returns an `int` status (NTK_OK == 0); nothing
+ * throws or aborts across this boundary (the reference panics on misuse, src/kmer.rs:91,
+ * src/bitkmer.rs:51 — here misuse is NTK_ERR_BAD_K / NTK_ERR_BAD_ARG).
+ *
+ * There is no CPU fallback anywhere behind this header: every function that computes runs HIP
+ * kernels on a gfx950 device and fails with NTK_ERR_NO_DEVICE / NTK_ERR_HIP when it cannot.
+ *
+ * Two faces:
+ *   1. batch face   — the fast path.  Whole record batches (concatenated sequence bytes, one break
+ *                     byte between records) are scanned by one kernel launch; results are either
+ *                     REDUCED on device (counters + prefix histogram + digests, ntk_result) or
+ *                     MATERIALISED densely (one u64 per window + valid / is_rc bit planes).
+ *   2. compat face  — per-sequence functions with the reference's shapes (eager, synchronous),
+ *                     returning exactly what the reference's iterators yield.
+ *
+ * A Rust maintainer binds these with an `extern "C"` block (INTEGRATION.md shows it) and keeps
+ * `impl Sequence` unchanged on top.
+ */
+#ifndef NEEDLETAIL_AMD_H
+#define NEEDLETAIL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTK_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+enum {
+    NTK_OK = 0,
+    NTK_ERR_BAD_K = 1,       /* k == 0, or k beyond what the entry point supports               */
+    NTK_ERR_BAD_ARG = 2,     /* null pointer, misaligned device pointer, bad enum value ...     */
+    NTK_ERR_HIP = 3,         /* a HIP runtime call failed; ntk_last_hip_error() has the code    */
+    NTK_ERR_NO_DEVICE = 4,   /* no usable gfx950 device                                         */
+    NTK_ERR_CAPACITY = 5,    /* caller-provided output / batch capacity too small               */
+    NTK_ERR_UNSUPPORTED = 6, /* combination not available on the device path (never falls back) */
+    NTK_ERR_NOMEM = 7
+};
+const char *ntk_strerror(int status);
+int ntk_last_hip_error(void);
+int ntk_abi_version(void);
+
+/* ---- parameters (mirror the arguments of the reference's trait methods) --------------------- */
+enum { /* which iterator: reference src/sequence.rs:237-252 */
+    NTK_PATH_BYTES_CANONICAL = 0, /* Sequence::canonical_kmers(k, &rc): tie (fwd == rc) reports is_rc = true  (src/kmer.rs:124-128) */
+    NTK_PATH_BITS = 1,            /* Sequence::bit_kmers(k, false): forward value, flag false (src/bitkmer.rs:105-107)   */
+    NTK_PATH_BITS_CANONICAL = 2   /* Sequence::bit_kmers(k, true): tie reports was_rc = false (src/bitkmer.rs:136-143)   */
+};
+enum { /* which pre-step the record went through: fixes the alphabet */
+    NTK_PRE_NONE = 0,            /* raw slice: bases = acgtACGT, every other byte breaks the window         */
+    NTK_PRE_STRIP_RETURNS = 1,   /* Sequence::strip_returns (src/sequence.rs:165-191): CR/LF deleted        */
+    NTK_PRE_NORMALIZE = 2,       /* Sequence::normalize(false) (src/sequence.rs:19-62,226-232): U/u -> T,   */
+    NTK_PRE_NORMALIZE_IUPAC = 3  /*   whitespace deleted; _IUPAC = normalize(true) (same k-mer stream)      */
+};
+
+typedef struct ntk_params {
+    uint32_t k;    /* 1..32 on the batch face (values are packed into a u64)          */
+    uint32_t path; /* NTK_PATH_*                                                       */
+    uint32_t pre;  /* NTK_PRE_*                                                        */
+    uint32_t flags;/* reserved, must be 0                                              */
+} ntk_params;
+
+/* Reduced result of a scan.  `value` is the emitted k-mer in the reference's
+ * 2-bit encoding (A0 C1 G2 T3, first base most significant; src/bitkmer.rs:5-36). */
+#define NTK_HIST_MAX_PREFIX 6
+#define NTK_HIST_BINS 4096
+typedef struct ntk_result {
+    uint64_t n_total; /* emitted k-mers                                                         */
+    uint64_t n_fwd;   /* items whose flag is false ("n_canonical" in benches/benchmark.rs:37-39) */
+    uint64_t n_rc;    /* items whose flag is true                                               */
+    uint64_t sum;     /* sum of values mod 2^64                                                 */
+    uint64_t xr;      /* xor of values                                                          */
+    uint64_t hist[NTK_HIST_BINS]; /* bin = value >> 2*(k-p), p = min(k,6): leading p bases       */
+} ntk_result;
+/* Device-side accumulator layout (u64 words), for callers that reduce across GPUs themselves: */
+#define NTK_ACC_N_TOTAL 0
+#define NTK_ACC_N_FWD 1
+#define NTK_ACC_N_RC 2
+#define NTK_ACC_SUM 3
+#define NTK_ACC_XOR 4   /* NOT summable: combine with xor (or use the bit counters below) */
+#define NTK_ACC_HIST 8  /* 4096 words follow */
+#define NTK_ACC_XOR_BITS (8 + NTK_HIST_BINS) /* 64 words: how many folded partial xors had bit i set; summable
+                                                across GPUs with one ncclSum all-reduce, xor bit i = parity */
+#define NTK_ACC_WORDS (8 + NTK_HIST_BINS + 64)
+
+/* ---- context ---------------------------------------------------------------------------------
+ * One ctx per (thread, device); a ctx is not thread-safe, independent ctxs are.  The ctx owns the
+ * device accumulators, per-block partials, scratch and (unless borrowed) its HIP stream. */
+typedef struct ntk_ctx ntk_ctx;
+int ntk_ctx_create(int device, ntk_ctx **out);
+/* Borrow the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int ntk_ctx_create_on_stream(int device, void *hip_stream, ntk_ctx **out);
+void ntk_ctx_destroy(ntk_ctx *ctx);
+int ntk_ctx_synchronize(ntk_ctx *ctx);
+/* Launch geometry of the scan kernel: blocks (0 = auto: resident grid) x threads (256/512/1024). */
+int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
+/* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
+ * scan kernels' durations since the last call and how many launches that covers (synchronises). */
+int ntk_ctx_enable_timing(ntk_ctx *ctx, int on);
+int ntk_ctx_scan_time_ms(ntk_ctx *ctx, double *total_ms, uint64_t *launches);
+
+/* ---- batch face, reduce mode ----------------------------------------------------------------
+ * Device batch layout: the records' sequence bytes back to back, each followed by ONE break byte
+ * (any non-base byte; the packer writes '\n'), no bytes of the pre-step's "deleted" class inside a
+ * record (the packer / ntk_*_device compaction removed them).  d_seq must be 16-byte aligned.
+ * Replaces, per record: seq.normalize(..) / strip_returns(), seq.reverse_complement(),
+ * seq.canonical_kmers(k,&rc) or seq.bit_kmers(k,canonical) and the user's counting loop
+ * (reference src/lib.rs:22-31, benches/benchmark.rs:32-41,55-64). */
+int ntk_accum_reset(ntk_ctx *ctx);
+int ntk_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p); /* async */
+int ntk_accum_read(ntk_ctx *ctx, ntk_result *out);            /* synchronises the ctx stream        */
+int ntk_accum_device_ptr(ntk_ctx *ctx, uint64_t **d_words);  /* NTK_ACC_WORDS u64 words on device  */
+/* Accumulate into caller-owned device memory (NTK_ACC_WORDS u64, e.g. a torch tensor that is then
+ * all-reduced over RCCL); NULL re-binds the ctx's own buffer.  The caller zeroes / resets it via
+ * ntk_accum_reset as usual. */
+int ntk_accum_bind_device(ntk_ctx *ctx, uint64_t *d_words);
+
+/* ---- batch face, materialise mode -------------------------------------------------------------
+ * Dense outputs indexed by the window's END byte e (window = d_seq[e-k+1 .. e]):
+ *   d_values[e]                     emitted value (canonical or forward), undefined where invalid
+ *   d_valid16[e/16] bit (15 - e%16) window is emitted
+ *   d_rc16[e/16]    bit (15 - e%16) flag (is_rc / was_rc)
+ * The reference's `pos` is e - (k-1) - record_start.  Arrays must hold round_up(n_bytes,1024)
+ * values / round_up(n_bytes,1024)/16 u16 each.  d_values may be NULL (flags only). */
+int ntk_materialize_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p,
+                           uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16);   /* async */
+
+/* ---- batch face, pinned host batches (CPU parser fills, H2D copy overlaps the kernels) ---------
+ * A batch exposes PINNED host memory; the caller (FastxReader loop) appends records between
+ * acquire and submit; submit enqueues hipMemcpyAsync + the scan on the ctx stream and returns at
+ * once; the batch may be re-acquired after ntk_batch_wait.  Results accumulate in the ctx. */
+typedef struct ntk_batch ntk_batch;
+int ntk_batch_acquire(ntk_ctx *ctx, uint64_t max_bytes, uint64_t max_records, ntk_batch **out);
+/* Copies one record's raw sequence (`SequenceRecord::sequence()`, reference src/parser/record.rs:181-185)
+ * applying the DELETE part of `pre` (NONE: nothing; STRIP_RETURNS: CR/LF; NORMALIZE*: space, tab, CR, LF),
+ * then one break byte.  NTK_ERR_CAPACITY when the batch is full (submit it and acquire another). */
+int ntk_batch_append(ntk_batch *b, const uint8_t *seq, uint64_t n, uint32_t pre);
+int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t *n_bytes, uint64_t *n_records);
+int ntk_batch_submit(ntk_ctx *ctx, ntk_batch *b, const ntk_params *p);  /* async: H2D + reduce */
+int ntk_batch_wait(ntk_ctx *ctx, ntk_batch *b);
+void ntk_batch_release(ntk_ctx *ctx, ntk_batch *b);
+
+/* ---- compat face: the reference's per-sequence functions, eager ---------------------------------
+ * Caller-allocated outputs; *_len out-params; outputs need capacity n unless stated. */
+/* sequence::normalize (src/sequence.rs:19-62): *changed == 0 <=> the reference returns None. */
+int ntk_normalize(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, int allow_iupac,
+                  uint8_t *out, uint64_t *out_len, int *changed);
+/* Sequence::strip_returns (src/sequence.rs:165-191): *borrowed != 0 <=> Cow::Borrowed. */
+int ntk_strip_returns(ntk_ctx *ctx, const uint8_t *seq, uint64_t n,
+                      uint8_t *out, uint64_t *out_len, int *borrowed);
+/* Sequence::reverse_complement (src/sequence.rs:202-208, complement :68-105). */
+int ntk_reverse_complement(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint8_t *out);
+/* Sequence::canonical_kmers(k, rc) (src/kmer.rs:48-130): item i is (pos_out[i], is_rc_out[i]); the
+ * slice is seq[pos..pos+k] or rc[n-pos-k..n-pos] as in src/kmer.rs:121-128.  Raw-byte comparison,
+ * any k in 1..255.  Returns NTK_ERR_CAPACITY (with *count = needed) if cap is too small. */
+int ntk_canonical_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k,
+                        uint64_t *pos_out, uint8_t *is_rc_out, uint64_t cap, uint64_t *count);
+/* Sequence::bit_kmers(k, canonical) (src/bitkmer.rs:72-109): items (pos, (value,k), was_rc); k 1..32. */
+int ntk_bit_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k, int canonical,
+                  uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *count);
+
+/* ---- device utilities (bench / parity properties; records stay resident in HBM) ----------------- */
+/* Synthetic read set of SURVEY.md §8d generated straight into HBM: reads first_read..+n_reads, each
+ * read_len bases + '\n'; d_out holds n_reads*(read_len+1) bytes (+ padding to 16). */
+int ntk_synth_reads_device(ntk_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                           uint32_t read_len, uint32_t n_per_1024, uint8_t *d_out);
+/* Reverse-complement every fixed-stride record in place order (record r = bytes [r*stride, r*stride+len)),
+ * bytes outside records copied: the batch form of Sequence::reverse_complement. */
+int ntk_reverse_complement_records_device(ntk_ctx *ctx, const uint8_t *d_in, uint8_t *d_out,
+                                          uint64_t n_records, uint32_t record_len, uint32_t stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEEDLETAIL_AMD_H */

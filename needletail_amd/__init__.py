@@ -1,0 +1,18 @@
+"""needletail_amd — MI355X-native k-mer extraction engine behind needletail's Sequence-trait surface.
+
+Only the hot path lives here: csrc/ (HIP kernels + the C ABI of include/needletail_amd.h) and the
+host-side mirror of the reference interface.  Importing the package does not need a GPU; calling it does.
+"""
+from ._lib import (PATH_BITS, PATH_BITS_CANONICAL, PATH_BYTES_CANONICAL, PRE_NONE, PRE_NORMALIZE,
+                   PRE_NORMALIZE_IUPAC, PRE_STRIP_RETURNS, NtkError)
+from .engine import Batch, Context, default_context
+from .sequence import (bit_kmers, bit_kmers_arrays, canonical_kmers, canonical_kmers_arrays, kmers, normalize,
+                       normalize_opt, normalize_seq, reverse_complement, strip_returns)
+
+__all__ = [
+    "Context", "Batch", "default_context", "NtkError",
+    "PATH_BYTES_CANONICAL", "PATH_BITS", "PATH_BITS_CANONICAL",
+    "PRE_NONE", "PRE_STRIP_RETURNS", "PRE_NORMALIZE", "PRE_NORMALIZE_IUPAC",
+    "normalize", "normalize_opt", "normalize_seq", "strip_returns", "reverse_complement",
+    "kmers", "canonical_kmers", "canonical_kmers_arrays", "bit_kmers", "bit_kmers_arrays",
+]

@@ -1,0 +1,113 @@
+"""ctypes binding of libneedletail_amd.so (the C ABI in include/needletail_amd.h).
+
+There is no fallback: if the HIP library is missing or fails to load this raises, and every compute
+entry point fails with a status code when no gfx950 device is usable."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneedletail_amd.so")
+
+NTK_OK = 0
+PATH_BYTES_CANONICAL, PATH_BITS, PATH_BITS_CANONICAL = 0, 1, 2
+PRE_NONE, PRE_STRIP_RETURNS, PRE_NORMALIZE, PRE_NORMALIZE_IUPAC = 0, 1, 2, 3
+HIST_BINS = 4096
+ACC_N_TOTAL, ACC_N_FWD, ACC_N_RC, ACC_SUM, ACC_XOR, ACC_HIST = 0, 1, 2, 3, 4, 8
+ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
+
+# every symbol include/needletail_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
+SYMBOLS = [
+    "ntk_strerror", "ntk_last_hip_error", "ntk_abi_version",
+    "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
+    "ntk_ctx_set_launch", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
+    "ntk_accum_reset", "ntk_reduce_device", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
+    "ntk_materialize_device",
+    "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
+    "ntk_batch_release",
+    "ntk_normalize", "ntk_strip_returns", "ntk_reverse_complement", "ntk_canonical_kmers", "ntk_bit_kmers",
+    "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("path", C.c_uint32), ("pre", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_total", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("sum", C.c_uint64),
+                ("xr", C.c_uint64), ("hist", C.c_uint64 * HIST_BINS)]
+
+
+class NtkError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({strerror(status)}; hip={last_hip_error()})")
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C needletail_amd/csrc). needletail_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    pp = C.POINTER(C.c_void_p)
+    L.ntk_strerror.restype = C.c_char_p
+    L.ntk_strerror.argtypes = [i32]
+    L.ntk_last_hip_error.restype = i32
+    L.ntk_abi_version.restype = i32
+    L.ntk_ctx_create.argtypes = [i32, pp]
+    L.ntk_ctx_create_on_stream.argtypes = [i32, vp, pp]
+    L.ntk_ctx_destroy.restype = None
+    L.ntk_ctx_destroy.argtypes = [vp]
+    L.ntk_ctx_synchronize.argtypes = [vp]
+    L.ntk_ctx_set_launch.argtypes = [vp, i32, i32]
+    L.ntk_ctx_enable_timing.argtypes = [vp, i32]
+    L.ntk_ctx_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.ntk_accum_reset.argtypes = [vp]
+    L.ntk_reduce_device.argtypes = [vp, vp, u64, C.POINTER(Params)]
+    L.ntk_accum_read.argtypes = [vp, C.POINTER(Result)]
+    L.ntk_accum_device_ptr.argtypes = [vp, pp]
+    L.ntk_accum_bind_device.argtypes = [vp, vp]
+    L.ntk_materialize_device.argtypes = [vp, vp, u64, C.POINTER(Params), vp, vp, vp]
+    L.ntk_batch_acquire.argtypes = [vp, u64, u64, pp]
+    L.ntk_batch_append.argtypes = [vp, C.c_char_p, u64, u32]
+    L.ntk_batch_buffers.argtypes = [vp, pp, pp, C.POINTER(u64), C.POINTER(u64)]
+    L.ntk_batch_submit.argtypes = [vp, vp, C.POINTER(Params)]
+    L.ntk_batch_wait.argtypes = [vp, vp]
+    L.ntk_batch_release.restype = None
+    L.ntk_batch_release.argtypes = [vp, vp]
+    L.ntk_normalize.argtypes = [vp, C.c_char_p, u64, i32, C.c_char_p, C.POINTER(u64), C.POINTER(i32)]
+    L.ntk_strip_returns.argtypes = [vp, C.c_char_p, u64, C.c_char_p, C.POINTER(u64), C.POINTER(i32)]
+    L.ntk_reverse_complement.argtypes = [vp, C.c_char_p, u64, C.c_char_p]
+    L.ntk_canonical_kmers.argtypes = [vp, C.c_char_p, u64, u32, vp, vp, u64, C.POINTER(u64)]
+    L.ntk_bit_kmers.argtypes = [vp, C.c_char_p, u64, u32, i32, vp, vp, vp, u64, C.POINTER(u64)]
+    L.ntk_synth_reads_device.argtypes = [vp, u64, u64, u64, u32, u32, vp]
+    L.ntk_reverse_complement_records_device.argtypes = [vp, vp, vp, u64, u32, u32]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("ntk_last_hip_error", "ntk_abi_version"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def strerror(status: int) -> str:
+    return lib().ntk_strerror(status).decode()
+
+
+def last_hip_error() -> int:
+    return lib().ntk_last_hip_error()
+
+
+def check(status: int, what: str) -> None:
+    if status != NTK_OK:
+        raise NtkError(status, what)

@@ -1,0 +1,679 @@
+// ntk_api.hip — host side of the C ABI declared in include/needletail_amd.h.
+// Everything that computes launches HIP kernels (ntk_kernels.hpp); there is no CPU fallback.
+#include "../../include/needletail_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ntk_kernels.hpp"
+
+using namespace ntk;
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+#define HIPCHK(expr)                                     \
+    do {                                                 \
+        hipError_t e__ = (expr);                         \
+        if (e__ != hipSuccess) {                         \
+            g_last_hip = (int)e__;                       \
+            (void)hipGetLastError();                     \
+            return NTK_ERR_HIP;                          \
+        }                                                \
+    } while (0)
+
+constexpr uint32_t kLutChanged = 0x100, kLutDeleted = 0x200;
+
+// Byte maps, restated from the reference's match arms.
+// normalize: reference src/sequence.rs:24-51 (priority order matters only for overlapping arms; none overlap).
+void build_normalize_lut(uint16_t *lut, bool iupac)
+{
+    for (int c = 0; c < 256; c++) {
+        uint32_t v;
+        switch (c) {
+        case 'A': case 'C': case 'G': case 'T': case 'N': case '-': v = (uint32_t)c; break;
+        case 'a': v = 'A' | kLutChanged; break;
+        case 'c': v = 'C' | kLutChanged; break;
+        case 'g': v = 'G' | kLutChanged; break;
+        case 't': case 'u': case 'U': v = 'T' | kLutChanged; break;
+        case '.': case '~': v = '-' | kLutChanged; break;
+        case 'B': case 'D': case 'H': case 'V': case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M':
+            v = iupac ? (uint32_t)c : ('N' | kLutChanged); break;
+        case 'b': case 'd': case 'h': case 'v': case 'r': case 'y': case 's': case 'w': case 'k': case 'm':
+            v = iupac ? ((uint32_t)(c - 32) | kLutChanged) : ('N' | kLutChanged); break;
+        case ' ': case '\t': case '\r': case '\n': v = ' ' | kLutChanged | kLutDeleted; break;
+        default: v = 'N' | kLutChanged; break;
+        }
+        lut[c] = (uint16_t)v;
+    }
+}
+// strip_returns: reference src/sequence.rs:165-191.
+void build_strip_lut(uint16_t *lut)
+{
+    for (int c = 0; c < 256; c++) lut[c] = (uint16_t)((c == '\r' || c == '\n') ? (c | kLutChanged | kLutDeleted) : c);
+}
+// complement: reference src/sequence.rs:68-105.
+void build_complement_lut(uint16_t *lut)
+{
+    for (int c = 0; c < 256; c++) lut[c] = (uint16_t)c;
+    const char *pairs = "atcgrykmbvdhATCGRYKMBVDH";  // consecutive pairs swap; s/w/S/W map to themselves
+    for (int i = 0; pairs[i]; i += 2) {
+        lut[(uint8_t)pairs[i]] = (uint8_t)pairs[i + 1];
+        lut[(uint8_t)pairs[i + 1]] = (uint8_t)pairs[i];
+    }
+}
+
+struct Scratch {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct ntk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream (kernels, compat-face copies)
+    hipStream_t copy_stream = nullptr;  // H2D copies of pinned batches
+    bool owns_stream = false;
+    int n_cu = 256;
+    int launch_blocks = 0, launch_threads = 1024;
+    uint64_t *d_acc = nullptr;      // accumulators in use (own or caller-bound)
+    uint64_t *d_acc_own = nullptr;
+    uint32_t *d_part_hist = nullptr;
+    uint64_t *d_part_scalars = nullptr;
+    int part_blocks = 0;
+    uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
+    Scratch scratch[6];
+    void *h_pinned = nullptr;  // small pinned staging for scalar read-backs
+    bool timing = false;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
+};
+
+struct ntk_batch {
+    uint8_t *h_seq = nullptr;
+    uint64_t *h_off = nullptr;
+    uint8_t *d_seq = nullptr;
+    uint64_t cap_bytes = 0, cap_records = 0, n_bytes = 0, n_records = 0;
+    hipEvent_t ev_copied = nullptr, ev_done = nullptr;
+    bool in_flight = false;
+};
+
+namespace {
+
+int ensure_scratch(ntk_ctx *c, int slot, size_t bytes)
+{
+    if (bytes < 256) bytes = 256;
+    Scratch &s = c->scratch[slot];
+    if (s.bytes >= bytes) return NTK_OK;
+    if (s.p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&s.p, want));
+    s.bytes = want;
+    return NTK_OK;
+}
+
+int ensure_partials(ntk_ctx *c, int blocks)
+{
+    if (c->part_blocks >= blocks) return NTK_OK;
+    if (c->d_part_hist) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_part_hist)); HIPCHK(hipFree(c->d_part_scalars)); }
+    c->d_part_hist = nullptr; c->d_part_scalars = nullptr; c->part_blocks = 0;
+    HIPCHK(hipMalloc(&c->d_part_hist, (size_t)blocks * kHistBins * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_part_scalars, (size_t)blocks * 4 * sizeof(uint64_t)));
+    c->part_blocks = blocks;
+    return NTK_OK;
+}
+
+struct Mode { int kw; bool canon, tie_rc, accept_u; };
+
+int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
+{
+    if (!p) return NTK_ERR_BAD_ARG;
+    if (p->k < 1 || p->k > 32) return NTK_ERR_BAD_K;
+    if (p->flags != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
+    m->kw = p->k > 16 ? 2 : 1;
+    m->accept_u = p->pre >= NTK_PRE_NORMALIZE;
+    switch (p->path) {
+    case NTK_PATH_BYTES_CANONICAL:
+        // The byte path compares RAW bytes (reference src/kmer.rs:124); that equals the 2-bit order only when
+        // every base has the same case, which normalize guarantees.  Un-normalised byte-path input goes through
+        // ntk_canonical_kmers (raw-byte kernel); the packed-value scan refuses it rather than approximate.
+        if (batch_face && p->pre < NTK_PRE_NORMALIZE) return NTK_ERR_UNSUPPORTED;
+        m->canon = true; m->tie_rc = true; break;
+    case NTK_PATH_BITS: m->canon = false; m->tie_rc = false; break;
+    case NTK_PATH_BITS_CANONICAL: m->canon = true; m->tie_rc = false; break;
+    default: return NTK_ERR_BAD_ARG;
+    }
+    return NTK_OK;
+}
+
+template <bool REDUCE>
+hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, hipStream_t st)
+{
+#define NTK_LAUNCH(KW, C, T, U)                                                                 \
+    if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U) {                       \
+        hipLaunchKernelGGL((scan_kernel<KW, C, T, U, REDUCE>), grid, block, 0, st, a);          \
+        return hipGetLastError();                                                               \
+    }
+    NTK_LAUNCH(1, false, false, false) NTK_LAUNCH(1, false, false, true)
+    NTK_LAUNCH(1, true, false, false) NTK_LAUNCH(1, true, false, true)
+    NTK_LAUNCH(1, true, true, false) NTK_LAUNCH(1, true, true, true)
+    NTK_LAUNCH(2, false, false, false) NTK_LAUNCH(2, false, false, true)
+    NTK_LAUNCH(2, true, false, false) NTK_LAUNCH(2, true, false, true)
+    NTK_LAUNCH(2, true, true, false) NTK_LAUNCH(2, true, true, true)
+#undef NTK_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+int get_event(ntk_ctx *c, hipEvent_t *e)
+{
+    if (!c->ev_free.empty()) { *e = c->ev_free.back(); c->ev_free.pop_back(); return NTK_OK; }
+    HIPCHK(hipEventCreate(e));
+    return NTK_OK;
+}
+
+// One scan over d_seq[0, n): launches cover at most kMaxTilesPerLaunch tiles each so that per-block u32
+// histogram cells and 32-bit buffer offsets cannot overflow.
+int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
+             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16)
+{
+    if (n == 0) return NTK_OK;
+    if (!d_seq || ((uintptr_t)d_seq & 15)) return NTK_ERR_BAD_ARG;
+    const int threads = c->launch_threads;
+    const int waves_per_block = threads / 64;
+    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : c->n_cu * (1024 / threads);
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    scan_args_set_k(a, p->k);
+    a.seq = d_seq;
+    a.n_bytes = n;
+    a.n_tiles = (n + kTileBytes - 1) / kTileBytes;
+    a.values = d_values; a.valid16 = d_valid16; a.rc16 = d_rc16;
+    const uint64_t kMaxTilesPerLaunch = (uint64_t)1 << 26;  // 64 GiB of sequence per launch
+    for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
+        const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
+        const uint64_t tiles = te - tb;
+        uint64_t waves = (uint64_t)blocks_max * waves_per_block;
+        if (waves > tiles) waves = tiles;
+        const uint64_t tpw = (tiles + waves - 1) / waves;
+        const int blocks = (int)((tiles + tpw * waves_per_block - 1) / (tpw * waves_per_block));
+        a.tile_begin = tb; a.tile_end = te; a.tiles_per_wave = (uint32_t)tpw;
+        if (reduce) {
+            int rc = ensure_partials(c, blocks);
+            if (rc) return rc;
+            a.part_hist = c->d_part_hist; a.part_scalars = c->d_part_scalars;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing) {
+            int rc = get_event(c, &e0); if (rc) return rc;
+            rc = get_event(c, &e1); if (rc) return rc;
+            HIPCHK(hipEventRecord(e0, c->stream));
+        }
+        HIPCHK(reduce ? launch_scan<true>(m, a, dim3(blocks), dim3(threads), c->stream)
+                      : launch_scan<false>(m, a, dim3(blocks), dim3(threads), c->stream));
+        if (c->timing) {
+            HIPCHK(hipEventRecord(e1, c->stream));
+            c->ev_used.emplace_back(e0, e1);
+        }
+        if (reduce) {
+            hipLaunchKernelGGL(fold_kernel, dim3(kHistBins / 256), dim3(256), 0, c->stream,
+                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return NTK_OK;
+}
+
+int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
+{
+    if (!out) return NTK_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return NTK_ERR_NO_DEVICE; }
+    if (device < 0 || device >= count) return NTK_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return NTK_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+    ntk_ctx *c = new (std::nothrow) ntk_ctx();
+    if (!c) return NTK_ERR_NOMEM;
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (borrow) { c->stream = (hipStream_t)stream; c->owns_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&c->d_acc_own, NTK_ACC_WORDS * sizeof(uint64_t)));
+    c->d_acc = c->d_acc_own;
+    HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    HIPCHK(hipMalloc(&c->d_lut, 4 * 256 * sizeof(uint16_t)));
+    HIPCHK(hipHostMalloc(&c->h_pinned, 64 * 1024, hipHostMallocDefault));
+    uint16_t *h = (uint16_t *)c->h_pinned;
+    build_normalize_lut(h, false);
+    build_normalize_lut(h + 256, true);
+    build_strip_lut(h + 512);
+    build_complement_lut(h + 768);
+    HIPCHK(hipMemcpyAsync(c->d_lut, h, 4 * 256 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c;
+    return NTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ntk_strerror(int s)
+{
+    switch (s) {
+    case NTK_OK: return "ok";
+    case NTK_ERR_BAD_K: return "k out of range for this entry point";
+    case NTK_ERR_BAD_ARG: return "bad argument (null / misaligned pointer or bad enum)";
+    case NTK_ERR_HIP: return "HIP runtime error (see ntk_last_hip_error)";
+    case NTK_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case NTK_ERR_CAPACITY: return "output or batch capacity too small";
+    case NTK_ERR_UNSUPPORTED: return "combination not supported on the device path (no CPU fallback exists)";
+    case NTK_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+int ntk_last_hip_error(void) { return g_last_hip; }
+int ntk_abi_version(void) { return NTK_ABI_VERSION; }
+
+int ntk_ctx_create(int device, ntk_ctx **out) { return create_ctx(device, nullptr, false, out); }
+int ntk_ctx_create_on_stream(int device, void *hip_stream, ntk_ctx **out) { return create_ctx(device, hip_stream, true, out); }
+
+void ntk_ctx_destroy(ntk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->copy_stream);
+    for (auto &p : c->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    for (auto &s : c->scratch) if (s.p) (void)hipFree(s.p);
+    if (c->d_part_hist) (void)hipFree(c->d_part_hist);
+    if (c->d_part_scalars) (void)hipFree(c->d_part_scalars);
+    if (c->d_acc_own) (void)hipFree(c->d_acc_own);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+int ntk_ctx_synchronize(ntk_ctx *c)
+{
+    if (!c) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
+int ntk_ctx_set_launch(ntk_ctx *c, int blocks, int threads)
+{
+    if (!c || blocks < 0 || (threads != 256 && threads != 512 && threads != 1024)) return NTK_ERR_BAD_ARG;
+    c->launch_blocks = blocks; c->launch_threads = threads;
+    return NTK_OK;
+}
+
+int ntk_ctx_enable_timing(ntk_ctx *c, int on)
+{
+    if (!c) return NTK_ERR_BAD_ARG;
+    c->timing = on != 0;
+    return NTK_OK;
+}
+
+int ntk_ctx_scan_time_ms(ntk_ctx *c, double *total_ms, uint64_t *launches)
+{
+    if (!c || !total_ms) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double t = 0;
+    for (auto &p : c->ev_used) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        t += ms;
+        c->ev_free.push_back(p.first); c->ev_free.push_back(p.second);
+    }
+    if (launches) *launches = c->ev_used.size();
+    c->ev_used.clear();
+    *total_ms = t;
+    return NTK_OK;
+}
+
+int ntk_accum_reset(ntk_ctx *c)
+{
+    if (!c) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    return NTK_OK;
+}
+
+int ntk_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p)
+{
+    if (!c) return NTK_ERR_BAD_ARG;
+    Mode m;
+    int rc = resolve_mode(p, true, &m);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr);
+}
+
+int ntk_accum_read(ntk_ctx *c, ntk_result *out)
+{
+    if (!c || !out) return NTK_ERR_BAD_ARG;
+    uint64_t *h = (uint64_t *)c->h_pinned;
+    HIPCHK(hipMemcpyAsync(h, c->d_acc, NTK_ACC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    out->n_total = h[NTK_ACC_N_TOTAL]; out->n_fwd = h[NTK_ACC_N_FWD]; out->n_rc = h[NTK_ACC_N_RC];
+    out->sum = h[NTK_ACC_SUM]; out->xr = h[NTK_ACC_XOR];
+    memcpy(out->hist, h + NTK_ACC_HIST, sizeof(out->hist));
+    return NTK_OK;
+}
+
+int ntk_accum_device_ptr(ntk_ctx *c, uint64_t **d_words)
+{
+    if (!c || !d_words) return NTK_ERR_BAD_ARG;
+    *d_words = c->d_acc;
+    return NTK_OK;
+}
+
+int ntk_accum_bind_device(ntk_ctx *c, uint64_t *d_words)
+{
+    if (!c || ((uintptr_t)d_words & 7)) return NTK_ERR_BAD_ARG;
+    c->d_acc = d_words ? d_words : c->d_acc_own;
+    return NTK_OK;
+}
+
+int ntk_materialize_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p,
+                           uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16)
+{
+    if (!c || !d_valid16 || !d_rc16) return NTK_ERR_BAD_ARG;
+    Mode m;
+    int rc = resolve_mode(p, true, &m);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    return run_scan(c, d_seq, n, p, m, false, d_values, d_valid16, d_rc16);
+}
+
+/* ---- pinned batches ------------------------------------------------------------------------ */
+
+int ntk_batch_acquire(ntk_ctx *c, uint64_t max_bytes, uint64_t max_records, ntk_batch **out)
+{
+    if (!c || !out || max_bytes == 0) return NTK_ERR_BAD_ARG;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    ntk_batch *b = new (std::nothrow) ntk_batch();
+    if (!b) return NTK_ERR_NOMEM;
+    b->cap_bytes = (max_bytes + 1023) & ~(uint64_t)1023;
+    b->cap_records = max_records ? max_records : 1;
+    if (hipHostMalloc((void **)&b->h_seq, b->cap_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&b->h_off, (b->cap_records + 1) * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&b->d_seq, b->cap_bytes) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
+        g_last_hip = (int)hipGetLastError();
+        ntk_batch_release(c, b);
+        return NTK_ERR_HIP;
+    }
+    b->h_off[0] = 0;
+    *out = b;
+    return NTK_OK;
+}
+
+int ntk_batch_append(ntk_batch *b, const uint8_t *seq, uint64_t n, uint32_t pre)
+{
+    if (!b || (!seq && n) || pre > NTK_PRE_NORMALIZE_IUPAC || b->in_flight) return NTK_ERR_BAD_ARG;
+    if (b->n_records >= b->cap_records || b->n_bytes + n + 1 > b->cap_bytes) return NTK_ERR_CAPACITY;
+    uint8_t *o = b->h_seq + b->n_bytes;
+    uint64_t w = 0;
+    if (pre == NTK_PRE_NONE) {
+        memcpy(o, seq, n); w = n;
+    } else if (pre == NTK_PRE_STRIP_RETURNS) {
+        for (uint64_t i = 0; i < n; i++) { const uint8_t ch = seq[i]; if (ch != '\r' && ch != '\n') o[w++] = ch; }
+    } else {
+        for (uint64_t i = 0; i < n; i++) { const uint8_t ch = seq[i]; if (ch != '\r' && ch != '\n' && ch != ' ' && ch != '\t') o[w++] = ch; }
+    }
+    o[w++] = '\n';
+    b->n_bytes += w;
+    b->n_records += 1;
+    b->h_off[b->n_records] = b->n_bytes;
+    return NTK_OK;
+}
+
+int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t *n_bytes, uint64_t *n_records)
+{
+    if (!b) return NTK_ERR_BAD_ARG;
+    if (seq) *seq = b->h_seq;
+    if (offsets) *offsets = b->h_off;
+    if (n_bytes) *n_bytes = b->n_bytes;
+    if (n_records) *n_records = b->n_records;
+    return NTK_OK;
+}
+
+int ntk_batch_submit(ntk_ctx *c, ntk_batch *b, const ntk_params *p)
+{
+    if (!c || !b || b->in_flight) return NTK_ERR_BAD_ARG;
+    Mode m;
+    int rc = resolve_mode(p, true, &m);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (b->n_bytes) {
+        const uint64_t padded = (b->n_bytes + 15) & ~(uint64_t)15;
+        for (uint64_t i = b->n_bytes; i < padded; i++) b->h_seq[i] = '\n';
+        HIPCHK(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(hipEventRecord(b->ev_copied, c->copy_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, b->ev_copied, 0));
+        rc = run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(b->ev_done, c->stream));
+    b->in_flight = true;
+    return NTK_OK;
+}
+
+int ntk_batch_wait(ntk_ctx *c, ntk_batch *b)
+{
+    if (!c || !b) return NTK_ERR_BAD_ARG;
+    if (b->in_flight) { HIPCHK(hipEventSynchronize(b->ev_done)); b->in_flight = false; }
+    b->n_bytes = 0; b->n_records = 0; b->h_off[0] = 0;
+    return NTK_OK;
+}
+
+void ntk_batch_release(ntk_ctx *c, ntk_batch *b)
+{
+    if (!b) return;
+    if (c) (void)hipSetDevice(c->device);
+    if (b->in_flight && b->ev_done) (void)hipEventSynchronize(b->ev_done);
+    if (b->h_seq) (void)hipHostFree(b->h_seq);
+    if (b->h_off) (void)hipHostFree(b->h_off);
+    if (b->d_seq) (void)hipFree(b->d_seq);
+    if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
+    if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+    delete b;
+}
+
+/* ---- compat face ------------------------------------------------------------------------------ */
+
+static int compact_with_lut(ntk_ctx *c, const uint8_t *seq, uint64_t n, const uint16_t *d_lut,
+                            uint8_t *out, uint64_t *out_len, uint32_t *flags_out)
+{
+    flags_out[0] = flags_out[1] = 0;
+    *out_len = 0;
+    if (n == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t nblocks = (uint32_t)((n + kCompactBlockBytes - 1) / kCompactBlockBytes);
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n))) return rc;                                   // input
+    if ((rc = ensure_scratch(c, 1, n))) return rc;                                   // output
+    if ((rc = ensure_scratch(c, 2, (size_t)nblocks * 4 + 16))) return rc;            // kept per block
+    if ((rc = ensure_scratch(c, 3, (size_t)nblocks * 8 + 64))) return rc;            // offsets + total + flags
+    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_out = (uint8_t *)c->scratch[1].p;
+    uint32_t *d_kept = (uint32_t *)c->scratch[2].p;
+    uint64_t *d_off = (uint64_t *)c->scratch[3].p;
+    uint64_t *d_total = d_off + nblocks;
+    uint32_t *d_flags = (uint32_t *)(d_total + 1);
+    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_total, 0, 16, c->stream));
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(kCompactThreads), 0, c->stream, (const uint8_t *)d_in, n, d_lut, d_kept, d_flags);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_kept, d_off, nblocks, d_total);
+    hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(kCompactThreads), 0, c->stream, (const uint8_t *)d_in, n, d_lut, (const uint64_t *)d_off, d_out);
+    HIPCHK(hipGetLastError());
+    uint64_t *h = (uint64_t *)c->h_pinned;
+    HIPCHK(hipMemcpyAsync(h, d_total, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t total = h[0];
+    memcpy(flags_out, h + 1, 8);
+    if (total) {
+        HIPCHK(hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *out_len = total;
+    return NTK_OK;
+}
+
+int ntk_normalize(ntk_ctx *c, const uint8_t *seq, uint64_t n, int allow_iupac, uint8_t *out, uint64_t *out_len, int *changed)
+{
+    if (!c || (!seq && n) || (!out && n) || !out_len) return NTK_ERR_BAD_ARG;
+    uint32_t flags[2];
+    int rc = compact_with_lut(c, seq, n, c->d_lut + (allow_iupac ? 256 : 0), out, out_len, flags);
+    if (rc) return rc;
+    if (changed) *changed = flags[0] ? 1 : 0;
+    return NTK_OK;
+}
+
+int ntk_strip_returns(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *out, uint64_t *out_len, int *borrowed)
+{
+    if (!c || (!seq && n) || (!out && n) || !out_len) return NTK_ERR_BAD_ARG;
+    uint32_t flags[2];
+    int rc = compact_with_lut(c, seq, n, c->d_lut + 512, out, out_len, flags);
+    if (rc) return rc;
+    if (borrowed) *borrowed = flags[1] ? 0 : 1;
+    return NTK_OK;
+}
+
+int ntk_reverse_complement(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *out)
+{
+    if (!c || (!seq && n) || (!out && n)) return NTK_ERR_BAD_ARG;
+    if (n == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n))) return rc;
+    if ((rc = ensure_scratch(c, 1, n))) return rc;
+    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_out = (uint8_t *)c->scratch[1].p;
+    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(map_reverse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint8_t *)d_in, d_out, n, (const uint16_t *)(c->d_lut + 768));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
+int ntk_canonical_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, uint64_t *pos_out, uint8_t *is_rc_out,
+                        uint64_t cap, uint64_t *count)
+{
+    if (!c || (!seq && n) || !count) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 255) return NTK_ERR_BAD_K;
+    *count = 0;
+    if (n < k) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n))) return rc;
+    if ((rc = ensure_scratch(c, 1, n))) return rc;
+    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_flags = (uint8_t *)c->scratch[1].p;
+    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(canonical_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint8_t *)d_in, n, k, (const uint16_t *)(c->d_lut + 768), d_flags);
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> flags(n);
+    HIPCHK(hipMemcpyAsync(flags.data(), d_flags, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t m = 0;
+    for (uint64_t p = 0; p + k <= n; p++) {
+        if (flags[p] & 1) {
+            if (m < cap) { if (pos_out) pos_out[m] = p; if (is_rc_out) is_rc_out[m] = (flags[p] >> 1) & 1; }
+            m++;
+        }
+    }
+    *count = m;
+    return m > cap ? NTK_ERR_CAPACITY : NTK_OK;
+}
+
+int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int canonical, uint64_t *pos_out,
+                  uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *count)
+{
+    if (!c || (!seq && n) || !count) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 32) return NTK_ERR_BAD_K;
+    *count = 0;
+    if (n < k) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    ntk_params p = {k, (uint32_t)(canonical ? NTK_PATH_BITS_CANONICAL : NTK_PATH_BITS), NTK_PRE_NONE, 0};
+    Mode m;
+    int rc = resolve_mode(&p, true, &m);
+    if (rc) return rc;
+    const uint64_t nt = (n + kTileBytes - 1) / kTileBytes * kTileBytes;
+    if ((rc = ensure_scratch(c, 0, nt))) return rc;
+    if ((rc = ensure_scratch(c, 1, nt * 8))) return rc;
+    if ((rc = ensure_scratch(c, 2, nt / 8))) return rc;
+    if ((rc = ensure_scratch(c, 3, nt / 8))) return rc;
+    uint8_t *d_in = (uint8_t *)c->scratch[0].p;
+    uint64_t *d_val = (uint64_t *)c->scratch[1].p;
+    uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
+    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_scan(c, d_in, n, &p, m, false, d_val, d_v16, d_r16))) return rc;
+    std::vector<uint64_t> vals(nt);
+    std::vector<uint16_t> v16(nt / 16), r16(nt / 16);
+    HIPCHK(hipMemcpyAsync(vals.data(), d_val, nt * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(v16.data(), d_v16, nt / 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(r16.data(), d_r16, nt / 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t mcount = 0;
+    for (uint64_t e = k - 1; e < n; e++) {
+        const uint32_t bit = 15 - (uint32_t)(e & 15);
+        if ((v16[e >> 4] >> bit) & 1) {
+            if (mcount < cap) {
+                if (pos_out) pos_out[mcount] = e - (k - 1);
+                if (val_out) val_out[mcount] = vals[e];
+                if (was_rc_out) was_rc_out[mcount] = (r16[e >> 4] >> bit) & 1;
+            }
+            mcount++;
+        }
+    }
+    *count = mcount;
+    return mcount > cap ? NTK_ERR_CAPACITY : NTK_OK;
+}
+
+/* ---- device utilities ---------------------------------------------------------------------------- */
+
+int ntk_synth_reads_device(ntk_ctx *c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                           uint32_t n_per_1024, uint8_t *d_out)
+{
+    if (!c || !d_out || read_len == 0) return NTK_ERR_BAD_ARG;
+    if (n_reads == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t total = n_reads * ((uint64_t)read_len + 1);
+    const uint64_t threads = (total + 15) / 16;
+    hipLaunchKernelGGL(synth_reads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                       seed, first_read, n_reads, read_len, n_per_1024, d_out);
+    HIPCHK(hipGetLastError());
+    return NTK_OK;
+}
+
+int ntk_reverse_complement_records_device(ntk_ctx *c, const uint8_t *d_in, uint8_t *d_out, uint64_t n_records,
+                                          uint32_t record_len, uint32_t stride)
+{
+    if (!c || !d_in || !d_out || stride == 0 || record_len > stride) return NTK_ERR_BAD_ARG;
+    if (n_records == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t total = n_records * stride;
+    hipLaunchKernelGGL(revcomp_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       d_in, d_out, n_records, record_len, stride, (const uint16_t *)(c->d_lut + 768));
+    HIPCHK(hipGetLastError());
+    return NTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,390 @@
+// ntk_kernels.hpp — hand-written HIP kernels for gfx950 (CDNA4, wave64).  No CUDA path, no MFMA:
+// the work is byte/integer scanning bounded by HBM reads and VALU issue.
+//
+// The scan engine restates the reference's per-record chain as one streaming pass over a batch:
+//   normalize/strip_returns (alphabet part)  reference src/sequence.rs:19-62,165-191
+//   reverse_complement                       reference src/sequence.rs:68-105,202-208
+//   CanonicalKmers / BitNuclKmer             reference src/kmer.rs:48-130, src/bitkmer.rs:26-143
+// Per raw byte only a 2-way class matters on device: "base" (extends the window, 2-bit
+// code A0 C1 G2 T3) or "break" (resets it).  Bytes of the pre-step's "deleted" class never reach the
+// device (the host packer drops them while copying into the pinned batch).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "ntk_tile.hpp"
+
+namespace ntk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Cross-lane "value held by the previous lane"; lane 0 receives lane 63 of `prev_tile`.
+// DPP wave_shr:1 / wave_ror:1 are single VALU moves on gfx9-family (gfx950 included).
+constexpr int kDppWaveShr1 = 0x138;
+constexpr int kDppWaveRor1 = 0x13C;
+#ifndef NTK_NO_DPP
+__device__ __forceinline__ uint32_t lane_prev(uint32_t cur, uint32_t prev_tile)
+{
+    uint32_t rot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)prev_tile, kDppWaveRor1, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)rot, (int)cur, kDppWaveShr1, 0xf, 0xf, false);
+}
+#else
+__device__ __forceinline__ uint32_t lane_prev(uint32_t cur, uint32_t prev_tile)
+{
+    uint32_t up = __shfl_up(cur, 1, 64);
+    uint32_t last = __shfl(prev_tile, 63, 64);
+    return (threadIdx.x & 63) ? up : last;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// sinks
+// ---------------------------------------------------------------------------------------------
+template <int KW>
+struct ReduceSink {
+    static constexpr bool kReduce = true;
+    uint64_t sum = 0, xr = 0;
+    uint32_t n_fwd = 0, n_valid = 0;
+    uint32_t *hist;
+    uint32_t bin_shift;
+
+    __device__ __forceinline__ void begin_tile(uint64_t, uint32_t inval16) { n_valid += __popc(~inval16 & 0xFFFFu); }
+    __device__ __forceinline__ void emit(int, bool valid, bool take_fwd, uint32_t hi, uint32_t lo)
+    {
+        if (valid) {
+            const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+            sum += v;
+            xr ^= v;
+            n_fwd += take_fwd ? 1u : 0u;
+            atomicAdd(&hist[(uint32_t)(v >> bin_shift)], 1u);
+        }
+    }
+    __device__ __forceinline__ void end_tile() {}
+};
+
+template <int KW>
+struct MaterializeSink {
+    static constexpr bool kReduce = false;
+    uint64_t *values;
+    uint16_t *valid16, *rc16;
+    uint64_t base = 0;     // global byte index of this lane's first base in the current tile
+    uint32_t inval = 0, rcbits = 0;
+
+    __device__ __forceinline__ void begin_tile(uint64_t lane_base, uint32_t inval16) { base = lane_base; inval = inval16; rcbits = 0; }
+    __device__ __forceinline__ void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
+    {
+        if (values) values[base + (uint64_t)j] = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+        rcbits |= (take_fwd ? 0u : 1u) << (15 - j);
+    }
+    __device__ __forceinline__ void end_tile()
+    {
+        const uint32_t v = ~inval & 0xFFFFu;
+        valid16[base >> 4] = (uint16_t)v;
+        rc16[base >> 4] = (uint16_t)(rcbits & v);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// the scan kernel
+//   KW       1: k <= 16 (32-bit values)   2: 17 <= k <= 32 (64-bit values)
+//   CANON    emit min(fwd, revcomp) with the strand flag; else the forward value, flag false
+//   TIE_RC   fwd == rc reports flag true (byte path, reference src/kmer.rs:124-128);
+//            false: flag false (bit path, reference src/bitkmer.rs:138-142)
+//   ACCEPT_U U/u is a base coding T (records went through normalize)
+// Work split: every wave streams its own contiguous run of 1-KiB tiles; a lane owns the 16 windows
+// that END at its 16 bytes and takes the preceding k-1 <= 31 bases from the two previous lanes (DPP),
+// lanes 0/1 from the previous tile of the same wave (registers) - so no byte is fetched twice except
+// one 1-KiB look-back tile per wave run.
+// ---------------------------------------------------------------------------------------------
+struct LaneHist {  // what must survive from the previous tile for the halo
+    uint32_t code = 0, code1 = 0, rcode = 0, rcode1 = 0, bad = 0xFFFFu, bad1 = 0xFFFFu;
+};
+
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, class Sink>
+__device__ __forceinline__ void process_tile(const ScanArgs &a, Sink &sink, LaneHist &ph, u32x4 raw,
+                                             uint64_t lane_base, bool emit)
+{
+    Enc en = encode16<ACCEPT_U>(Raw16{raw.x, raw.y, raw.z, raw.w});
+    // bytes at or beyond n_bytes are breaks (the last 16-B line may carry allocation padding)
+    if (lane_base + 16 > a.n_bytes) {
+        const uint32_t keep = lane_base >= a.n_bytes ? 0u : (uint32_t)(a.n_bytes - lane_base);
+        en.bad |= 0xFFFFu >> keep;
+    }
+    const uint32_t c1 = lane_prev(en.code, ph.code), c2 = lane_prev(c1, ph.code1);
+    const uint32_t r1 = lane_prev(en.rcode, ph.rcode), r2 = lane_prev(r1, ph.rcode1);
+    const uint32_t b1 = lane_prev(en.bad, ph.bad), b2 = lane_prev(b1, ph.bad1);
+    ph.code = en.code; ph.code1 = c1; ph.rcode = en.rcode; ph.rcode1 = r1; ph.bad = en.bad; ph.bad1 = b1;
+    if (!emit) return;
+    TileWords tw;
+    tw.W[0] = c2; tw.W[1] = c1; tw.W[2] = en.code;
+    tw.R[0] = en.rcode; tw.R[1] = r1; tw.R[2] = r2;
+    tw.bad48 = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;
+    emit_windows<KW, CANON, TIE_RC>(a, sink, tw, lane_base);
+}
+
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE>
+__global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
+{
+    using Sink = typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type;
+    __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
+    __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
+
+    Sink sink;
+    if constexpr (REDUCE) {
+        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+        sink.hist = s_hist;
+        sink.bin_shift = a.bin_shift;
+    } else {
+        sink.values = a.values; sink.valid16 = a.valid16; sink.rc16 = a.rc16;
+    }
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint64_t t0 = a.tile_begin + gw * a.tiles_per_wave;
+    uint64_t t1 = t0 + a.tiles_per_wave;
+    if (t1 > a.tile_end) t1 = a.tile_end;
+
+    if (t0 < t1) {
+        // wave-uniform buffer descriptor over [first look-back tile, end of input): hardware bounds
+        // checking returns 0 (a break byte) beyond the padded end.
+        const uint64_t tstart = t0 ? t0 - 1 : 0;
+        const uint64_t cbase = (uint64_t)a.seq + tstart * kTileBytes;
+        uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - tstart * kTileBytes;
+        if (rem > 0xFFFFFFFFull) rem = 0xFFFFFFFFull;
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
+        const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+
+        LaneHist ph;
+        uint32_t voff = lane * 16u;
+        uint64_t lane_base = tstart * kTileBytes + lane * 16u;
+        u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        if (t0) {  // look-back tile: only its halo is needed
+            u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileBytes, 0, 0);
+            process_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, ph, cur, lane_base, false);
+            cur = nxt; voff += kTileBytes; lane_base += kTileBytes;
+        }
+        for (uint64_t t = t0; t < t1; t++) {
+            u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileBytes, 0, 0);
+            process_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, ph, cur, lane_base, true);
+            cur = nxt; voff += kTileBytes; lane_base += kTileBytes;
+        }
+    }
+
+    if constexpr (REDUCE) {
+        // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
+        uint64_t sum = sink.sum, xr = sink.xr, nf = sink.n_fwd, nv = sink.n_valid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o, 64);
+            xr ^= __shfl_xor(xr, o, 64);
+            nf += __shfl_xor(nf, o, 64);
+            nv += __shfl_xor(nv, o, 64);
+        }
+        if (lane == 0) { s_red[wave * 4 + 0] = nv; s_red[wave * 4 + 1] = nf; s_red[wave * 4 + 2] = sum; s_red[wave * 4 + 3] = xr; }
+        __syncthreads();
+        uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
+        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
+        if (threadIdx.x == 0) {
+            uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {
+                tv += s_red[w * 4 + 0]; tf += s_red[w * 4 + 1]; ts += s_red[w * 4 + 2]; tx ^= s_red[w * 4 + 3];
+            }
+            uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
+            ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
+        }
+    }
+}
+
+// Sums the per-block partials into the ctx accumulators (same stream, after the scan kernel).
+__global__ void fold_kernel(const uint32_t *part_hist, const uint64_t *part_scalars, int nblocks, uint64_t *acc)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin < kHistBins) {
+        uint64_t s = 0;
+        for (int b = 0; b < nblocks; b++) s += part_hist[(size_t)b * kHistBins + bin];
+        acc[8 + bin] += s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+        for (int b = 0; b < nblocks; b++) {
+            tv += part_scalars[b * 4 + 0]; tf += part_scalars[b * 4 + 1];
+            ts += part_scalars[b * 4 + 2]; tx ^= part_scalars[b * 4 + 3];
+        }
+        acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx;
+        for (int i = 0; i < 64; i++) acc[8 + kHistBins + i] += (tx >> i) & 1;  // summable form of the xor
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compat-face kernels (per-sequence API parity; not the throughput path)
+// ---------------------------------------------------------------------------------------------
+
+// byte LUT map (normalize / complement): out[i] = lut[in[i]] & 0xFF
+__global__ void map_reverse_kernel(const uint8_t *in, uint8_t *out, uint64_t n, const uint16_t *lut)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)lut[in[n - 1 - i]];
+}
+
+// Fixed-stride records, reverse-complemented record by record; bytes outside records are copied.
+__global__ void revcomp_records_kernel(const uint8_t *in, uint8_t *out, uint64_t n_records, uint32_t len,
+                                       uint32_t stride, const uint16_t *lut)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_records * stride) return;
+    const uint64_t r = g / stride;
+    const uint32_t j = (uint32_t)(g - r * stride);
+    out[g] = j < len ? (uint8_t)lut[in[r * stride + (len - 1 - j)]] : in[g];
+}
+
+// Stream compaction with a byte map: lut low byte = mapped char, bit 8 = "changed", bit 9 = "deleted".
+constexpr int kCompactThreads = 256, kCompactPerThread = 16, kCompactBlockBytes = kCompactThreads * kCompactPerThread;
+__global__ __launch_bounds__(kCompactThreads) void compact_count_kernel(const uint8_t *in, uint64_t n, const uint16_t *lut,
+                                                                        uint32_t *block_kept, uint32_t *flags)
+{
+    __shared__ uint32_t s_cnt[kCompactThreads / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kCompactBlockBytes + (uint64_t)threadIdx.x * kCompactPerThread;
+    uint32_t kept = 0, changed = 0, deleted = 0;
+    for (int i = 0; i < kCompactPerThread; i++) {
+        if (base + i < n) {
+            const uint16_t m = lut[in[base + i]];
+            kept += (m & 0x200) ? 0u : 1u;
+            changed |= (m >> 8) & 1u;
+            deleted |= (m >> 9) & 1u;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
+    if (__any(changed) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1u);
+    if (__any(deleted) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1u);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kCompactThreads / 64; w++) t += s_cnt[w];
+        block_kept[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of block_kept -> block_off (u64), single block
+__global__ __launch_bounds__(1024) void compact_scan_kernel(const uint32_t *block_kept, uint64_t *block_off, uint32_t nblocks,
+                                                            uint64_t *total)
+{
+    __shared__ uint64_t s_tot[1024];
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < per; i++) if (b0 + i < nblocks) t += block_kept[b0 + i];
+    s_tot[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; i++) { uint64_t v = s_tot[i]; s_tot[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = s_tot[threadIdx.x];
+    for (uint32_t i = 0; i < per; i++) if (b0 + i < nblocks) { block_off[b0 + i] = run; run += block_kept[b0 + i]; }
+}
+
+__global__ __launch_bounds__(kCompactThreads) void compact_write_kernel(const uint8_t *in, uint64_t n, const uint16_t *lut,
+                                                                        const uint64_t *block_off, uint8_t *out)
+{
+    __shared__ uint32_t s_off[kCompactThreads];
+    const uint64_t base = (uint64_t)blockIdx.x * kCompactBlockBytes + (uint64_t)threadIdx.x * kCompactPerThread;
+    uint16_t m[kCompactPerThread];
+    uint32_t kept = 0;
+#pragma unroll
+    for (int i = 0; i < kCompactPerThread; i++) {
+        m[i] = base + i < n ? lut[in[base + i]] : (uint16_t)0x200;
+        kept += (m[i] & 0x200) ? 0u : 1u;
+    }
+    s_off[threadIdx.x] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < kCompactThreads; i++) { uint32_t v = s_off[i]; s_off[i] = run; run += v; }
+    }
+    __syncthreads();
+    uint64_t w = block_off[blockIdx.x] + s_off[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < kCompactPerThread; i++)
+        if (!(m[i] & 0x200)) out[w++] = (uint8_t)m[i];
+}
+
+// CanonicalKmers with the reference's raw-byte comparison (reference src/kmer.rs:84-129), any k <= 255.
+// One thread per window start; flags8[p]: bit0 = emitted, bit1 = is_rc.  cls: 1 = good base; comp LUT.
+__global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t k, const uint16_t *comp_lut, uint8_t *flags8)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint8_t f = 0;
+    if (p + k <= n) {
+        bool good = true;
+        for (uint32_t i = 0; i < k; i++) {
+            const uint8_t c = seq[p + i] & 0xDF;
+            good = good && (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        }
+        if (good) {
+            bool is_rc = true;  // equal slices -> rc (reference src/kmer.rs:124-128)
+            for (uint32_t i = 0; i < k; i++) {
+                const uint8_t a = seq[p + i], b = (uint8_t)comp_lut[seq[p + k - 1 - i]];
+                if (a != b) { is_rc = !(a < b); break; }
+            }
+            f = (uint8_t)(1u | (is_rc ? 2u : 0u));
+        }
+    }
+    flags8[p] = f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic reads: counter-based SplitMix64, one thread per 16 output bytes
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
+{
+    uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void synth_reads_kernel(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                   uint32_t n_per_1024, uint8_t *out)
+{
+    const uint64_t total = n_reads * ((uint64_t)read_len + 1);
+    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (g0 >= total) return;
+    const uint32_t wpr = (read_len + 31) / 32, npr = (read_len + 5) / 6;
+    uint64_t r = g0 / (read_len + 1);
+    uint32_t j = (uint32_t)(g0 - r * (read_len + 1));
+    uint8_t buf[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint8_t b = '\n';
+        if (g0 + i < total) {
+            if (j < read_len) {
+                const uint64_t rr = first_read + r;
+                const uint64_t w = splitmix64_at(seed, rr * wpr + j / 32);
+                b = (uint8_t)"ACGT"[(w >> (2 * (j % 32))) & 3];
+                if (n_per_1024) {
+                    const uint64_t m = splitmix64_at(seed + 1, rr * npr + j / 6);
+                    if (((m >> (10 * (j % 6))) & 1023) < n_per_1024) b = 'N';
+                }
+            }
+            if (++j > read_len) { j = 0; r++; }
+        }
+        buf[i] = b;
+    }
+    if (g0 + 16 <= total) {
+        *reinterpret_cast<u32x4 *>(out + g0) = *reinterpret_cast<u32x4 *>(buf);
+    } else {
+        for (int i = 0; i < 16 && g0 + i < total; i++) out[g0 + i] = buf[i];
+    }
+}
+
+}  // namespace ntk

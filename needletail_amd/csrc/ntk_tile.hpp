@@ -1,0 +1,224 @@
+// ntk_tile.hpp — per-lane tile logic of the scan engine, written so that the SAME source compiles
+// for gfx950 (inside the HIP kernels) and for the host (tests/emu/, a lock-step 64-lane emulation used
+// by the CPU test-suite to check the bit manipulation without a GPU).  Nothing here touches memory.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NTK_HD __host__ __device__ __forceinline__
+#else
+#define NTK_HD inline
+#endif
+
+namespace ntk {
+
+constexpr int kTileBytes = 1024;  // one wave-tile = 64 lanes x 16 B = one coalesced dwordx4 load
+constexpr int kHistBins = 4096;
+
+struct ScanArgs {
+    const uint8_t *seq;   // 16-B aligned, readable up to round_up(n_bytes, 16)
+    uint64_t n_bytes;
+    uint64_t n_tiles;     // ceil(n_bytes / 1024)
+    uint64_t tile_begin;  // first tile of this launch (a launch covers tiles [tile_begin, tile_end))
+    uint64_t tile_end;
+    uint32_t tiles_per_wave;
+    uint32_t k;
+    uint32_t sh_r;        // right shift of the reverse-complement stream: 64-2k (KW=2) / 32-2k (KW=1)
+    uint32_t mask_hi;     // KW=2: (1 << (2k-32)) - 1
+    uint32_t mask_lo;     // KW=1: (1 << 2k) - 1 (k=16: ~0); KW=2: ~0
+    uint32_t smear[5];    // doubling shifts that OR a break bit over the k windows containing it
+    uint32_t bin_shift;   // 2*(k - min(k,6))
+    // reduce sink
+    uint32_t *part_hist;     // [grid][kHistBins]
+    uint64_t *part_scalars;  // [grid][4]: n_total, n_fwd, sum, xor
+    // materialise sink
+    uint64_t *values;
+    uint16_t *valid16;
+    uint16_t *rc16;
+};
+
+// Fills the k-derived fields (host side).  k must be 1..32.
+inline void scan_args_set_k(ScanArgs &a, uint32_t k)
+{
+    a.k = k;
+    if (k > 16) {
+        a.sh_r = 64 - 2 * k;
+        a.mask_hi = k == 32 ? 0xFFFFFFFFu : ((1u << (2 * k - 32)) - 1u);
+        a.mask_lo = 0xFFFFFFFFu;
+    } else {
+        a.sh_r = 32 - 2 * k;
+        a.mask_hi = 0;
+        a.mask_lo = k == 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    }
+    uint32_t len = 1;
+    for (int i = 0; i < 5; i++) {
+        uint32_t s = len < k ? (len < k - len ? len : k - len) : 0;
+        a.smear[i] = s;
+        len += s;
+    }
+    const uint32_t p = k < 6 ? k : 6;
+    a.bin_shift = 2 * (k - p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// instruction-level helpers: gfx950 builtins on device, portable C on the host
+// ---------------------------------------------------------------------------------------------
+NTK_HD uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+NTK_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)  // v_perm_b32: selector 0-3 -> lo bytes, 4-7 -> hi bytes
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t src = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t s = (sel >> (8 * i)) & 0xFF;
+        const uint32_t b = s < 8 ? (uint32_t)((src >> (8 * s)) & 0xFF) : (s >= 13 ? 0xFFu : 0u);
+        r |= b << (8 * i);
+    }
+    return r;
+#endif
+}
+
+NTK_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)  // v_alignbit_b32: ({hi,lo} >> (sh & 31))[31:0]
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
+#endif
+}
+
+NTK_HD uint32_t brev32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+
+// 32 bits of a big-endian word stream starting `off` bits after the MSB of W[0].
+template <int N>
+NTK_HD uint32_t win32(const uint32_t (&W)[N], int off)
+{
+    const int wi = off >> 5, s = off & 31;
+    if (s == 0) return W[wi];
+    return alignbit(W[wi], (wi + 1 < N) ? W[wi + 1] : 0u, 32 - s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode: 16 raw ASCII bytes -> 2-bit codes (base 0 in bits 31:30), break mask (base i at bit 15-i),
+// and the lane's word of the reverse-complement stream.  Pure SWAR, no LUT in memory.
+// ---------------------------------------------------------------------------------------------
+struct Raw16 { uint32_t x, y, z, w; };  // little-endian dwords: byte 0 of x is base 0
+struct Enc {
+    uint32_t code;   // 2-bit codes, MSB-first
+    uint32_t rcode;  // group g (bits 2g+1:2g) = complement of base g: the reverse-complement stream word
+    uint32_t bad;    // bit (15-i) set when byte i is not a base
+};
+
+template <bool ACCEPT_U>
+NTK_HD Enc encode16(Raw16 d)
+{
+    // 4x4 byte transpose so that E_s holds bases {s, 4+s, 8+s, 12+s} with base s in the top byte.
+    const uint32_t x0 = perm(d.x, d.y, 0x04000501u), x1 = perm(d.x, d.y, 0x06020703u);
+    const uint32_t y0 = perm(d.z, d.w, 0x04000501u), y1 = perm(d.z, d.w, 0x06020703u);
+    const uint32_t e0 = perm(x0, y0, 0x07060302u), e1 = perm(x0, y0, 0x05040100u);
+    const uint32_t e2 = perm(x1, y1, 0x07060302u), e3 = perm(x1, y1, 0x05040100u);
+
+    // ASCII bits 2:1 give A0 C1 T2 G3 (either case, U == T); merge the four slots of every byte.
+    const uint32_t m = bfi(0xC0C0C0C0u, e0 << 5, bfi(0x30303030u, e1 << 3, bfi(0x0C0C0C0Cu, e2 << 1, e3 >> 1)));
+    Enc r;
+    r.code = m ^ ((m >> 1) & 0x55555555u);  // -> A0 C1 G2 T3 (reference src/bitkmer.rs:8-15)
+
+    // complement (3 - c == ~c on 2 bits) and reverse the order of the 16 groups
+    const uint32_t t = brev32(~r.code);
+    r.rcode = bfi(0x55555555u, t >> 1, t << 1);
+
+    // break mask: a byte is a base iff (byte & 0xDF) equals the letter its bits 2:1 select.
+    // ACCEPT_U (normalize pipeline, reference src/sequence.rs:30): fold T(0x54) and U(0x55) together.
+    constexpr uint32_t kTable = ACCEPT_U ? 0x47554341u : 0x47544341u;  // byte x: A C T/U G
+    uint32_t h[4];
+    const uint32_t e[4] = {e0, e1, e2, e3};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        uint32_t u = e[s] & 0xDFDFDFDFu;
+        if (ACCEPT_U) u |= (u >> 4) & 0x01010101u;
+        const uint32_t sel = (e[s] >> 1) & 0x03030303u;
+        const uint32_t dif = perm(0u, kTable, sel) ^ u;
+        h[s] = ((dif & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | dif;  // bit 7 of every byte: byte differs
+    }
+    uint32_t g = bfi(0x80808080u, h[0], bfi(0x40404040u, h[1] >> 1, bfi(0x20202020u, h[2] >> 2, h[3] >> 3)));
+    g = (g >> 4) & 0x0F0F0F0Fu;
+    g = (g | (g >> 4)) & 0x00FF00FFu;
+    r.bad = (g | (g >> 8)) & 0xFFFFu;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// windows: everything one lane needs for its 16 window-end positions
+//   W  = {codes of lane-2, lane-1, own}            (forward stream, 48 bases)
+//   R  = {rcode of own, lane-1, lane-2}            (reverse-complement stream of the same 48 bases)
+//   bad48 = break bits, base i of lane-2 at bit 47-i ... own base i at bit 15-i
+//   KW       1: k <= 16 (32-bit values)   2: 17 <= k <= 32 (64-bit values)
+//   CANON    emit min(fwd, revcomp) with the strand flag; else the forward value, flag false
+//   TIE_RC   fwd == rc reports flag true (byte path, reference src/kmer.rs:124-128);
+//            false: flag false (bit path, reference src/bitkmer.rs:138-142)
+// The window ending at own base j is the 2k bits of W ending 2(33+j) bits after the MSB of W[0]
+// (independent of k), and the 2k bits of R starting 2(15-j) bits in; R is pre-shifted right by sh_r once
+// per tile so that both are read right-aligned at k-independent offsets with v_alignbit.
+// ---------------------------------------------------------------------------------------------
+struct TileWords {
+    uint32_t W[3];
+    uint32_t R[3];
+    uint64_t bad48;
+};
+
+template <int KW, bool CANON, bool TIE_RC, class Sink>
+NTK_HD void emit_windows(const ScanArgs &a, Sink &sink, const TileWords &tw, uint64_t lane_base)
+{
+    // windows containing a break: OR every break bit over the k window-end positions that follow it
+    uint64_t bw = tw.bad48;
+#pragma unroll
+    for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+    const uint32_t inval = (uint32_t)bw & 0xFFFFu;
+    sink.begin_tile(lane_base, inval);
+
+    uint32_t Q[3];
+    Q[0] = tw.R[0] >> a.sh_r;
+    Q[1] = alignbit(tw.R[0], tw.R[1], a.sh_r);
+    Q[2] = KW == 2 ? alignbit(tw.R[1], tw.R[2], a.sh_r) : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t fh = 0, fl, rh = 0, rl;
+        if (KW == 2) {
+            fl = win32(tw.W, 34 + 2 * j);
+            fh = win32(tw.W, 2 + 2 * j) & a.mask_hi;
+            rh = win32(Q, 2 * (15 - j)) & a.mask_hi;
+            rl = win32(Q, 32 + 2 * (15 - j));
+        } else {
+            fl = win32(tw.W, 34 + 2 * j) & a.mask_lo;
+            rl = win32(Q, 2 * (15 - j)) & a.mask_lo;
+        }
+        bool take_fwd = true;
+        if (CANON) {
+            if (KW == 2) {
+                const uint64_t f = ((uint64_t)fh << 32) | fl, r = ((uint64_t)rh << 32) | rl;
+                take_fwd = TIE_RC ? (f < r) : (f <= r);
+            } else {
+                take_fwd = TIE_RC ? (fl < rl) : (fl <= rl);
+            }
+        }
+        const bool valid = ((inval >> (15 - j)) & 1u) == 0u;
+        sink.emit(j, valid, take_fwd, take_fwd ? fh : rh, take_fwd ? fl : rl);
+    }
+    sink.end_tile();
+}
+
+}  // namespace ntk

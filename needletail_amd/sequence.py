@@ -1,0 +1,108 @@
+"""Host-side mirror of needletail's `Sequence` trait (reference src/sequence.rs:156-253) and of the
+two hot-path functions its Python module exposes (reference src/python.rs:365-371,391-399), all running on
+the HIP engine through the C ABI's compat face.  Names, argument meaning and results follow the reference
+so that the parity tests read like the reference's own tests."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterator, List, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Context, default_context
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else default_context()
+
+
+def normalize(seq: bytes, iupac: bool = False, ctx: Context = None) -> bytes:
+    """Sequence::normalize (reference src/sequence.rs:226-232): the normalised bytes (the input itself when
+    nothing changed, like Cow::Borrowed)."""
+    out, changed = normalize_opt(seq, iupac, ctx)
+    return out if changed else seq
+
+
+def normalize_opt(seq: bytes, iupac: bool = False, ctx: Context = None) -> Tuple[bytes, bool]:
+    """sequence::normalize (reference src/sequence.rs:19-62): (bytes, changed); changed False <=> `None`."""
+    c = _ctx(ctx)
+    out = C.create_string_buffer(max(len(seq), 1))
+    n, ch = C.c_uint64(0), C.c_int(0)
+    L.check(L.lib().ntk_normalize(c._h, seq, len(seq), int(iupac), out, C.byref(n), C.byref(ch)), "ntk_normalize")
+    return out.raw[: n.value], bool(ch.value)
+
+
+def strip_returns(seq: bytes, ctx: Context = None) -> bytes:
+    """Sequence::strip_returns (reference src/sequence.rs:165-191)."""
+    c = _ctx(ctx)
+    out = C.create_string_buffer(max(len(seq), 1))
+    n, b = C.c_uint64(0), C.c_int(0)
+    L.check(L.lib().ntk_strip_returns(c._h, seq, len(seq), out, C.byref(n), C.byref(b)), "ntk_strip_returns")
+    return seq if b.value else out.raw[: n.value]
+
+
+def reverse_complement(seq, ctx: Context = None):
+    """Sequence::reverse_complement (reference src/sequence.rs:202-208); str in -> str out like the
+    reference's Python function (reference src/python.rs:391-399)."""
+    if isinstance(seq, str):
+        return reverse_complement(seq.encode("utf-8"), ctx).decode("utf-8")
+    c = _ctx(ctx)
+    out = C.create_string_buffer(max(len(seq), 1))
+    L.check(L.lib().ntk_reverse_complement(c._h, seq, len(seq), out), "ntk_reverse_complement")
+    return out.raw[: len(seq)]
+
+
+def normalize_seq(seq: str, iupac: bool = False, ctx: Context = None) -> str:
+    """needletail.normalize_seq (reference src/python.rs:365-371)."""
+    return normalize(seq.encode("utf-8"), iupac, ctx).decode("utf-8")
+
+
+def kmers(seq: bytes, k: int) -> Iterator[bytes]:
+    """Sequence::kmers (reference src/kmer.rs:13-41): plain windows, pure slicing (nothing to accelerate)."""
+    for i in range(0, len(seq) - k + 1):
+        yield seq[i : i + k]
+
+
+def canonical_kmers_arrays(seq: bytes, k: int, ctx: Context = None):
+    c = _ctx(ctx)
+    if k < 1 or k > 255:
+        raise ValueError("k must be 1..255")
+    cap = max(len(seq), 1)
+    pos = np.empty(cap, dtype=np.uint64)
+    flg = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    L.check(L.lib().ntk_canonical_kmers(c._h, seq, len(seq), k, pos.ctypes.data, flg.ctypes.data, cap, C.byref(n)),
+            "ntk_canonical_kmers")
+    return pos[: n.value], flg[: n.value]
+
+
+def canonical_kmers(seq: bytes, k: int, reverse_complement: bytes, ctx: Context = None) -> List[Tuple[int, bytes, bool]]:
+    """Sequence::canonical_kmers(k, &rc) (reference src/sequence.rs:237-239, src/kmer.rs:48-130): items
+    (pos, slice, is_rc) with the slice drawn from `seq` or from the caller's `reverse_complement`."""
+    rc = reverse_complement
+    pos, flg = canonical_kmers_arrays(seq, k, ctx)
+    out = []
+    for p, f in zip(pos.tolist(), flg.tolist()):
+        out.append((p, rc[len(rc) - p - k : len(rc) - p] if f else seq[p : p + k], bool(f)))
+    return out
+
+
+def bit_kmers_arrays(seq: bytes, k: int, canonical: bool, ctx: Context = None):
+    c = _ctx(ctx)
+    if k < 1 or k > 32:
+        raise ValueError("k must be 1..32")
+    cap = max(len(seq), 1)
+    pos = np.empty(cap, dtype=np.uint64)
+    val = np.empty(cap, dtype=np.uint64)
+    flg = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    L.check(L.lib().ntk_bit_kmers(c._h, seq, len(seq), k, int(canonical), pos.ctypes.data, val.ctypes.data,
+                                  flg.ctypes.data, cap, C.byref(n)), "ntk_bit_kmers")
+    return pos[: n.value], val[: n.value], flg[: n.value]
+
+
+def bit_kmers(seq: bytes, k: int, canonical: bool, ctx: Context = None) -> List[Tuple[int, Tuple[int, int], bool]]:
+    """Sequence::bit_kmers(k, canonical) (reference src/sequence.rs:250-252, src/bitkmer.rs:72-109)."""
+    pos, val, flg = bit_kmers_arrays(seq, k, canonical, ctx)
+    return [(p, (v, k), bool(f)) for p, v, f in zip(pos.tolist(), val.tolist(), flg.tolist())]

@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
         L.ntko_reduce_batch.argtypes = [C.POINTER(Stats), C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int]
         L.ntko_reduce_batch_mt.restype = C.c_int
         L.ntko_reduce_batch_mt.argtypes = [C.POINTER(Stats), C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
+        L.ntko_count_batch_mt.restype = C.c_int
+        L.ntko_count_batch_mt.argtypes = [u64p, u64p, C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
         L.ntko_reduce_fused.restype = C.c_int
         L.ntko_reduce_fused.argtypes = [C.POINTER(Stats), C.c_void_p, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
         L.ntko_splitmix64_at.restype = C.c_uint64
@@ -259,6 +261,18 @@ def reduce_batch(buf: np.ndarray, offsets: np.ndarray, gap: int, k: int, path: i
     if rc:
         raise ValueError("ntko_reduce_batch failed")
     return st.as_dict()
+
+
+def count_batch(buf: np.ndarray, offsets: np.ndarray, gap: int, k: int, path: int, pre: int, threads: int = 1):
+    """(n_total, n_fwd) by the reference benchmark's own loop (benches/benchmark.rs:32-41)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nt, nf = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().ntko_count_batch_mt(C.byref(nt), C.byref(nf), buf.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                   gap, k, path, pre, threads)
+    if rc:
+        raise ValueError("ntko_count_batch_mt failed")
+    return int(nt.value), int(nf.value)
 
 
 def reduce_fused(buf, k: int, canonical: bool, tie_rc: bool, accept_u: bool) -> dict:

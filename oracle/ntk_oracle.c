@@ -428,6 +428,84 @@ int ntko_reduce_record(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, i
     return 0;
 }
 
+/* The reference benchmark's own per-record loop (benches/benchmark.rs:32-41 / :55-64): walk the iterator and
+ * count items and `!was_rc` items - no value is folded, exactly the work the reference times. */
+int ntko_count_record(uint64_t *n_total, uint64_t *n_fwd, const uint8_t *seq, size_t n, uint8_t k, int path, int pre)
+{
+    if (k < 1 || (path != NTKO_PATH_BYTES_CANONICAL && k > 32)) return -1;
+    uint8_t *tmp = NULL;
+    const uint8_t *cur = seq;
+    size_t cn = n;
+    if (pre == NTKO_PRE_STRIP_RETURNS) {
+        tmp = (uint8_t *)malloc(n ? n : 1);
+        int borrowed;
+        cn = ntko_strip_returns(seq, n, tmp, &borrowed);
+        cur = borrowed ? seq : tmp;
+    } else if (pre == NTKO_PRE_NORMALIZE || pre == NTKO_PRE_NORMALIZE_IUPAC) {
+        tmp = (uint8_t *)malloc(n ? n : 1);
+        int changed;
+        cn = ntko_normalize(seq, n, pre == NTKO_PRE_NORMALIZE_IUPAC, tmp, &changed);
+        cur = changed ? tmp : seq;
+    }
+    uint64_t nt = 0, nf = 0;
+    if (path == NTKO_PATH_BYTES_CANONICAL) {
+        uint8_t *rc = (uint8_t *)malloc(cn ? cn : 1);
+        ntko_reverse_complement(cur, cn, rc);
+        ntko_canonical_kmers it;
+        ntko_ck_new(&it, cur, cn, rc, cn, k);
+        size_t pos; const uint8_t *sl; int f;
+        while (ntko_ck_next(&it, &pos, &sl, &f)) { nt++; nf += !f; }
+        free(rc);
+    } else {
+        ntko_bit_nucl_kmer it;
+        ntko_bnk_new(&it, cur, cn, k, path == NTKO_PATH_BITS_CANONICAL);
+        size_t pos; ntko_bitkmer km; int f;
+        while (ntko_bnk_next(&it, &pos, &km, &f)) { nt++; nf += !f; }
+    }
+    free(tmp);
+    *n_total += nt; *n_fwd += nf;
+    return 0;
+}
+
+typedef struct {
+    uint64_t nt, nf;
+    const uint8_t *seq; const uint64_t *offsets; size_t r0, r1, gap; uint8_t k; int path, pre;
+} cnt_job;
+
+static void *cnt_run(void *p)
+{
+    cnt_job *j = (cnt_job *)p;
+    j->nt = j->nf = 0;
+    for (size_t r = j->r0; r < j->r1; r++) {
+        size_t b = j->offsets[r], e = j->offsets[r + 1];
+        size_t len = e - b >= j->gap ? e - b - j->gap : 0;
+        ntko_count_record(&j->nt, &j->nf, j->seq + b, len, j->k, j->path, j->pre);
+    }
+    return NULL;
+}
+
+int ntko_count_batch_mt(uint64_t *n_total, uint64_t *n_fwd, const uint8_t *seq, const uint64_t *offsets,
+                        size_t n_records, size_t gap, uint8_t k, int path, int pre, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    cnt_job *jobs = (cnt_job *)calloc((size_t)n_threads, sizeof(cnt_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].seq = seq; jobs[t].offsets = offsets; jobs[t].gap = gap;
+        jobs[t].r0 = n_records * (size_t)t / (size_t)n_threads;
+        jobs[t].r1 = n_records * (size_t)(t + 1) / (size_t)n_threads;
+        jobs[t].k = k; jobs[t].path = path; jobs[t].pre = pre;
+        if (n_threads == 1) cnt_run(&jobs[t]); else pthread_create(&th[t], NULL, cnt_run, &jobs[t]);
+    }
+    *n_total = 0; *n_fwd = 0;
+    for (int t = 0; t < n_threads; t++) {
+        if (n_threads > 1) pthread_join(th[t], NULL);
+        *n_total += jobs[t].nt; *n_fwd += jobs[t].nf;
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
 int ntko_reduce_batch(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,
                       size_t gap, uint8_t k, int path, int pre)
 {

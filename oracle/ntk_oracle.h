@@ -143,6 +143,12 @@ void ntko_stats_merge(ntko_stats *dst, const ntko_stats *src);
  * k must be 1..32 (values are folded into a u64).  Returns 0, or -1 on bad arguments. */
 int ntko_reduce_record(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, int path, int pre);
 
+/* The reference benchmark's own loop (benches/benchmark.rs:32-41,55-64): iterate and count items and
+ * `!was_rc` items only.  This is what bench.py's cpu_baseline times. */
+int ntko_count_record(uint64_t *n_total, uint64_t *n_fwd, const uint8_t *seq, size_t n, uint8_t k, int path, int pre);
+int ntko_count_batch_mt(uint64_t *n_total, uint64_t *n_fwd, const uint8_t *seq, const uint64_t *offsets,
+                        size_t n_records, size_t gap, uint8_t k, int path, int pre, int n_threads);
+
 /* Records concatenated in `seq`; record r = seq[offsets[r] .. offsets[r+1] - gap).  `gap` is the
  * number of separator bytes after every record (1 in the device batch layout, 0 for none). */
 int ntko_reduce_batch(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,

@@ -1,0 +1,319 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+Bit-exact is the bar (integer k-mers, flags, counts).  Run with `pytest -m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import needletail_amd as nt  # noqa: E402
+import oracle as O  # noqa: E402  (the checker)
+from _fastx import fasta_raw_seqs, fastq_raw_seqs  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    c = nt.Context(0)
+    yield c
+    c.close()
+
+
+def to_dev(buf: bytes):
+    n = len(buf)
+    t = torch.full(((n + 1023) // 1024 * 1024 + 1024,), 0x41, dtype=torch.uint8, device="cuda")  # 'A' padding: must be ignored
+    if n:
+        t[:n] = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    return t
+
+
+def gpu_reduce(ctx, buf: bytes, k, path, pre):
+    t = to_dev(buf)
+    ctx.accum_reset()
+    ctx.reduce_device(t, len(buf), k, path, pre)
+    return ctx.accum_read()
+
+
+def assert_stats_equal(a, b, what=""):
+    for key in ("n_total", "n_fwd", "n_rc", "sum", "xor"):
+        assert a[key] == b[key], (what, key, a[key], b[key])
+    assert np.array_equal(a["hist"], b["hist"]), what
+
+
+MODES = [  # (path, pre, canonical, tie_rc, accept_u) for the oracle's fused formulation
+    (nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True, True),
+    (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, True, False, False),
+    (nt.PATH_BITS, nt.PRE_STRIP_RETURNS, False, False, False),
+    (nt.PATH_BITS_CANONICAL, nt.PRE_NORMALIZE_IUPAC, True, False, True),
+]
+
+
+# ---- compat face: reads like the reference's unit tests ------------------------------------------
+
+def test_normalize_kats(ctx):
+    # reference src/sequence.rs:316-344, :219-224
+    assert nt.normalize_opt(b"ACGTU", False, ctx) == (b"ACGTT", True)
+    assert nt.normalize_opt(b"acgtu", False, ctx) == (b"ACGTT", True)
+    assert nt.normalize_opt(b"N.N-N~N N", False, ctx) == (b"N-N-N-NN", True)
+    assert nt.normalize_opt(b"BDHVRYSWKM", True, ctx) == (b"BDHVRYSWKM", False)
+    assert nt.normalize_opt(b"bdhvryswkm", True, ctx) == (b"BDHVRYSWKM", True)
+    assert nt.normalize_opt(b"BDHVRYSWKM", False, ctx) == (b"NNNNNNNNNN", True)
+    assert nt.normalize_opt(b"bdhvryswkm", False, ctx) == (b"NNNNNNNNNN", True)
+    assert nt.normalize(b"ADGH", False, ctx) == b"ANGN"
+    assert nt.normalize(b"ADGH", True, ctx) == b"ADGH"
+    assert nt.normalize(b"ACGU", True, ctx) == b"ACGT"
+    assert nt.normalize(b"", False, ctx) == b""
+
+
+def test_python_facade_literals(ctx):
+    # reference test_python.py:101-149, :36-41
+    n = lambda s, iupac=False: nt.normalize_seq(s, iupac, ctx)
+    assert n("ACGTU") == "ACGTT" and n("acgtu") == "ACGTT"
+    assert n("BDHVRYSWKM") == "NNNNNNNNNN" and n("BDHVRYSWKM", True) == "BDHVRYSWKM" and n("bdhvryswkm", True) == "BDHVRYSWKM"
+    assert n("N-N-N-N") == "N-N-N-N" and n("N.N.N.N") == "N-N-N-N" and n("N~N~N~N") == "N-N-N-N"
+    for ws in " \t\n\r":
+        assert n(ws.join("NNNN")) == "NNNN"
+    for junk in "!@#$%^&*|":
+        assert n(junk.join("NNNN")) == "NNNNNNN"
+    assert n("N9N5N1N") == "NNNNNNN"
+    assert n("AGCTGYrtcga", True) == "AGCTGYRTCGA" and n("AGCTGYRTCGA") == "AGCTGNNTCGA"
+    rc = lambda s: nt.reverse_complement(s, ctx)
+    assert rc("a") == "t" and rc("c") == "g" and rc("g") == "c" and rc("n") == "n"
+    assert rc("atcg") == "cgat" and rc("ATCG") == "CGAT"
+    assert nt.reverse_complement(b"AACC", ctx) == b"GGTT"  # reference src/sequence.rs:200
+
+
+def test_normalize_strip_revcomp_random(ctx):
+    rng = np.random.default_rng(3)
+    for n in (1, 15, 16, 17, 4095, 4096, 4097, 70001):
+        seq = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        for iupac in (False, True):
+            assert nt.normalize_opt(seq, iupac, ctx) == O.normalize(seq, iupac)
+        s, borrowed = O.strip_returns(seq)
+        assert nt.strip_returns(seq, ctx) == (seq if borrowed else s)
+        assert nt.reverse_complement(seq, ctx) == O.reverse_complement(seq)
+    clean = b"ACGTNACGT-" * 1000
+    assert nt.normalize_opt(clean, False, ctx) == (clean, False)
+    assert nt.strip_returns(clean, ctx) is clean
+
+
+def test_canonical_kmers_kats(ctx):
+    # reference src/kmer.rs:171-226
+    seq = b"AGCT"
+    got = nt.canonical_kmers(seq, 1, nt.reverse_complement(seq, ctx), ctx)
+    assert [(k, f) for _, k, f in got] == [(b"A", False), (b"C", True), (b"C", False), (b"A", True)]
+    seq = b"AGCTA"
+    assert [k for _, k, _ in nt.canonical_kmers(seq, 2, nt.reverse_complement(seq, ctx), ctx)] == [b"AG", b"GC", b"AG", b"TA"]
+    seq = b"AGNTA"
+    assert [(p, k) for p, k, _ in nt.canonical_kmers(seq, 2, nt.reverse_complement(seq, ctx), ctx)] == [(0, b"AG"), (3, b"TA")]
+    # palindrome reports true on the byte path; mixed case compares raw bytes
+    assert nt.canonical_kmers(b"AGCT", 4, b"AGCT", ctx) == [(0, b"AGCT", True)]
+    seq = b"acgTT"
+    assert nt.canonical_kmers(seq, 3, O.reverse_complement(seq), ctx) == [(0, b"acg", False), (1, b"Acg", True), (2, b"AAc", True)]
+
+
+def test_bit_kmers_kats(ctx):
+    # reference src/bitkmer.rs:193-251
+    assert [v for _, (v, _), _ in nt.bit_kmers(b"AGCT", 1, False, ctx)] == [0, 2, 1, 3]
+    assert [v for _, (v, _), _ in nt.bit_kmers(b"ACNGT", 2, False, ctx)] == [0b0001, 0b1011]
+    assert [v for _, (v, _), _ in nt.bit_kmers(b"ACNG", 2, False, ctx)] == [1]
+    assert [v for _, (v, _), _ in nt.bit_kmers(b"AC", 2, False, ctx)] == [1]
+    assert nt.bit_kmers(b"ACGTA", 3, False, ctx) == [(0, (6, 3), False), (1, (27, 3), False), (2, (44, 3), False)]
+    assert nt.bit_kmers(b"TA", 3, False, ctx) == []
+    assert nt.bit_kmers(b"AGCT", 4, True, ctx) == [(0, (39, 4), False)]  # palindrome reports false on the bit path
+
+
+def test_compat_iterators_random(ctx):
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b"ACGTACGTACGTacgtNnUuRY-\n", dtype=np.uint8)
+    for trial in range(40):
+        n = int(rng.integers(0, 3000))
+        seq = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        k = int(rng.integers(1, 33))
+        canonical = bool(rng.integers(0, 2))
+        p, v, f = nt.bit_kmers_arrays(seq, k, canonical, ctx)
+        op, ov, of = O.bit_kmers_arrays(seq, k, canonical)
+        assert np.array_equal(p, op) and np.array_equal(v, ov) and np.array_equal(f, of), (trial, n, k)
+        kb = int(rng.integers(1, 80))
+        p, f = nt.canonical_kmers_arrays(seq, kb, ctx)
+        op, of = O.canonical_kmers_arrays(seq, O.reverse_complement(seq), kb)
+        assert np.array_equal(p, op) and np.array_equal(f, of), (trial, n, kb)
+    with pytest.raises(ValueError):
+        nt.bit_kmers(b"ACGT", 0, True, ctx)
+    with pytest.raises(ValueError):
+        nt.bit_kmers(b"ACGT", 33, True, ctx)
+
+
+# ---- batch face, reduce mode ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 20, 21, 22, 1023, 1024, 1025, 2047, 5000, 65536 + 7])
+def test_reduce_edge_lengths(ctx, n):
+    rng = np.random.default_rng(n + 1)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTACGTN\n", dtype=np.uint8)
+    buf = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+    for k in (1, 4, 16, 17, 21, 31, 32):
+        for path, pre, canon, tie, u in MODES:
+            want = O.reduce_fused(buf, k, canon, tie, u)
+            assert_stats_equal(gpu_reduce(ctx, buf, k, path, pre), want, (n, k, path, pre))
+
+
+@pytest.mark.parametrize("k", list(range(1, 33)))
+def test_reduce_all_k_synthetic(ctx, k):
+    buf = O.synth_reads(0x5EED0002, 0, 3000, 150, 4).tobytes()
+    for path, pre, canon, tie, u in MODES[:3]:
+        want = O.reduce_fused(buf, k, canon, tie, u)
+        assert_stats_equal(gpu_reduce(ctx, buf, k, path, pre), want, (k, path))
+
+
+def test_reduce_random_bytes_all_classes(ctx):
+    rng = np.random.default_rng(99)
+    for trial in range(6):
+        buf = bytes(rng.integers(0, 256, 200_000, dtype=np.uint8))
+        mix = np.frombuffer(b"ACGTacgtUuNn\n \t", dtype=np.uint8)
+        buf2 = bytes(mix[rng.integers(0, len(mix), 200_000)])
+        for b in (buf, buf2):
+            for k in (3, 21, 32):
+                for path, pre, canon, tie, u in MODES:
+                    assert_stats_equal(gpu_reduce(ctx, b, k, path, pre), O.reduce_fused(b, k, canon, tie, u), (trial, k, path))
+
+
+def test_launch_geometry_invariance(ctx):
+    buf = O.synth_reads(0x5EED0002, 100, 20000, 150, 1).tobytes()
+    want = O.reduce_fused(buf, 21, True, True, True)
+    try:
+        for blocks, threads in ((0, 1024), (1, 256), (3, 512), (7, 1024), (512, 256), (2048, 256), (100000, 256)):
+            ctx.set_launch(blocks, threads)
+            assert_stats_equal(gpu_reduce(ctx, buf, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), want, (blocks, threads))
+    finally:
+        ctx.set_launch(0, 1024)
+
+
+def test_unsupported_and_bad_args_are_errors(ctx):
+    t = to_dev(b"ACGT" * 100)
+    with pytest.raises(nt.NtkError) as e:
+        ctx.reduce_device(t, 400, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+    assert e.value.status == 6
+    for k in (0, 33):
+        with pytest.raises(nt.NtkError) as e:
+            ctx.reduce_device(t, 400, k, nt.PATH_BITS, nt.PRE_NONE)
+        assert e.value.status == 1
+    with pytest.raises(nt.NtkError) as e:
+        ctx.reduce_device(t.data_ptr() + 1, 100, 5, nt.PATH_BITS, nt.PRE_NONE)
+    assert e.value.status == 2
+
+
+# ---- whole-file pins through the pinned-batch face (reference benches/benchmark.rs:43-44,66-67) -----------
+
+def _run_records(ctx, recs, k, path, pre, batch_bytes=1 << 18):
+    ctx.accum_reset()
+    batches = [ctx.batch(batch_bytes, 4096) for _ in range(3)]
+    cur = 0
+    for r in recs:
+        if not batches[cur].append(r, pre):
+            batches[cur].submit(k, path, pre)
+            cur = (cur + 1) % len(batches)
+            batches[cur].wait()
+            assert batches[cur].append(r, pre)
+    batches[cur].submit(k, path, pre)
+    for b in batches:
+        b.wait()
+        b.release()
+    return ctx.accum_read()
+
+
+def test_28s_whole_file_pins(ctx, golden_dir):
+    recs = fasta_raw_seqs(open(os.path.join(golden_dir, "28S.fasta"), "rb").read())
+    st = _run_records(ctx, recs, 31, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE_IUPAC)
+    assert (st["n_total"], st["n_fwd"]) == (718_007, 350_983)
+    st = _run_records(ctx, recs, 31, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS)
+    assert (st["n_total"], st["n_fwd"]) == (718_007, 350_983)
+    assert_stats_equal(st, O.reduce_records(recs, 31, O.PATH_BITS_CANONICAL, O.PRE_STRIP_RETURNS), "28S bits")
+    # README program (reference src/lib.rs:11-38): k=4 AAAA count
+    st = _run_records(ctx, recs, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    assert st["hist"][0] == 8_108
+    assert_stats_equal(st, O.reduce_records(recs, 4, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), "28S readme")
+
+
+def test_fastq_head_pins(ctx, golden_dir):
+    recs = fastq_raw_seqs(open(os.path.join(golden_dir, "PRJNA271013_head.fq"), "rb").read())
+    st = _run_records(ctx, recs, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    assert_stats_equal(st, O.reduce_records(recs, 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), "fq bytes")
+    assert st["n_total"] == 209_965 and st["sum"] == 0x047AD82A7ED0CABA
+
+
+# ---- materialise mode ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("k,path", [(5, nt.PATH_BITS), (16, nt.PATH_BITS_CANONICAL), (21, nt.PATH_BITS_CANONICAL), (32, nt.PATH_BITS_CANONICAL)])
+def test_materialize_dense(ctx, k, path):
+    buf = O.synth_reads(0x5EED0003, 7, 400, 150, 8).tobytes()
+    n = len(buf)
+    t = to_dev(buf)
+    nt_ = (n + 1023) // 1024 * 1024
+    vals = torch.zeros(nt_, dtype=torch.int64, device="cuda")
+    v16 = torch.zeros(nt_ // 16, dtype=torch.int16, device="cuda")
+    r16 = torch.zeros(nt_ // 16, dtype=torch.int16, device="cuda")
+    ctx.materialize_device(t, n, k, path, nt.PRE_NONE, vals, v16, r16)
+    ctx.synchronize()
+    vals = vals.cpu().numpy().view(np.uint64)
+    v16 = v16.cpu().numpy().view(np.uint16)
+    r16 = r16.cpu().numpy().view(np.uint16)
+    e = np.arange(n)
+    valid = (v16[e // 16] >> (15 - e % 16)) & 1
+    rcb = (r16[e // 16] >> (15 - e % 16)) & 1
+    # oracle per record
+    recs = buf.split(b"\n")[:-1]
+    start = 0
+    for r in recs:
+        pos, val, flg = O.bit_kmers_arrays(r, k, path == nt.PATH_BITS_CANONICAL)
+        ends = start + pos.astype(np.int64) + (k - 1)
+        got_ends = e[start : start + len(r) + 1][valid[start : start + len(r) + 1] == 1]
+        assert np.array_equal(got_ends, ends)
+        assert np.array_equal(vals[ends], val)
+        assert np.array_equal(rcb[ends].astype(np.uint8), flg)
+        start += len(r) + 1
+
+
+# ---- synthetic generator and BASELINE-size properties ----------------------------------------------------
+
+def test_device_synth_matches_cpu_generator(ctx):
+    n_reads, L = 5000, 150
+    t = torch.zeros(n_reads * (L + 1) + 64, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0002, 123, n_reads, L, 1, t)
+    ctx.synchronize()
+    got = t[: n_reads * (L + 1)].cpu().numpy()
+    assert np.array_equal(got, O.synth_reads(0x5EED0002, 123, n_reads, L, 1))
+
+
+def test_full_size_properties_config2(ctx):
+    """BASELINE.json configs[1]: 10M x 150 bp, k=21 canonical, checked through size-independent properties:
+    (1) a sample prefix equals the oracle exactly; (2) linearity: whole == sum of record-aligned parts;
+    (3) reverse-complementing every read leaves histogram / sum / xor unchanged and swaps n_fwd <-> n_rc (k odd)."""
+    n_reads, L, k = 10_000_000, 150, 21
+    stride = L + 1
+    nbytes = n_reads * stride
+    t = torch.empty(nbytes + 1024, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0002, 0, n_reads, L, 1, t)
+    path, pre = nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE
+    ctx.accum_reset(); ctx.reduce_device(t, nbytes, k, path, pre); whole = ctx.accum_read()
+    assert whole["n_total"] == whole["n_fwd"] + whole["n_rc"] == int(whole["hist"].sum())
+    assert 0 < whole["n_total"] <= n_reads * (L - k + 1)
+    # (1) sample
+    sample = 20_000
+    ctx.accum_reset(); ctx.reduce_device(t, sample * stride, k, path, pre); part = ctx.accum_read()
+    assert_stats_equal(part, O.reduce_fused(O.synth_reads(0x5EED0002, 0, sample, L, 1), k, True, True, True), "sample")
+    # (2) linearity over three unequal record-aligned parts (16-B aligned cuts: 16 | 151*16)
+    a = 16 * 100_003  # reads; a*stride is a multiple of 16
+    b = 16 * 400_001
+    ctx.accum_reset()
+    for lo, hi in ((0, a), (a, b), (b, n_reads)):
+        ctx.reduce_device(t.data_ptr() + lo * stride, (hi - lo) * stride, k, path, pre)
+    assert_stats_equal(ctx.accum_read(), whole, "linearity")
+    # (3) reverse-complement invariance
+    t2 = torch.empty_like(t)
+    ctx.reverse_complement_records_device(t, t2, n_reads, L, stride)
+    ctx.accum_reset(); ctx.reduce_device(t2, nbytes, k, path, pre); rcst = ctx.accum_read()
+    assert rcst["n_total"] == whole["n_total"] and rcst["n_fwd"] == whole["n_rc"] and rcst["n_rc"] == whole["n_fwd"]
+    assert rcst["sum"] == whole["sum"] and rcst["xor"] == whole["xor"] and np.array_equal(rcst["hist"], whole["hist"])

@@ -1,0 +1,121 @@
+"""CPU check of the scan kernel's per-lane bit manipulation: tests/emu/emu_scan.cpp compiles the same
+source the HIP kernels use (needletail_amd/csrc/ntk_tile.hpp) for the host and emulates one wave64 in
+lock-step; results are compared with the oracle.  (The GPU parity tests proper are in test_gpu_parity.py.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(EMU_DIR, "libntk_emu.so")
+    src = os.path.join(EMU_DIR, "emu_scan.cpp")
+    hdr = os.path.join(HERE, "..", "needletail_amd", "csrc", "ntk_tile.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
+    L = C.CDLL(so)
+    L.emu_scan.restype = C.c_int
+    L.emu_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emu_encode16.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    return L
+
+
+def emu_scan(L, buf: bytes, k, canon, tie_rc, accept_u, tpw=3, materialize=False):
+    n = len(buf)
+    npad = (n + 15) // 16 * 16
+    arr = np.frombuffer(buf + b"\xAA" * (npad - n), dtype=np.uint8).copy()  # garbage in the 16-B padding
+    out = np.zeros(4 + 4096, dtype=np.uint64)
+    nt = (n + 1023) // 1024 * 1024
+    vals = np.zeros(max(nt, 1), dtype=np.uint64) if materialize else None
+    v16 = np.zeros(max(nt // 16, 1), dtype=np.uint16) if materialize else None
+    r16 = np.zeros(max(nt // 16, 1), dtype=np.uint16) if materialize else None
+    rc = L.emu_scan(arr.ctypes.data, n, npad, k, int(canon), int(tie_rc), int(accept_u), tpw, out.ctypes.data,
+                    vals.ctypes.data if materialize else None, v16.ctypes.data if materialize else None,
+                    r16.ctypes.data if materialize else None)
+    assert rc == 0
+    st = {"n_total": int(out[0]), "n_fwd": int(out[1]), "n_rc": int(out[0] - out[1]), "sum": int(out[2]),
+          "xor": int(out[3]), "hist": out[4:].copy()}
+    return (st, vals, v16, r16) if materialize else st
+
+
+def assert_stats_equal(a, b, ctx=""):
+    for key in ("n_total", "n_fwd", "n_rc", "sum", "xor"):
+        assert a[key] == b[key], (ctx, key, a[key], b[key])
+    assert np.array_equal(a["hist"], b["hist"]), ctx
+
+
+def test_encode16_all_bytes(emu):
+    out = np.zeros(3, dtype=np.uint32)
+    for accept_u in (0, 1):
+        for b0 in range(256):
+            for slot in (0, 5, 15):
+                raw = bytearray(b"ACGTACGTACGTACGT")
+                raw[slot] = b0
+                emu.emu_encode16(bytes(raw), accept_u, out.ctypes.data)
+                code, rcode, bad = (int(x) for x in out)
+                good = bytes([b0]) in (b"A", b"C", b"G", b"T", b"a", b"c", b"g", b"t") or (accept_u and b0 in b"Uu")
+                assert bool((bad >> (15 - slot)) & 1) == (not good), (accept_u, b0, slot)
+                assert bad & ~(1 << (15 - slot)) == 0
+                if good:
+                    exp = 3 if b0 in b"Uu" else O.lib().ntko_nuc2bit(b0)
+                    assert (code >> (30 - 2 * slot)) & 3 == exp
+                    assert (rcode >> (2 * slot)) & 3 == 3 - exp
+
+
+@pytest.mark.parametrize("k", list(range(1, 33)))
+def test_emu_vs_oracle_synthetic(emu, k):
+    buf = O.synth_reads(0x5EED0002, 0, 40, 150, 8).tobytes()  # ~0.8% N, '\n' separators
+    for canon, tie_rc, accept_u in ((1, 1, 1), (1, 0, 0), (0, 0, 0)):
+        want = O.reduce_fused(buf, k, bool(canon), bool(tie_rc), bool(accept_u))
+        for tpw in (1, 2, 7):
+            got = emu_scan(emu, buf, k, canon, tie_rc, accept_u, tpw)
+            assert_stats_equal(got, want, (k, canon, tie_rc, accept_u, tpw))
+
+
+def test_emu_vs_literal_reference_chain(emu, golden_dir):
+    from _fastx import fastq_raw_seqs
+    recs = fastq_raw_seqs(open(os.path.join(golden_dir, "PRJNA271013_head.fq"), "rb").read())[:300]
+    buf = b"".join(r + b"\n" for r in recs)
+    for k in (4, 21, 31):
+        want = O.reduce_records(recs, k, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE)
+        assert_stats_equal(emu_scan(emu, buf, k, 1, 1, 1), want, ("bytes", k))
+        want = O.reduce_records(recs, k, O.PATH_BITS_CANONICAL, O.PRE_NONE)
+        assert_stats_equal(emu_scan(emu, buf, k, 1, 0, 0), want, ("bits", k))
+
+
+def test_emu_random_alphabet_and_lengths(emu):
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTacgtACGTACGTNnUuRY-\n\x00\xff", dtype=np.uint8)
+    for trial in range(60):
+        n = int(rng.integers(0, 2500))
+        buf = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        k = int(rng.integers(1, 33))
+        for canon, tie_rc, accept_u in ((1, 1, 1), (1, 0, 0), (0, 0, 1)):
+            want = O.reduce_fused(buf, k, bool(canon), bool(tie_rc), bool(accept_u))
+            got = emu_scan(emu, buf, k, canon, tie_rc, accept_u, int(rng.integers(1, 4)))
+            assert_stats_equal(got, want, (trial, n, k, canon, tie_rc, accept_u))
+
+
+def test_emu_materialize_matches_bit_kmers(emu):
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTACGTACGTacgtN", dtype=np.uint8)
+    for k, canonical in ((3, True), (16, True), (17, False), (21, True), (32, True)):
+        seq = bytes(alphabet[rng.integers(0, len(alphabet), 1500)])
+        st, vals, v16, r16 = emu_scan(emu, seq, k, canonical, 0, 0, 2, materialize=True)
+        pos, val, flg = O.bit_kmers_arrays(seq, k, canonical)
+        e = np.arange(len(seq))
+        valid = (v16[e // 16] >> (15 - e % 16)) & 1
+        rcb = (r16[e // 16] >> (15 - e % 16)) & 1
+        ends = e[valid == 1]
+        assert np.array_equal(ends - (k - 1), pos.astype(np.int64))
+        assert np.array_equal(vals[ends], val)
+        assert np.array_equal(rcb[ends].astype(np.uint8), flg)
