@@ -130,8 +130,8 @@ int ntk_accum_bind_device(ntk_ctx *ctx, uint64_t *d_words);
  *   d_values[e]                     emitted value (canonical or forward), undefined where invalid
  *   d_valid16[e/16] bit (15 - e%16) window is emitted
  *   d_rc16[e/16]    bit (15 - e%16) flag (is_rc / was_rc)
- * The reference's `pos` is e - (k-1) - record_start.  Arrays must hold round_up(n_bytes,1024)
- * values / round_up(n_bytes,1024)/16 u16 each.  d_values may be NULL (flags only). */
+ * The reference's `pos` is e - (k-1) - record_start.  d_values holds round_up(n_bytes,16) u64, d_valid16 and
+ * d_rc16 hold ceil(n_bytes/16) u16 each.  d_values may be NULL (flags only). */
 int ntk_materialize_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p,
                            uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16);   /* async */
 

@@ -186,15 +186,18 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     if (!d_seq || ((uintptr_t)d_seq & 15)) return NTK_ERR_BAD_ARG;
     const int threads = c->launch_threads;
     const int waves_per_block = threads / 64;
-    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : c->n_cu * (1024 / threads);
+    // auto: 32 waves per CU (the kernel needs <= 64 VGPRs), e.g. 2 x 1024-thread blocks - measured best (profiles/r01_launch_sweep_first.jsonl)
+    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : c->n_cu * 2 * (1024 / threads);
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     scan_args_set_k(a, p->k);
     a.seq = d_seq;
     a.n_bytes = n;
-    a.n_tiles = (n + kTileBytes - 1) / kTileBytes;
+    a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
     a.values = d_values; a.valid16 = d_valid16; a.rc16 = d_rc16;
-    const uint64_t kMaxTilesPerLaunch = (uint64_t)1 << 26;  // 64 GiB of sequence per launch
+    // per launch: tiles_per_wave <= 2^17 keeps 32-bit buffer offsets (tpw * 992 B) and the per-block u32 histogram
+    // cells (<= 16 waves * tpw * 992 windows) from overflowing
+    const uint64_t kMaxTilesPerLaunch = (uint64_t)blocks_max * waves_per_block << 17;
     for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
         const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
         const uint64_t tiles = te - tb;
@@ -221,7 +224,7 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
             c->ev_used.emplace_back(e0, e1);
         }
         if (reduce) {
-            hipLaunchKernelGGL(fold_kernel, dim3(kHistBins / 256), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
                                (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
             HIPCHK(hipGetLastError());
         }
@@ -615,7 +618,7 @@ int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int ca
     Mode m;
     int rc = resolve_mode(&p, true, &m);
     if (rc) return rc;
-    const uint64_t nt = (n + kTileBytes - 1) / kTileBytes * kTileBytes;
+    const uint64_t nt = (n + 15) / 16 * 16;
     if ((rc = ensure_scratch(c, 0, nt))) return rc;
     if ((rc = ensure_scratch(c, 1, nt * 8))) return rc;
     if ((rc = ensure_scratch(c, 2, nt / 8))) return rc;

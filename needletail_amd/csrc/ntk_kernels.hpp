@@ -19,37 +19,44 @@ namespace ntk {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Cross-lane "value held by the previous lane"; lane 0 receives lane 63 of `prev_tile`.
-// DPP wave_shr:1 / wave_ror:1 are single VALU moves on gfx9-family (gfx950 included).
+// Cross-lane "value the previous lane holds": DPP wave_shr:1 (lane 0 reads 0), a single VALU move that the
+// compiler folds into the consuming VOP2 where it can (v_and_b32_dpp).  gfx9-family DPP, available on gfx950.
 constexpr int kDppWaveShr1 = 0x138;
-constexpr int kDppWaveRor1 = 0x13C;
-#ifndef NTK_NO_DPP
-__device__ __forceinline__ uint32_t lane_prev(uint32_t cur, uint32_t prev_tile)
-{
-    uint32_t rot = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)prev_tile, kDppWaveRor1, 0xf, 0xf, false);
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)rot, (int)cur, kDppWaveShr1, 0xf, 0xf, false);
-}
+struct DevXL {
+#ifdef NTK_V_ANDDPP
+    // (previous lane's x) & mask as ONE v_and_b32_dpp; the s_nop covers the VALU-write -> DPP-read hazard that hipcc
+    // cannot see inside an asm statement (x was usually produced by the immediately preceding v_alignbit).
+    __device__ __forceinline__ uint32_t prev_and(int, uint32_t x, uint32_t mask_vgpr) const
+    {
+        uint32_t r;
+        asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(mask_vgpr));
+        return r;
+    }
 #else
-__device__ __forceinline__ uint32_t lane_prev(uint32_t cur, uint32_t prev_tile)
-{
-    uint32_t up = __shfl_up(cur, 1, 64);
-    uint32_t last = __shfl(prev_tile, 63, 64);
-    return (threadIdx.x & 63) ? up : last;
-}
+    __device__ __forceinline__ uint32_t prev_and(int s, uint32_t x, uint32_t mask) const { return prev(s, x) & mask; }
 #endif
+    __device__ __forceinline__ uint32_t prev(int, uint32_t x) const
+    {
+#ifndef NTK_NO_DPP
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kDppWaveShr1, 0xf, 0xf, true);
+#else
+        const uint32_t up = __shfl_up(x, 1, 64);
+        return (threadIdx.x & 63) ? up : 0u;
+#endif
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // sinks
 // ---------------------------------------------------------------------------------------------
 template <int KW>
 struct ReduceSink {
-    static constexpr bool kReduce = true;
     uint64_t sum = 0, xr = 0;
     uint32_t n_fwd = 0, n_valid = 0;
     uint32_t *hist;
     uint32_t bin_shift;
 
-    __device__ __forceinline__ void begin_tile(uint64_t, uint32_t inval16) { n_valid += __popc(~inval16 & 0xFFFFu); }
+    __device__ __forceinline__ void begin_tile(int64_t, uint32_t inval16, bool) { n_valid += __popc(~inval16 & 0xFFFFu); }
     __device__ __forceinline__ void emit(int, bool valid, bool take_fwd, uint32_t hi, uint32_t lo)
     {
         if (valid) {
@@ -65,20 +72,22 @@ struct ReduceSink {
 
 template <int KW>
 struct MaterializeSink {
-    static constexpr bool kReduce = false;
     uint64_t *values;
     uint16_t *valid16, *rc16;
-    uint64_t base = 0;     // global byte index of this lane's first base in the current tile
+    int64_t base = 0;     // global byte index of this lane's first base in the current tile
+    uint64_t n_bytes = 0;
     uint32_t inval = 0, rcbits = 0;
+    bool skip = true;     // halo lanes and slots past the end of the input own no output
 
-    __device__ __forceinline__ void begin_tile(uint64_t lane_base, uint32_t inval16) { base = lane_base; inval = inval16; rcbits = 0; }
+    __device__ __forceinline__ void begin_tile(int64_t lane_base, uint32_t inval16, bool halo) { base = lane_base; inval = inval16; rcbits = 0; skip = halo || lane_base >= (int64_t)n_bytes; }
     __device__ __forceinline__ void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
     {
-        if (values) values[base + (uint64_t)j] = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+        if (values && !skip) values[base + j] = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
         rcbits |= (take_fwd ? 0u : 1u) << (15 - j);
     }
     __device__ __forceinline__ void end_tile()
     {
+        if (skip) return;
         const uint32_t v = ~inval & 0xFFFFu;
         valid16[base >> 4] = (uint16_t)v;
         rc16[base >> 4] = (uint16_t)(rcbits & v);
@@ -86,43 +95,11 @@ struct MaterializeSink {
 };
 
 // ---------------------------------------------------------------------------------------------
-// the scan kernel
-//   KW       1: k <= 16 (32-bit values)   2: 17 <= k <= 32 (64-bit values)
-//   CANON    emit min(fwd, revcomp) with the strand flag; else the forward value, flag false
-//   TIE_RC   fwd == rc reports flag true (byte path, reference src/kmer.rs:124-128);
-//            false: flag false (bit path, reference src/bitkmer.rs:138-142)
-//   ACCEPT_U U/u is a base coding T (records went through normalize)
-// Work split: every wave streams its own contiguous run of 1-KiB tiles; a lane owns the 16 windows
-// that END at its 16 bytes and takes the preceding k-1 <= 31 bases from the two previous lanes (DPP),
-// lanes 0/1 from the previous tile of the same wave (registers) - so no byte is fetched twice except
-// one 1-KiB look-back tile per wave run.
+// the scan kernel (template flags: see lane_tile in ntk_tile.hpp; ACCEPT_U: U/u is a base coding T because the
+// records went through normalize).  Work split: every wave streams its own contiguous run of tiles (992 emitting
+// bytes each) with the next tile's load in flight while the current one is processed; no byte is fetched from HBM
+// twice (the 32 halo bytes of a tile come back from L2).
 // ---------------------------------------------------------------------------------------------
-struct LaneHist {  // what must survive from the previous tile for the halo
-    uint32_t code = 0, code1 = 0, rcode = 0, rcode1 = 0, bad = 0xFFFFu, bad1 = 0xFFFFu;
-};
-
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, class Sink>
-__device__ __forceinline__ void process_tile(const ScanArgs &a, Sink &sink, LaneHist &ph, u32x4 raw,
-                                             uint64_t lane_base, bool emit)
-{
-    Enc en = encode16<ACCEPT_U>(Raw16{raw.x, raw.y, raw.z, raw.w});
-    // bytes at or beyond n_bytes are breaks (the last 16-B line may carry allocation padding)
-    if (lane_base + 16 > a.n_bytes) {
-        const uint32_t keep = lane_base >= a.n_bytes ? 0u : (uint32_t)(a.n_bytes - lane_base);
-        en.bad |= 0xFFFFu >> keep;
-    }
-    const uint32_t c1 = lane_prev(en.code, ph.code), c2 = lane_prev(c1, ph.code1);
-    const uint32_t r1 = lane_prev(en.rcode, ph.rcode), r2 = lane_prev(r1, ph.rcode1);
-    const uint32_t b1 = lane_prev(en.bad, ph.bad), b2 = lane_prev(b1, ph.bad1);
-    ph.code = en.code; ph.code1 = c1; ph.rcode = en.rcode; ph.rcode1 = r1; ph.bad = en.bad; ph.bad1 = b1;
-    if (!emit) return;
-    TileWords tw;
-    tw.W[0] = c2; tw.W[1] = c1; tw.W[2] = en.code;
-    tw.R[0] = en.rcode; tw.R[1] = r1; tw.R[2] = r2;
-    tw.bad48 = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;
-    emit_windows<KW, CANON, TIE_RC>(a, sink, tw, lane_base);
-}
-
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE>
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
@@ -137,7 +114,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         sink.hist = s_hist;
         sink.bin_shift = a.bin_shift;
     } else {
-        sink.values = a.values; sink.valid16 = a.valid16; sink.rc16 = a.rc16;
+        sink.values = a.values; sink.valid16 = a.valid16; sink.rc16 = a.rc16; sink.n_bytes = a.n_bytes;
     }
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -148,31 +125,29 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     if (t1 > a.tile_end) t1 = a.tile_end;
 
     if (t0 < t1) {
-        // wave-uniform buffer descriptor over [first look-back tile, end of input): hardware bounds
-        // checking returns 0 (a break byte) beyond the padded end.
-        const uint64_t tstart = t0 ? t0 - 1 : 0;
-        const uint64_t cbase = (uint64_t)a.seq + tstart * kTileBytes;
-        uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - tstart * kTileBytes;
-        if (rem > 0xFFFFFFFFull) rem = 0xFFFFFFFFull;
+        // wave-uniform buffer descriptor starting 32 bytes (the halo) before the run; hardware bounds checking
+        // returns 0 (a break byte) past the padded end, and for the "negative" halo offsets of the very first run.
+        const uint64_t run_byte = t0 * kTileStride;
+        const uint32_t halo = t0 ? 32u : 0u;
+        const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
+        uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - (run_byte - halo);
+        if (rem > 0xFFFFFF00ull) rem = 0xFFFFFF00ull;
         const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
         const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
         const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
 
-        LaneHist ph;
-        uint32_t voff = lane * 16u;
-        uint64_t lane_base = tstart * kTileBytes + lane * 16u;
+        DevXL xl;
+        const bool halo_lane = lane < (uint32_t)kHaloLanes;
+        uint32_t voff = lane * 16u - (32u - halo);  // wraps (out of range -> 0) for the halo lanes of the first run
+        int64_t lane_base = (int64_t)run_byte - 32 + lane * 16;
         u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-        if (t0) {  // look-back tile: only its halo is needed
-            u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileBytes, 0, 0);
-            process_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, ph, cur, lane_base, false);
-            cur = nxt; voff += kTileBytes; lane_base += kTileBytes;
-        }
         for (uint64_t t = t0; t < t1; t++) {
-            u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileBytes, 0, 0);
-            process_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, ph, cur, lane_base, true);
-            cur = nxt; voff += kTileBytes; lane_base += kTileBytes;
+            const u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);
+            const bool tail = (t + 1) * kTileStride > a.n_bytes;
+            lane_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
+            cur = nxt; voff += kTileStride; lane_base += kTileStride;
         }
     }
 
@@ -202,22 +177,38 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 }
 
 // Sums the per-block partials into the ctx accumulators (same stream, after the scan kernel).
-__global__ void fold_kernel(const uint32_t *part_hist, const uint64_t *part_scalars, int nblocks, uint64_t *acc)
+// Grid: kFoldBinGroups x kFoldRowGroups blocks sum disjoint (bin range, row subset) pieces and add them with one
+// u64 atomic per bin; one extra block reduces the scalar partials.  (A single pass over <= 8 MiB, a few microseconds.)
+constexpr int kFoldThreads = 256, kFoldBinGroups = kHistBins / kFoldThreads, kFoldRowGroups = 32;
+constexpr int kFoldBlocks = kFoldBinGroups * kFoldRowGroups + 1;
+__global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part_hist, const uint64_t *part_scalars, int nblocks,
+                                                            uint64_t *acc)
 {
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin < kHistBins) {
+    if (blockIdx.x < kFoldBinGroups * kFoldRowGroups) {
+        const int bin = (blockIdx.x % kFoldBinGroups) * kFoldThreads + threadIdx.x;
         uint64_t s = 0;
-        for (int b = 0; b < nblocks; b++) s += part_hist[(size_t)b * kHistBins + bin];
-        acc[8 + bin] += s;
+#pragma unroll 8
+        for (int b = blockIdx.x / kFoldBinGroups; b < nblocks; b += kFoldRowGroups) s += part_hist[(size_t)b * kHistBins + bin];
+        if (s) atomicAdd((unsigned long long *)&acc[8 + bin], (unsigned long long)s);
+        return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
-        for (int b = 0; b < nblocks; b++) {
-            tv += part_scalars[b * 4 + 0]; tf += part_scalars[b * 4 + 1];
-            ts += part_scalars[b * 4 + 2]; tx ^= part_scalars[b * 4 + 3];
-        }
-        acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx;
-        for (int i = 0; i < 64; i++) acc[8 + kHistBins + i] += (tx >> i) & 1;  // summable form of the xor
+    __shared__ uint64_t s_red[kFoldThreads / 64][4];
+    uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+    for (int b = threadIdx.x; b < nblocks; b += kFoldThreads) {
+        tv += part_scalars[b * 4 + 0]; tf += part_scalars[b * 4 + 1];
+        ts += part_scalars[b * 4 + 2]; tx ^= part_scalars[b * 4 + 3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tv += __shfl_xor(tv, o, 64); tf += __shfl_xor(tf, o, 64); ts += __shfl_xor(ts, o, 64); tx ^= __shfl_xor(tx, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = tv; s_red[threadIdx.x >> 6][1] = tf; s_red[threadIdx.x >> 6][2] = ts; s_red[threadIdx.x >> 6][3] = tx; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        tv = tf = ts = tx = 0;
+        for (int w = 0; w < kFoldThreads / 64; w++) { tv += s_red[w][0]; tf += s_red[w][1]; ts += s_red[w][2]; tx ^= s_red[w][3]; }
+        if (threadIdx.x == 0) { acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx; }
+        acc[8 + kHistBins + threadIdx.x] += (tx >> threadIdx.x) & 1;  // summable form of the xor (one bit counter per lane)
     }
 }
 

@@ -12,13 +12,13 @@
 
 namespace ntk {
 
-constexpr int kTileBytes = 1024;  // one wave-tile = 64 lanes x 16 B = one coalesced dwordx4 load
+constexpr int kTileBytes = 1024;  // bytes LOADED per wave-tile = 64 lanes x 16 B = one coalesced dwordx4 load
 constexpr int kHistBins = 4096;
 
 struct ScanArgs {
     const uint8_t *seq;   // 16-B aligned, readable up to round_up(n_bytes, 16)
     uint64_t n_bytes;
-    uint64_t n_tiles;     // ceil(n_bytes / 1024)
+    uint64_t n_tiles;     // ceil(ceil(n_bytes / 16) / 62): tiles of 62 emitting 16-byte slots
     uint64_t tile_begin;  // first tile of this launch (a launch covers tiles [tile_begin, tile_end))
     uint64_t tile_end;
     uint32_t tiles_per_wave;
@@ -162,48 +162,67 @@ NTK_HD Enc encode16(Raw16 d)
 }
 
 // ---------------------------------------------------------------------------------------------
-// windows: everything one lane needs for its 16 window-end positions
-//   W  = {codes of lane-2, lane-1, own}            (forward stream, 48 bases)
-//   R  = {rcode of own, lane-1, lane-2}            (reverse-complement stream of the same 48 bases)
-//   bad48 = break bits, base i of lane-2 at bit 47-i ... own base i at bit 15-i
+// lane_tile: everything one lane does for one wave-tile.
+//
+// Tile geometry: a wave-tile is 64 lanes x 16 bytes, loaded with one coalesced dwordx4 per lane.  Lanes 0 and 1 only
+// provide the k-1 <= 31 base halo; lanes 2..63 each own the 16 windows that END at their 16 bytes.  Consecutive
+// tiles of a wave therefore advance by kTileStride = 62 x 16 = 992 bytes (the 32 halo bytes are re-read, an L2 hit),
+// and no state is carried from tile to tile.
+//
+// Cross-lane traffic is always "the value the previous lane holds in the same register" (DPP wave_shr:1 on the
+// device, XL::prev); slot ids only matter to the host emulation.
+//   forward value, right-aligned, window ending at own base j:
+//       lo = 32 bits ending at base j   = alignbit(C[lane-1], C[lane], 30-2j)        (independent of k)
+//       hi = the 2k-32 bits before that = lo of the PREVIOUS LANE, same j, masked     (one v_and_b32_dpp)
+//   reverse-complement value: R = per-lane word of the reverse-complement stream (group g = complement of base g);
+//       {R[lane], R[lane-1], R[lane-2]} >> sh_r (sh_r = 64-2k or 32-2k) is read at the k-independent bit offset 2(15-j).
 //   KW       1: k <= 16 (32-bit values)   2: 17 <= k <= 32 (64-bit values)
 //   CANON    emit min(fwd, revcomp) with the strand flag; else the forward value, flag false
 //   TIE_RC   fwd == rc reports flag true (byte path, reference src/kmer.rs:124-128);
 //            false: flag false (bit path, reference src/bitkmer.rs:138-142)
-// The window ending at own base j is the 2k bits of W ending 2(33+j) bits after the MSB of W[0]
-// (independent of k), and the 2k bits of R starting 2(15-j) bits in; R is pre-shifted right by sh_r once
-// per tile so that both are read right-aligned at k-independent offsets with v_alignbit.
 // ---------------------------------------------------------------------------------------------
-struct TileWords {
-    uint32_t W[3];
-    uint32_t R[3];
-    uint64_t bad48;
-};
+constexpr int kHaloLanes = 2;
+constexpr int kTileSlots = 64 - kHaloLanes;         // emitting 16-byte slots per tile
+constexpr int kTileStride = kTileSlots * 16;        // 992 bytes
 
-template <int KW, bool CANON, bool TIE_RC, class Sink>
-NTK_HD void emit_windows(const ScanArgs &a, Sink &sink, const TileWords &tw, uint64_t lane_base)
+enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 = 20, kNumSlots = 21 };
+
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, class Sink, class XL>
+NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t lane_base, bool halo_lane, bool tail_tile)
 {
+    Enc en = encode16<ACCEPT_U>(raw);
+    if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
+        const int64_t keep = (int64_t)a.n_bytes - lane_base;
+        en.bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
+    }
+    const uint32_t c1 = xl.prev(kSlotCode, en.code);
+    const uint32_t r1 = xl.prev(kSlotRcode, en.rcode);
+    const uint32_t b1 = xl.prev(kSlotBad, en.bad);
+    const uint32_t b2 = xl.prev(kSlotBad1, b1);
+
     // windows containing a break: OR every break bit over the k window-end positions that follow it
-    uint64_t bw = tw.bad48;
+    uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;
 #pragma unroll
     for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
-    const uint32_t inval = (uint32_t)bw & 0xFFFFu;
-    sink.begin_tile(lane_base, inval);
+    const uint32_t inval = halo_lane ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    sink.begin_tile(lane_base, inval, halo_lane);
 
     uint32_t Q[3];
-    Q[0] = tw.R[0] >> a.sh_r;
-    Q[1] = alignbit(tw.R[0], tw.R[1], a.sh_r);
-    Q[2] = KW == 2 ? alignbit(tw.R[1], tw.R[2], a.sh_r) : 0u;
+    Q[0] = en.rcode >> a.sh_r;
+    Q[1] = alignbit(en.rcode, r1, a.sh_r);
+    Q[2] = KW == 2 ? xl.prev(kSlotQ1, Q[1]) : 0u;  // == alignbit(R[lane-1], R[lane-2], sh_r)
+    uint32_t vbits = inval << 16;  // bit 31 = window ending at own base 0; one flag is shifted out per position
+    const uint32_t mask_hi_v = a.mask_hi;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         uint32_t fh = 0, fl, rh = 0, rl;
+        fl = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
         if (KW == 2) {
-            fl = win32(tw.W, 34 + 2 * j);
-            fh = win32(tw.W, 2 + 2 * j) & a.mask_hi;
+            fh = xl.prev_and(j, fl, mask_hi_v);
             rh = win32(Q, 2 * (15 - j)) & a.mask_hi;
             rl = win32(Q, 32 + 2 * (15 - j));
         } else {
-            fl = win32(tw.W, 34 + 2 * j) & a.mask_lo;
+            fl &= a.mask_lo;
             rl = win32(Q, 2 * (15 - j)) & a.mask_lo;
         }
         bool take_fwd = true;
@@ -215,7 +234,7 @@ NTK_HD void emit_windows(const ScanArgs &a, Sink &sink, const TileWords &tw, uin
                 take_fwd = TIE_RC ? (fl < rl) : (fl <= rl);
             }
         }
-        const bool valid = ((inval >> (15 - j)) & 1u) == 0u;
+        const bool valid = !__builtin_add_overflow(vbits, vbits, &vbits);  // v_add_co_u32: carry-out = the flag
         sink.emit(j, valid, take_fwd, take_fwd ? fh : rh, take_fwd ? fl : rl);
     }
     sink.end_tile();

@@ -23,39 +23,42 @@ template <int KW>
 struct HostSink {
     HostStats *st;
     uint32_t bin_shift;
-    uint64_t *values; uint16_t *valid16, *rc16;
-    uint64_t base = 0; uint32_t inval = 0, rcbits = 0;
-    void begin_tile(uint64_t lane_base, uint32_t inval16) { base = lane_base; inval = inval16; rcbits = 0; }
+    uint64_t *values; uint16_t *valid16, *rc16; uint64_t n_bytes = 0;
+    int64_t base = 0; uint32_t inval = 0, rcbits = 0; bool skip = true;
+    void begin_tile(int64_t lane_base, uint32_t inval16, bool halo) { base = lane_base; inval = inval16; rcbits = 0; skip = halo || lane_base >= (int64_t)n_bytes; }
     void emit(int j, bool valid, bool take_fwd, uint32_t hi, uint32_t lo)
     {
         const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
         if (valid) {
             st->n_total++; st->n_fwd += take_fwd; st->sum += v; st->xr ^= v; st->hist[v >> bin_shift]++;
         }
-        if (values) values[base + j] = v;
+        if (values && !skip) values[base + j] = v;
         rcbits |= (take_fwd ? 0u : 1u) << (15 - j);
     }
     void end_tile()
     {
+        if (skip) return;
         const uint32_t v = ~inval & 0xFFFFu;
         if (valid16) valid16[base >> 4] = (uint16_t)v;
         if (rc16) rc16[base >> 4] = (uint16_t)(rcbits & v);
     }
 };
 
-struct LaneHistE { uint32_t code = 0, code1 = 0, rcode = 0, rcode1 = 0, bad = 0xFFFFu, bad1 = 0xFFFFu; };
+// Host stand-in for DPP wave_shr:1: lanes are emulated in increasing order, so "the previous lane's value in the
+// same register" is simply what the previous lane stored in that slot (lane 0 reads 0, like bound_ctrl:0).
+struct EmuXL {
+    uint32_t last[kNumSlots];   // values written by the previous lane
+    uint32_t cur[kNumSlots];    // values written by the current lane
+    bool first_lane = true;
+    void next_lane(bool first) { if (!first) memcpy(last, cur, sizeof(last)); else memset(last, 0, sizeof(last)); first_lane = first; }
+    uint32_t prev(int slot, uint32_t x) { cur[slot] = x; return last[slot]; }
+    uint32_t prev_and(int slot, uint32_t x, uint32_t mask) { return prev(slot, x) & mask; }
+};
 
-// lane_prev over a whole wave: out[l] = l ? cur[l-1] : prev_tile[63]
-void lane_prev_wave(const uint32_t *cur, const uint32_t *prev_tile, uint32_t *out)
-{
-    out[0] = prev_tile[63];
-    for (int l = 1; l < 64; l++) out[l] = cur[l - 1];
-}
-
-Raw16 load16(const uint8_t *buf, uint64_t n_padded, uint64_t off)
+Raw16 load16(const uint8_t *buf, uint64_t n_padded, int64_t off)
 {
     uint8_t b[16];
-    for (int i = 0; i < 16; i++) b[i] = off + i < n_padded ? buf[off + i] : 0;  // buffer bounds check returns 0
+    for (int i = 0; i < 16; i++) b[i] = (off + i >= 0 && (uint64_t)(off + i) < n_padded) ? buf[off + i] : 0;  // buffer bounds check returns 0
     Raw16 r;
     memcpy(&r.x, b, 4); memcpy(&r.y, b + 4, 4); memcpy(&r.z, b + 8, 4); memcpy(&r.w, b + 12, 4);
     return r;
@@ -65,40 +68,19 @@ template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U>
 void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st, uint64_t *values,
          uint16_t *valid16, uint16_t *rc16)
 {
-    const uint64_t n_tiles = (n + kTileBytes - 1) / kTileBytes;
+    const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
     for (uint64_t t0 = 0; t0 < n_tiles; t0 += a.tiles_per_wave) {  // one wave per run of tiles
         uint64_t t1 = t0 + a.tiles_per_wave; if (t1 > n_tiles) t1 = n_tiles;
-        LaneHistE ph[64];
         HostSink<KW> sinks[64];
-        for (auto &s : sinks) { s.st = st; s.bin_shift = a.bin_shift; s.values = values; s.valid16 = valid16; s.rc16 = rc16; }
-        for (uint64_t t = t0 ? t0 - 1 : 0; t < t1; t++) {
-            const bool emit = t >= t0;
-            Enc en[64];
-            uint32_t code[64], rcode[64], bad[64], pc[64], pc1[64], pr[64], pr1[64], pb[64], pb1[64];
+        for (auto &s : sinks) { s.st = st; s.bin_shift = a.bin_shift; s.values = values; s.valid16 = valid16; s.rc16 = rc16; s.n_bytes = n; }
+        for (uint64_t t = t0; t < t1; t++) {
+            const bool tail = (t + 1) * kTileStride > n;
+            EmuXL xl;
             for (int l = 0; l < 64; l++) {
-                const uint64_t lane_base = t * kTileBytes + l * 16;
-                en[l] = encode16<ACCEPT_U>(load16(buf, n_padded, lane_base));
-                if (lane_base + 16 > n) {
-                    const uint32_t keep = lane_base >= n ? 0u : (uint32_t)(n - lane_base);
-                    en[l].bad |= 0xFFFFu >> keep;
-                }
-                code[l] = en[l].code; rcode[l] = en[l].rcode; bad[l] = en[l].bad;
-                pc[l] = ph[l].code; pc1[l] = ph[l].code1; pr[l] = ph[l].rcode; pr1[l] = ph[l].rcode1;
-                pb[l] = ph[l].bad; pb1[l] = ph[l].bad1;
-            }
-            uint32_t c1[64], c2[64], r1[64], r2[64], b1[64], b2[64];
-            lane_prev_wave(code, pc, c1); lane_prev_wave(c1, pc1, c2);
-            lane_prev_wave(rcode, pr, r1); lane_prev_wave(r1, pr1, r2);
-            lane_prev_wave(bad, pb, b1); lane_prev_wave(b1, pb1, b2);
-            for (int l = 0; l < 64; l++) {
-                ph[l].code = code[l]; ph[l].code1 = c1[l]; ph[l].rcode = rcode[l]; ph[l].rcode1 = r1[l];
-                ph[l].bad = bad[l]; ph[l].bad1 = b1[l];
-                if (!emit) continue;
-                TileWords tw;
-                tw.W[0] = c2[l]; tw.W[1] = c1[l]; tw.W[2] = code[l];
-                tw.R[0] = rcode[l]; tw.R[1] = r1[l]; tw.R[2] = r2[l];
-                tw.bad48 = ((uint64_t)b2[l] << 32) | ((uint64_t)b1[l] << 16) | bad[l];
-                emit_windows<KW, CANON, TIE_RC>(a, sinks[l], tw, t * kTileBytes + l * 16);
+                xl.next_lane(l == 0);
+                const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
+                lane_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sinks[l], xl, load16(buf, n_padded, lane_base), lane_base,
+                                                       l < kHaloLanes, tail);
             }
         }
     }

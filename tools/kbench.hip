@@ -1,0 +1,64 @@
+// kbench.hip — standalone A/B harness for the scan kernel (no python/torch): generates the bench workload in HBM,
+// times scan_kernel<2,canon,tie_rc,accept_u,reduce> with hipEvents and prints the reduced result so that variants
+// (built with different -D NTK_V_* toggles / compiler flags) can be compared for speed AND equality.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#include "../needletail_amd/csrc/ntk_kernels.hpp"
+
+using namespace ntk;
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const uint64_t reads = argc > 1 ? strtoull(argv[1], 0, 10) : 10000000ull;
+    const uint32_t k = argc > 2 ? atoi(argv[2]) : 21;
+    int blocks = argc > 3 ? atoi(argv[3]) : 512;
+    const int threads = argc > 4 ? atoi(argv[4]) : 1024;
+    const int iters = argc > 5 ? atoi(argv[5]) : 10;
+    const char *tag = argc > 6 ? argv[6] : "kbench";
+    const uint32_t L = 150;
+    const uint64_t n = reads * (L + 1);
+    uint8_t *d_seq; uint32_t *d_ph; uint64_t *d_ps, *d_acc;
+    CHK(hipMalloc(&d_seq, n + 4096));
+    hipLaunchKernelGGL(synth_reads_kernel, dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, 0, 0x5EED0002ull, 0ull, reads, L, 1u, d_seq);
+    CHK(hipDeviceSynchronize());
+    ScanArgs a; memset(&a, 0, sizeof(a));
+    scan_args_set_k(a, k);
+    a.seq = d_seq; a.n_bytes = n; a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots; a.tile_begin = 0; a.tile_end = a.n_tiles;
+    const int wpb = threads / 64;
+    uint64_t waves = (uint64_t)blocks * wpb; if (waves > a.n_tiles) waves = a.n_tiles;
+    const uint64_t tpw = (a.n_tiles + waves - 1) / waves;
+    blocks = (int)((a.n_tiles + tpw * wpb - 1) / (tpw * wpb));
+    a.tiles_per_wave = (uint32_t)tpw;
+    CHK(hipMalloc(&d_ph, (size_t)blocks * kHistBins * 4)); CHK(hipMalloc(&d_ps, (size_t)blocks * 32)); CHK(hipMalloc(&d_acc, (8 + kHistBins + 64) * 8));
+    a.part_hist = d_ph; a.part_scalars = d_ps;
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    for (int it = 0; it < iters + 2; it++) {
+        CHK(hipMemsetAsync(d_acc, 0, (8 + kHistBins + 64) * 8, 0));
+        CHK(hipEventRecord(e0, 0));
+        if (k > 16) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true>), dim3(blocks), dim3(threads), 0, 0, a);
+        else hipLaunchKernelGGL((scan_kernel<1, true, true, true, true>), dim3(blocks), dim3(threads), 0, 0, a);
+        CHK(hipEventRecord(e1, 0));
+        hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, 0, (const uint32_t *)d_ph, (const uint64_t *)d_ps, blocks, d_acc);
+        CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 2) ts.push_back(ms);
+    }
+    CHK(hipDeviceSynchronize());
+    std::vector<uint64_t> acc(8 + kHistBins + 64);
+    CHK(hipMemcpy(acc.data(), d_acc, acc.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t hh = 1469598103934665603ull;
+    for (int i = 0; i < kHistBins; i++) { hh ^= acc[8 + i]; hh *= 1099511628211ull; }
+    std::sort(ts.begin(), ts.end());
+    double avg = 0; for (float t : ts) avg += t; avg /= ts.size();
+    printf("%-28s k=%u grid=%dx%d  avg %.4f ms  min %.4f  med %.4f  | %.1f GB/s %.1f Gbases/s (avg) | n_total=%llu n_fwd=%llu sum=%llx xor=%llx hist=%llx\n",
+           tag, k, blocks, threads, avg, ts.front(), ts[ts.size() / 2], n / (avg * 1e-3) / 1e9, reads * L / (avg * 1e-3) / 1e9,
+           (unsigned long long)acc[0], (unsigned long long)acc[1], (unsigned long long)acc[3], (unsigned long long)acc[4], (unsigned long long)hh);
+    return 0;
+}

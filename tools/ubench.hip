@@ -1,0 +1,147 @@
+// ubench.hip — VALU instruction issue-rate microbenchmark on gfx950 (which 64-bit / cross-lane ops are full rate?).
+// Each kernel runs a long dependent-free stream of ONE instruction in 8 independent chains per lane; the reported
+// number is wave-instructions per cycle per SIMD (1/2 = full rate for a wave64 on a SIMD32).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <string>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+
+#define BENCH_KERNEL(NAME, BODY)                                                        \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed)           \
+    {                                                                                   \
+        uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;        \
+        uint32_t b0 = a0 ^ 0x1234, b1 = a1 ^ 0x2345, b2 = a2 ^ 0x3456, b3 = a3 ^ 0x4567;\
+        uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3;                                    \
+        uint32_t cnt = 0;                                                               \
+        for (int i = 0; i < ITERS; i++) { BODY }                                        \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + b0 + b1 + b2 + b3 + cnt + (uint32_t)(q0 + q1 + q2 + q3); \
+    }
+
+// 8 instructions per iteration in each body
+BENCH_KERNEL(k_add32, {
+    asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %3\n v_add_u32 %4, %4, %5\n v_add_u32 %6, %6, %7\n"
+                 "v_add_u32 %1, %1, %0\n v_add_u32 %3, %3, %2\n v_add_u32 %5, %5, %4\n v_add_u32 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_alignbit, {
+    asm volatile("v_alignbit_b32 %0, %0, %1, 7\n v_alignbit_b32 %2, %2, %3, 7\n v_alignbit_b32 %4, %4, %5, 7\n v_alignbit_b32 %6, %6, %7, 7\n"
+                 "v_alignbit_b32 %1, %1, %0, 9\n v_alignbit_b32 %3, %3, %2, 9\n v_alignbit_b32 %5, %5, %4, 9\n v_alignbit_b32 %7, %7, %6, 9\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_perm, {
+    asm volatile("v_perm_b32 %0, %0, %1, %1\n v_perm_b32 %2, %2, %3, %3\n v_perm_b32 %4, %4, %5, %5\n v_perm_b32 %6, %6, %7, %7\n"
+                 "v_perm_b32 %1, %1, %0, %0\n v_perm_b32 %3, %3, %2, %2\n v_perm_b32 %5, %5, %4, %4\n v_perm_b32 %7, %7, %6, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_bitop3, {
+    asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8\n v_bitop3_b32 %2, %2, %3, %4 bitop3:0xc8\n v_bitop3_b32 %4, %4, %5, %6 bitop3:0xc8\n v_bitop3_b32 %6, %6, %7, %0 bitop3:0xc8\n"
+                 "v_bitop3_b32 %1, %1, %0, %3 bitop3:0xc8\n v_bitop3_b32 %3, %3, %2, %5 bitop3:0xc8\n v_bitop3_b32 %5, %5, %4, %7 bitop3:0xc8\n v_bitop3_b32 %7, %7, %6, %1 bitop3:0xc8\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_dpp_shr, {
+    asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %4, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %5, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_dpp_rowshr, {
+    asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %5, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_lshr64, {
+    asm volatile("v_lshrrev_b64 %0, 3, %0\n v_lshrrev_b64 %1, 3, %1\n v_lshrrev_b64 %2, 3, %2\n v_lshrrev_b64 %3, 3, %3\n"
+                 "v_lshrrev_b64 %0, 5, %0\n v_lshrrev_b64 %1, 5, %1\n v_lshrrev_b64 %2, 5, %2\n v_lshrrev_b64 %3, 5, %3\n"
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)); })
+BENCH_KERNEL(k_lshladd64, {
+    asm volatile("v_lshl_add_u64 %0, %1, 0, %0\n v_lshl_add_u64 %1, %2, 0, %1\n v_lshl_add_u64 %2, %3, 0, %2\n v_lshl_add_u64 %3, %0, 0, %3\n"
+                 "v_lshl_add_u64 %0, %2, 0, %0\n v_lshl_add_u64 %1, %3, 0, %1\n v_lshl_add_u64 %2, %0, 0, %2\n v_lshl_add_u64 %3, %1, 0, %3\n"
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)); })
+BENCH_KERNEL(k_cmp64, {
+    asm volatile("v_cmp_lt_u64 vcc, %0, %1\n v_cmp_lt_u64 vcc, %1, %2\n v_cmp_lt_u64 vcc, %2, %3\n v_cmp_lt_u64 vcc, %3, %0\n"
+                 "v_cmp_lt_u64 vcc, %0, %2\n v_cmp_lt_u64 vcc, %1, %3\n v_cmp_lt_u64 vcc, %2, %0\n v_cmp_lt_u64 vcc, %3, %1\n"
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "vcc"); })
+BENCH_KERNEL(k_cmp32, {
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0\n"
+                 "v_cmp_lt_u32 vcc, %0, %2\n v_cmp_lt_u32 vcc, %1, %3\n v_cmp_lt_u32 vcc, %2, %0\n v_cmp_lt_u32 vcc, %3, %1\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc"); })
+BENCH_KERNEL(k_cmp_cndmask, {
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %4, %0, %1, vcc\n v_cmp_lt_u32 vcc, %2, %3\n v_cndmask_b32 %5, %2, %3, vcc\n"
+                 "v_cmp_lt_u32 vcc, %1, %2\n v_cndmask_b32 %6, %1, %2, vcc\n v_cmp_lt_u32 vcc, %3, %0\n v_cndmask_b32 %7, %3, %0, vcc\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "vcc"); })
+BENCH_KERNEL(k_addco, {
+    asm volatile("v_add_co_u32 %0, vcc, %0, %0\n v_add_co_u32 %1, vcc, %1, %1\n v_add_co_u32 %2, vcc, %2, %2\n v_add_co_u32 %3, vcc, %3, %3\n"
+                 "v_add_co_u32 %4, vcc, %4, %4\n v_add_co_u32 %5, vcc, %5, %5\n v_add_co_u32 %6, vcc, %6, %6\n v_add_co_u32 %7, vcc, %7, %7\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "vcc"); })
+BENCH_KERNEL(k_saveexec, {
+    asm volatile("v_add_co_u32 %0, vcc, %0, %0\n s_andn2_saveexec_b64 s[20:21], vcc\n v_add_u32 %1, %1, %2\n s_or_b64 exec, exec, s[20:21]\n"
+                 "v_add_co_u32 %3, vcc, %3, %3\n s_andn2_saveexec_b64 s[20:21], vcc\n v_add_u32 %2, %2, %1\n s_or_b64 exec, exec, s[20:21]\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc", "s20", "s21"); })
+BENCH_KERNEL(k_mulu64u32, {
+    asm volatile("v_mad_u64_u32 %0, vcc, %4, 1, %0\n v_mad_u64_u32 %1, vcc, %5, 1, %1\n v_mad_u64_u32 %2, vcc, %6, 1, %2\n v_mad_u64_u32 %3, vcc, %7, 1, %3\n"
+                 "v_mad_u64_u32 %0, vcc, %5, 1, %0\n v_mad_u64_u32 %1, vcc, %6, 1, %1\n v_mad_u64_u32 %2, vcc, %7, 1, %2\n v_mad_u64_u32 %3, vcc, %4, 1, %3\n"
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc"); })
+
+__global__ __launch_bounds__(256) void k_ldsadd(uint32_t *out, uint32_t seed)
+{
+    __shared__ uint32_t h[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+    __syncthreads();
+    uint32_t x = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            x = x * 1664525u + 1013904223u;
+            atomicAdd(&h[(x >> 20) & 4095], 1u);
+        }
+    }
+    __syncthreads();
+    out[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_ldsadd_lcg_only(uint32_t *out, uint32_t seed)
+{
+    uint32_t x = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x, acc = 0;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { x = x * 1664525u + 1013904223u; acc ^= (x >> 20) & 4095; }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+int main()
+{
+    uint32_t *d;
+    const int blocks = 256 * 8;  // 8 blocks of 4 waves per CU -> 8 waves per SIMD
+    CHK(hipMalloc(&d, (size_t)blocks * 256 * 4));
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s CUs %d clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
+    struct B { const char *name; void (*fn)(uint32_t *, uint32_t); };
+    B list[] = {{"v_add_u32", k_add32}, {"v_alignbit_b32", k_alignbit}, {"v_perm_b32", k_perm}, {"v_bitop3_b32", k_bitop3},
+                {"v_mov_dpp wave_shr", k_dpp_shr}, {"v_mov_dpp row_shr", k_dpp_rowshr}, {"v_lshrrev_b64", k_lshr64},
+                {"v_lshl_add_u64", k_lshladd64}, {"v_cmp_lt_u64", k_cmp64}, {"v_cmp_lt_u32", k_cmp32},
+                {"cmp32+cndmask pair", k_cmp_cndmask}, {"v_add_co_u32", k_addco}, {"addco+saveexec+add+restore (per 4)", k_saveexec},
+                {"v_mad_u64_u32", k_mulu64u32}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    for (auto &b : list) {
+        hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, d, 1u);
+        CHK(hipDeviceSynchronize());
+        float best = 1e9;
+        for (int r = 0; r < 3; r++) {
+            CHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, d, 2u + r);
+            CHK(hipEventRecord(e1));
+            CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        // wave-instructions per SIMD: blocks*4 waves / (CUs*4 SIMDs) * ITERS * 8
+        double winstr = (double)blocks * 4 / (prop.multiProcessorCount * 4) * ITERS * 8;
+        double ns_per = best * 1e6 / winstr;
+        printf("%-42s %8.3f ms  %7.3f ns per wave-instr per SIMD  (=%5.2f cycles @2.4GHz)\n", b.name, best, ns_per, ns_per * 2.4);
+    }
+    return 0;
+}
