@@ -85,6 +85,7 @@ struct ntk_ctx {
     uint64_t *d_acc = nullptr;      // accumulators in use (own or caller-bound)
     uint64_t *d_acc_own = nullptr;
     uint32_t *d_part_hist = nullptr;
+    uint32_t *d_work = nullptr;     // 8 work counters, one per 64-B line
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
@@ -195,17 +196,22 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     a.n_bytes = n;
     a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
     a.values = d_values; a.valid16 = d_valid16; a.rc16 = d_rc16;
-    // per launch: tiles_per_wave <= 2^17 keeps 32-bit buffer offsets (tpw * 992 B) and the per-block u32 histogram
-    // cells (<= 16 waves * tpw * 992 windows) from overflowing
-    const uint64_t kMaxTilesPerLaunch = (uint64_t)blocks_max * waves_per_block << 17;
+    // per launch: a shard holds <= 2^22 tiles so that the per-block u32 histogram cells (a block can at most drain its
+    // whole shard: 2^22 * 992 windows) and the u32 work counters cannot overflow
+    const uint64_t kMaxTilesPerLaunch = (uint64_t)8 << 22;
     for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
         const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
         const uint64_t tiles = te - tb;
-        uint64_t waves = (uint64_t)blocks_max * waves_per_block;
-        if (waves > tiles) waves = tiles;
-        const uint64_t tpw = (tiles + waves - 1) / waves;
-        const int blocks = (int)((tiles + tpw * waves_per_block - 1) / (tpw * waves_per_block));
-        a.tile_begin = tb; a.tile_end = te; a.tiles_per_wave = (uint32_t)tpw;
+        uint64_t chunk = tiles / ((uint64_t)blocks_max * waves_per_block * 4);  // >= ~4 pulls per wave, <= 16 tiles each
+        chunk = chunk < 1 ? 1 : (chunk > 16 ? 16 : chunk);
+        const uint64_t want_blocks = (tiles + chunk * waves_per_block - 1) / (chunk * waves_per_block);
+        const int blocks = (int)(want_blocks < (uint64_t)blocks_max ? want_blocks : (uint64_t)blocks_max);
+        a.tile_begin = tb; a.tile_end = te;
+        a.n_shards = blocks < 8 ? (uint32_t)blocks : 8u;
+        a.tiles_per_shard = (uint32_t)((tiles + a.n_shards - 1) / a.n_shards);
+        a.chunk_tiles = (uint32_t)chunk;
+        a.work_counters = c->d_work;
+        HIPCHK(hipMemsetAsync(c->d_work, 0, 8 * 64, c->stream));
         if (reduce) {
             int rc = ensure_partials(c, blocks);
             if (rc) return rc;
@@ -253,6 +259,7 @@ int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
     HIPCHK(hipMalloc(&c->d_acc_own, NTK_ACC_WORDS * sizeof(uint64_t)));
     c->d_acc = c->d_acc_own;
     HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    HIPCHK(hipMalloc(&c->d_work, 8 * 64));
     HIPCHK(hipMalloc(&c->d_lut, 4 * 256 * sizeof(uint16_t)));
     HIPCHK(hipHostMalloc(&c->h_pinned, 64 * 1024, hipHostMallocDefault));
     uint16_t *h = (uint16_t *)c->h_pinned;
@@ -303,6 +310,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
     if (c->d_part_scalars) (void)hipFree(c->d_part_scalars);
     if (c->d_acc_own) (void)hipFree(c->d_acc_own);
     if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_work) (void)hipFree(c->d_work);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);

@@ -61,10 +61,16 @@ struct ReduceSink {
     {
         if (valid) {
             const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+#ifndef NTK_ABL_NODIGEST
             sum += v;
             xr ^= v;
-            n_fwd += take_fwd ? 1u : 0u;
+#endif
+            n_fwd += take_fwd ? 1u : 0u;  // v_addc_co_u32 off the compare's carry mask
+#ifndef NTK_ABL_NOHIST
             atomicAdd(&hist[(uint32_t)(v >> bin_shift)], 1u);
+#else
+            n_valid += (uint32_t)(v >> bin_shift);
+#endif
         }
     }
     __device__ __forceinline__ void end_tile() {}
@@ -107,6 +113,9 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
     __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
 
+#ifdef NTK_V_CLOCKS
+    const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
     Sink sink;
     if constexpr (REDUCE) {
         for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
@@ -119,14 +128,31 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    const uint64_t t0 = a.tile_begin + gw * a.tiles_per_wave;
-    uint64_t t1 = t0 + a.tiles_per_wave;
-    if (t1 > a.tile_end) t1 = a.tile_end;
 
-    if (t0 < t1) {
-        // wave-uniform buffer descriptor starting 32 bytes (the halo) before the run; hardware bounds checking
-        // returns 0 (a break byte) past the padded end, and for the "negative" halo offsets of the very first run.
+    // Dynamic work distribution.  The CU arbitrates VALU issue between its resident waves by age, so with a static
+    // split the oldest waves race ahead and the youngest finish alone on an under-filled SIMD (measured: wave end
+    // times spread over 0.25..0.92 ms of a 0.92 ms kernel).  Instead every wave pulls chunks of tiles from a
+    // per-shard counter (8 shards ~ one per XCD, <= ~20 pulls/us each) until the shard is empty; tiles carry no
+    // state from their predecessor (halo lanes), so any wave can take any chunk.
+    const uint32_t shard = blockIdx.x % a.n_shards;
+    const uint64_t shard_begin = a.tile_begin + (uint64_t)shard * a.tiles_per_shard;
+    uint64_t shard_end = shard_begin + a.tiles_per_shard;
+    if (shard_end > a.tile_end) shard_end = a.tile_end;
+    uint32_t *ctr = a.work_counters + shard * 16;
+    const uint32_t shard_tiles = shard_begin < shard_end ? (uint32_t)(shard_end - shard_begin) : 0u;
+    DevXL xl;
+    const bool halo_lane = lane < (uint32_t)kHaloLanes;
+
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+    next = __builtin_amdgcn_readfirstlane(next);
+    while (next < shard_tiles) {
+        const uint64_t t0 = shard_begin + next;
+        uint64_t t1 = t0 + a.chunk_tiles;
+        if (t1 > shard_end) t1 = shard_end;
+        if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);  // in flight while this chunk is processed
+        // wave-uniform buffer descriptor starting 32 bytes (the halo) before the chunk; hardware bounds checking
+        // returns 0 (a break byte) past the padded end, and for the "negative" halo offsets of tile 0.
         const uint64_t run_byte = t0 * kTileStride;
         const uint32_t halo = t0 ? 32u : 0u;
         const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
@@ -138,9 +164,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
 
-        DevXL xl;
-        const bool halo_lane = lane < (uint32_t)kHaloLanes;
-        uint32_t voff = lane * 16u - (32u - halo);  // wraps (out of range -> 0) for the halo lanes of the first run
+        uint32_t voff = lane * 16u - (32u - halo);  // wraps (out of range -> 0) for the halo lanes of tile 0
         int64_t lane_base = (int64_t)run_byte - 32 + lane * 16;
         u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
         for (uint64_t t = t0; t < t1; t++) {
@@ -149,8 +173,19 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
             lane_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
             cur = nxt; voff += kTileStride; lane_base += kTileStride;
         }
+        next = __builtin_amdgcn_readfirstlane(next);
     }
 
+#ifdef NTK_V_CLOCKS
+    if ((threadIdx.x & 63) == 0 && a.values) {  // per-wave census: start, end, shader cycles, placement
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        a.values[w * 4 + 0] = dbg_w0; a.values[w * 4 + 1] = wall_clock64();
+        a.values[w * 4 + 2] = clock64() - dbg_c0; a.values[w * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
+    }
+#endif
     if constexpr (REDUCE) {
         // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
         uint64_t sum = sink.sum, xr = sink.xr, nf = sink.n_fwd, nv = sink.n_valid;

@@ -21,7 +21,10 @@ struct ScanArgs {
     uint64_t n_tiles;     // ceil(ceil(n_bytes / 16) / 62): tiles of 62 emitting 16-byte slots
     uint64_t tile_begin;  // first tile of this launch (a launch covers tiles [tile_begin, tile_end))
     uint64_t tile_end;
-    uint32_t tiles_per_wave;
+    uint32_t *work_counters;  // n_shards counters, 16 u32 apart (one per 64-B line), zeroed before the launch
+    uint32_t n_shards;        // min(8, grid): block b pulls tile chunks from shard b % n_shards
+    uint32_t tiles_per_shard; // shard s owns tiles [tile_begin + s*tiles_per_shard, +tiles_per_shard) clipped to tile_end
+    uint32_t chunk_tiles;     // tiles handed out per pull
     uint32_t k;
     uint32_t sh_r;        // right shift of the reverse-complement stream: 64-2k (KW=2) / 32-2k (KW=1)
     uint32_t mask_hi;     // KW=2: (1 << (2k-32)) - 1
@@ -190,7 +193,11 @@ enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 =
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, class Sink, class XL>
 NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t lane_base, bool halo_lane, bool tail_tile)
 {
+#ifdef NTK_ABL_NOENC
+    Enc en; en.code = raw.x; en.rcode = raw.y; en.bad = raw.z & raw.w & 0xFFFFu;  // ablation: no encode
+#else
     Enc en = encode16<ACCEPT_U>(raw);
+#endif
     if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
         const int64_t keep = (int64_t)a.n_bytes - lane_base;
         en.bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
@@ -213,6 +220,11 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
     Q[2] = KW == 2 ? xl.prev(kSlotQ1, Q[1]) : 0u;  // == alignbit(R[lane-1], R[lane-2], sh_r)
     uint32_t vbits = inval << 16;  // bit 31 = window ending at own base 0; one flag is shifted out per position
     const uint32_t mask_hi_v = a.mask_hi;
+#ifdef NTK_ABL_NOPOS
+    sink.emit(0, (vbits ^ Q[0] ^ Q[1] ^ Q[2] ^ c1) == 0x12345u, true, mask_hi_v, c1);  // ablation: no per-position work
+    sink.end_tile();
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         uint32_t fh = 0, fl, rh = 0, rl;

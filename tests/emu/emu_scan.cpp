@@ -69,8 +69,8 @@ void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStat
          uint16_t *valid16, uint16_t *rc16)
 {
     const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
-    for (uint64_t t0 = 0; t0 < n_tiles; t0 += a.tiles_per_wave) {  // one wave per run of tiles
-        uint64_t t1 = t0 + a.tiles_per_wave; if (t1 > n_tiles) t1 = n_tiles;
+    {   // tiles carry no state from their predecessor, so the order in which waves pull them is irrelevant
+        const uint64_t t0 = 0, t1 = n_tiles;
         HostSink<KW> sinks[64];
         for (auto &s : sinks) { s.st = st; s.bin_shift = a.bin_shift; s.values = values; s.valid16 = valid16; s.rc16 = rc16; s.n_bytes = n; }
         for (uint64_t t = t0; t < t1; t++) {
@@ -99,7 +99,7 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     scan_args_set_k(a, k);
-    a.n_bytes = n; a.tiles_per_wave = tiles_per_wave ? tiles_per_wave : 1;
+    a.n_bytes = n; (void)tiles_per_wave;
     HostStats *st = new HostStats();
     const int kw = k > 16 ? 2 : 1;
 #define EMU_CASE(KW, C, T, U) \

@@ -31,16 +31,20 @@ int main(int argc, char **argv)
     scan_args_set_k(a, k);
     a.seq = d_seq; a.n_bytes = n; a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots; a.tile_begin = 0; a.tile_end = a.n_tiles;
     const int wpb = threads / 64;
-    uint64_t waves = (uint64_t)blocks * wpb; if (waves > a.n_tiles) waves = a.n_tiles;
-    const uint64_t tpw = (a.n_tiles + waves - 1) / waves;
-    blocks = (int)((a.n_tiles + tpw * wpb - 1) / (tpw * wpb));
-    a.tiles_per_wave = (uint32_t)tpw;
+    const uint32_t chunk = argc > 7 ? atoi(argv[7]) : 16;
+    uint32_t *d_work; CHK(hipMalloc(&d_work, 512));
+    a.n_shards = blocks < 8 ? blocks : 8; a.tiles_per_shard = (uint32_t)((a.n_tiles + a.n_shards - 1) / a.n_shards);
+    a.chunk_tiles = chunk; a.work_counters = d_work;
     CHK(hipMalloc(&d_ph, (size_t)blocks * kHistBins * 4)); CHK(hipMalloc(&d_ps, (size_t)blocks * 32)); CHK(hipMalloc(&d_acc, (8 + kHistBins + 64) * 8));
     a.part_hist = d_ph; a.part_scalars = d_ps;
+#ifdef NTK_V_CLOCKS
+    uint64_t *d_dbg; CHK(hipMalloc(&d_dbg, (size_t)blocks * wpb * 32)); CHK(hipMemset(d_dbg, 0, (size_t)blocks * wpb * 32)); a.values = d_dbg;
+#endif
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     std::vector<float> ts;
     for (int it = 0; it < iters + 2; it++) {
         CHK(hipMemsetAsync(d_acc, 0, (8 + kHistBins + 64) * 8, 0));
+        CHK(hipMemsetAsync(d_work, 0, 512, 0));
         CHK(hipEventRecord(e0, 0));
         if (k > 16) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true>), dim3(blocks), dim3(threads), 0, 0, a);
         else hipLaunchKernelGGL((scan_kernel<1, true, true, true, true>), dim3(blocks), dim3(threads), 0, 0, a);
@@ -60,5 +64,31 @@ int main(int argc, char **argv)
     printf("%-28s k=%u grid=%dx%d  avg %.4f ms  min %.4f  med %.4f  | %.1f GB/s %.1f Gbases/s (avg) | n_total=%llu n_fwd=%llu sum=%llx xor=%llx hist=%llx\n",
            tag, k, blocks, threads, avg, ts.front(), ts[ts.size() / 2], n / (avg * 1e-3) / 1e9, reads * L / (avg * 1e-3) / 1e9,
            (unsigned long long)acc[0], (unsigned long long)acc[1], (unsigned long long)acc[3], (unsigned long long)acc[4], (unsigned long long)hh);
+#ifdef NTK_V_CLOCKS
+    {
+        const int blocks_ = blocks; blocks = blocks * wpb;  // census entries are per wave
+        std::vector<uint64_t> dbg((size_t)blocks * 4);
+        CHK(hipMemcpy(dbg.data(), d_dbg, dbg.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t tmin = ~0ull, tmax = 0; double life = 0, cyc = 0;
+        for (int b = 0; b < blocks; b++) { tmin = std::min(tmin, dbg[b * 4]); tmax = std::max(tmax, dbg[b * 4 + 1]); life += dbg[b * 4 + 1] - dbg[b * 4]; cyc += dbg[b * 4 + 2]; }
+        printf("   census: span %.4f ms, mean block life %.4f ms, mean concurrency %.1f blocks, mean shader clock %.3f GHz\n",
+               (tmax - tmin) * 1e-5, life / blocks * 1e-5, life / (double)(tmax - tmin), cyc / (life * 10.0));
+        // concurrency histogram over 20 time slices, and distinct (xcc, se, sh, cu) seen
+        std::vector<int> conc(20, 0);
+        std::vector<uint64_t> places;
+        for (int b = 0; b < blocks; b++) {
+            for (int s = 0; s < 20; s++) { uint64_t ts = tmin + (tmax - tmin) * (2 * s + 1) / 40; if (dbg[b * 4] <= ts && ts < dbg[b * 4 + 1]) conc[s]++; }
+            uint64_t id = dbg[b * 4 + 3]; uint32_t hw = (uint32_t)id, xcc = (uint32_t)(id >> 32) & 0xF;
+            places.push_back(((uint64_t)xcc << 16) | (hw & 0xFF00));
+        }
+        std::sort(places.begin(), places.end()); places.erase(std::unique(places.begin(), places.end()), places.end());
+        printf("   running blocks at 20 time slices:"); for (int s = 0; s < 20; s++) printf(" %d", conc[s]); printf("\n   distinct (xcc,se,sh,cu) places: %zu; first start offsets (us):", places.size());
+        std::vector<uint64_t> starts; for (int b = 0; b < blocks; b++) starts.push_back(dbg[b * 4] - tmin); std::sort(starts.begin(), starts.end());
+        for (int i = 0; i < blocks; i += blocks / 16) printf(" %.1f", starts[i] * 0.01); printf("\n");
+        std::vector<uint64_t> ends; for (int b = 0; b < blocks; b++) ends.push_back(dbg[b * 4 + 1] - tmin); std::sort(ends.begin(), ends.end());
+        printf("   wave end-time percentiles (ms): p0 %.3f p10 %.3f p25 %.3f p50 %.3f p75 %.3f p90 %.3f p100 %.3f\n", ends[0]*1e-5, ends[blocks/10]*1e-5, ends[blocks/4]*1e-5, ends[blocks/2]*1e-5, ends[blocks*3/4]*1e-5, ends[blocks*9/10]*1e-5, ends[blocks-1]*1e-5);
+        blocks = blocks_;
+    }
+#endif
     return 0;
 }

@@ -18,7 +18,9 @@ constexpr int ITERS = 4096;
         uint32_t b0 = a0 ^ 0x1234, b1 = a1 ^ 0x2345, b2 = a2 ^ 0x3456, b3 = a3 ^ 0x4567;\
         uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3;                                    \
         uint32_t cnt = 0;                                                               \
+        const uint64_t c0_ = clock64(), w0_ = wall_clock64();                           \
         for (int i = 0; i < ITERS; i++) { BODY }                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { out[1 << 20] = (uint32_t)(clock64() - c0_); out[(1 << 20) + 1] = (uint32_t)(wall_clock64() - w0_); } \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + b0 + b1 + b2 + b3 + cnt + (uint32_t)(q0 + q1 + q2 + q3); \
     }
 
@@ -114,7 +116,7 @@ int main()
 {
     uint32_t *d;
     const int blocks = 256 * 8;  // 8 blocks of 4 waves per CU -> 8 waves per SIMD
-    CHK(hipMalloc(&d, (size_t)blocks * 256 * 4));
+    CHK(hipMalloc(&d, (size_t)blocks * 256 * 4 + (8 << 20)));
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, 0));
     printf("device %s CUs %d clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
@@ -141,7 +143,9 @@ int main()
         // wave-instructions per SIMD: blocks*4 waves / (CUs*4 SIMDs) * ITERS * 8
         double winstr = (double)blocks * 4 / (prop.multiProcessorCount * 4) * ITERS * 8;
         double ns_per = best * 1e6 / winstr;
-        printf("%-42s %8.3f ms  %7.3f ns per wave-instr per SIMD  (=%5.2f cycles @2.4GHz)\n", b.name, best, ns_per, ns_per * 2.4);
+        uint32_t ck[2] = {0, 1}; hipMemcpy(ck, d + (1 << 20), 8, hipMemcpyDeviceToHost);
+        const double ghz = ck[0] / (ck[1] * 10.0);
+        printf("%-42s %8.3f ms  %7.3f ns per wave-instr per SIMD  clock %.3f GHz -> %5.2f cycles\n", b.name, best, ns_per, ghz, ns_per * ghz);
     }
     return 0;
 }
