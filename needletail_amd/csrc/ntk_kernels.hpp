@@ -168,7 +168,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         int64_t lane_base = (int64_t)run_byte - 32 + lane * 16;
         u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
         for (uint64_t t = t0; t < t1; t++) {
-            const u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);
+            u32x4 nxt = cur;
+            if (t + 1 < t1) nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);  // wave-uniform
             const bool tail = (t + 1) * kTileStride > a.n_bytes;
             lane_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
             cur = nxt; voff += kTileStride; lane_base += kTileStride;
