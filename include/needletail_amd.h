@@ -44,7 +44,9 @@ enum {
     NTK_ERR_NO_DEVICE = 4,   /* no usable gfx950 device                                         */
     NTK_ERR_CAPACITY = 5,    /* caller-provided output / batch capacity too small               */
     NTK_ERR_UNSUPPORTED = 6, /* combination not available on the device path (never falls back) */
-    NTK_ERR_NOMEM = 7
+    NTK_ERR_NOMEM = 7,
+    NTK_ERR_PARSE = 8,       /* FASTA/FASTQ parse error; ntk_reader_error() has kind / line / id / message */
+    NTK_EOF = 100            /* ntk_reader_next: no more records (not an error)                 */
 };
 const char *ntk_strerror(int status);
 int ntk_last_hip_error(void);
@@ -149,6 +151,38 @@ int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t 
 int ntk_batch_submit(ntk_ctx *ctx, ntk_batch *b, const ntk_params *p);  /* async: H2D + reduce */
 int ntk_batch_wait(ntk_ctx *ctx, ntk_batch *b);
 void ntk_batch_release(ntk_ctx *ctx, ntk_batch *b);
+
+/* ---- CPU producer: FastxReader-shaped record reader + the whole-file pipeline -------------------
+ * The FASTX parser stays on the CPU (BASELINE.json north_star).  ntk_reader_* mirrors parse_fastx_file /
+ * parse_fastx_reader and FastxReader::next (reference src/parser/mod.rs:85-163, src/parser/utils.rs:119-130):
+ * plain or gzip input, FASTA or FASTQ by first byte, one BORROWED record at a time (pointers are valid until the
+ * next call), the reference's error kinds.  ntk_scan_reader is the README program (reference src/lib.rs:15-35)
+ * on the GPU: read records, pack them into pinned batches (deleting the pre-step's whitespace class), overlap the
+ * H2D copies with the scan kernels, accumulate into the ctx. */
+typedef struct ntk_reader ntk_reader;
+typedef struct ntk_record {
+    const uint8_t *id;   uint64_t id_len;    /* SequenceRecord::id()       reference src/parser/record.rs:68-73  */
+    const uint8_t *seq;  uint64_t seq_len;   /* SequenceRecord::raw_seq()  reference src/parser/record.rs:78-83  */
+    const uint8_t *qual; uint64_t qual_len;  /* SequenceRecord::qual(); NULL for FASTA                          */
+    uint32_t format;                         /* 0 = FASTA, 1 = FASTQ                                            */
+    uint32_t reserved;
+    uint64_t line;                           /* SequenceRecord::start_line_number()                            */
+    uint64_t num_bases;                      /* SequenceRecord::num_bases()                                    */
+} ntk_record;
+enum { /* ParseErrorKind, reference src/errors.rs:26-44 */
+    NTK_PARSE_IO = 1, NTK_PARSE_UNKNOWN_FORMAT = 2, NTK_PARSE_INVALID_START = 3, NTK_PARSE_INVALID_SEPARATOR = 4,
+    NTK_PARSE_UNEQUAL_LENGTHS = 5, NTK_PARSE_UNEXPECTED_END = 6, NTK_PARSE_EMPTY_FILE = 7
+};
+/* On NTK_ERR_PARSE *out is still a valid handle (query ntk_reader_error, then close it). */
+int ntk_reader_open_file(const char *path, ntk_reader **out);
+int ntk_reader_open_memory(const uint8_t *data, uint64_t n, ntk_reader **out); /* data must outlive the reader */
+int ntk_reader_next(ntk_reader *r, ntk_record *rec);  /* NTK_OK, NTK_EOF or NTK_ERR_PARSE */
+int ntk_reader_error(ntk_reader *r, int *kind, uint64_t *line, char *msg, uint64_t msg_cap, char *id, uint64_t id_cap);
+void ntk_reader_close(ntk_reader *r);
+/* Drains the reader through n_batches (>= 2) pinned batches of batch_bytes each; results accumulate in the ctx
+ * (ntk_accum_reset / ntk_accum_read around it).  A record longer than a batch is NTK_ERR_CAPACITY. */
+int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t batch_bytes, uint32_t n_batches,
+                    uint64_t *n_records, uint64_t *n_bases);
 
 /* ---- compat face: the reference's per-sequence functions, eager ---------------------------------
  * Caller-allocated outputs; *_len out-params; outputs need capacity n unless stated. */

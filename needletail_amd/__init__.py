@@ -6,6 +6,7 @@ host-side mirror of the reference interface.  Importing the package does not nee
 from ._lib import (PATH_BITS, PATH_BITS_CANONICAL, PATH_BYTES_CANONICAL, PRE_NONE, PRE_NORMALIZE,
                    PRE_NORMALIZE_IUPAC, PRE_STRIP_RETURNS, NtkError)
 from .engine import Batch, Context, default_context
+from .parser import FastxReader, NeedletailError, Record, parse_fastx_file, parse_fastx_string, scan_file
 from .sequence import (bit_kmers, bit_kmers_arrays, canonical_kmers, canonical_kmers_arrays, kmers, normalize,
                        normalize_opt, normalize_seq, reverse_complement, strip_returns)
 
@@ -13,6 +14,7 @@ __all__ = [
     "Context", "Batch", "default_context", "NtkError",
     "PATH_BYTES_CANONICAL", "PATH_BITS", "PATH_BITS_CANONICAL",
     "PRE_NONE", "PRE_STRIP_RETURNS", "PRE_NORMALIZE", "PRE_NORMALIZE_IUPAC",
+    "parse_fastx_file", "parse_fastx_string", "FastxReader", "Record", "NeedletailError", "scan_file",
     "normalize", "normalize_opt", "normalize_seq", "strip_returns", "reverse_complement",
     "kmers", "canonical_kmers", "canonical_kmers_arrays", "bit_kmers", "bit_kmers_arrays",
 ]

@@ -28,6 +28,8 @@ SYMBOLS = [
     "ntk_batch_release",
     "ntk_normalize", "ntk_strip_returns", "ntk_reverse_complement", "ntk_canonical_kmers", "ntk_bit_kmers",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
+    "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_close",
+    "ntk_scan_reader",
 ]
 
 
@@ -38,6 +40,12 @@ class Params(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_total", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("sum", C.c_uint64),
                 ("xr", C.c_uint64), ("hist", C.c_uint64 * HIST_BINS)]
+
+
+class Record(C.Structure):
+    _fields_ = [("id", C.c_void_p), ("id_len", C.c_uint64), ("seq", C.c_void_p), ("seq_len", C.c_uint64),
+                ("qual", C.c_void_p), ("qual_len", C.c_uint64), ("format", C.c_uint32), ("reserved", C.c_uint32),
+                ("line", C.c_uint64), ("num_bases", C.c_uint64)]
 
 
 class NtkError(RuntimeError):
@@ -92,6 +100,13 @@ def lib() -> C.CDLL:
     L.ntk_bit_kmers.argtypes = [vp, C.c_char_p, u64, u32, i32, vp, vp, vp, u64, C.POINTER(u64)]
     L.ntk_synth_reads_device.argtypes = [vp, u64, u64, u64, u32, u32, vp]
     L.ntk_reverse_complement_records_device.argtypes = [vp, vp, vp, u64, u32, u32]
+    L.ntk_reader_open_file.argtypes = [C.c_char_p, pp]
+    L.ntk_reader_open_memory.argtypes = [C.c_char_p, u64, pp]
+    L.ntk_reader_next.argtypes = [vp, C.POINTER(Record)]
+    L.ntk_reader_error.argtypes = [vp, C.POINTER(i32), C.POINTER(u64), C.c_char_p, u64, C.c_char_p, u64]
+    L.ntk_reader_close.restype = None
+    L.ntk_reader_close.argtypes = [vp]
+    L.ntk_scan_reader.argtypes = [vp, vp, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("ntk_last_hip_error", "ntk_abi_version"):

@@ -288,6 +288,8 @@ const char *ntk_strerror(int s)
     case NTK_ERR_CAPACITY: return "output or batch capacity too small";
     case NTK_ERR_UNSUPPORTED: return "combination not supported on the device path (no CPU fallback exists)";
     case NTK_ERR_NOMEM: return "out of memory";
+    case NTK_ERR_PARSE: return "FASTA/FASTQ parse error (see ntk_reader_error)";
+    case NTK_EOF: return "end of input";
     default: return "unknown status";
     }
 }

@@ -1,0 +1,308 @@
+// ntk_fastx.cpp — see ntk_fastx.hpp.  Host-only C++ (zlib for gzip); part of libneedletail_amd.so.
+#include "ntk_fastx.hpp"
+
+#include <string.h>
+#include <zlib.h>
+
+namespace ntk {
+
+namespace {
+constexpr size_t kBufSize = 64 * 1024;  // reference src/parser/utils.rs:8
+
+size_t grow_to(size_t cur)  // reference src/parser/utils.rs:24-30
+{
+    return cur < ((size_t)1 << 23) ? cur * 2 : cur + ((size_t)1 << 23);
+}
+
+inline size_t trim_cr_len(const uint8_t *p, size_t n)  // reference src/parser/utils.rs:12-18
+{
+    return (n && p[n - 1] == '\r') ? n - 1 : n;
+}
+
+std::string escape_byte(uint8_t b)  // Rust's char::escape_default for the bytes that can show up here
+{
+    char tmp[16];
+    if (b == '\n') return "\\n";
+    if (b == '\r') return "\\r";
+    if (b == '\t') return "\\t";
+    if (b == '\\') return "\\\\";
+    if (b == '\'') return "\\'";
+    if (b == '"') return "\\\"";
+    if (b >= 0x20 && b < 0x7f) { tmp[0] = (char)b; tmp[1] = 0; return tmp; }
+    snprintf(tmp, sizeof(tmp), "\\u{%x}", b);
+    return tmp;
+}
+
+std::string first_word(const uint8_t *p, size_t n)
+{
+    size_t e = 0;
+    while (e < n && p[e] != ' ') e++;
+    return std::string((const char *)p, e);
+}
+}  // namespace
+
+FastxReader::~FastxReader()
+{
+    if (zs_) { inflateEnd(zs_); delete zs_; }
+    if (fp_) fclose(fp_);
+}
+
+bool FastxReader::fail(int kind, const std::string &msg, uint64_t line, const std::string &id)
+{
+    err_kind_ = kind; err_msg_ = msg; err_line_ = line; err_id_ = id; finished_ = true;
+    return false;
+}
+
+size_t FastxReader::read_raw(uint8_t *dst, size_t cap)
+{
+    if (fp_) return fread(dst, 1, cap, fp_);
+    const size_t n = mem_n_ - mem_pos_ < cap ? (size_t)(mem_n_ - mem_pos_) : cap;
+    if (n) memcpy(dst, mem_ + mem_pos_, n);
+    mem_pos_ += n;
+    return n;
+}
+
+size_t FastxReader::read_plain(uint8_t *dst, size_t cap)
+{
+    if (!gz_) return read_raw(dst, cap);
+    if (z_eof_ || cap == 0) return 0;
+    zs_->next_out = dst;
+    zs_->avail_out = (uInt)(cap > 0x40000000u ? 0x40000000u : cap);
+    const size_t want = zs_->avail_out;
+    while (zs_->avail_out == want) {  // until at least one byte is produced or the input ends
+        if (zin_pos_ == zin_len_) {
+            zin_len_ = read_raw(zin_.data(), zin_.size());
+            zin_pos_ = 0;
+            if (zin_len_ == 0) { z_eof_ = true; break; }
+        }
+        zs_->next_in = zin_.data() + zin_pos_;
+        zs_->avail_in = (uInt)(zin_len_ - zin_pos_);
+        const int rc = inflate(zs_, Z_NO_FLUSH);
+        zin_pos_ = zin_len_ - zs_->avail_in;
+        if (rc == Z_STREAM_END) {
+            // concatenated members (MultiGzDecoder, reference src/parser/mod.rs:96): restart on the next one
+            if (zin_pos_ == zin_len_) {
+                zin_len_ = read_raw(zin_.data(), zin_.size());
+                zin_pos_ = 0;
+            }
+            if (zin_len_ == zin_pos_) { z_eof_ = true; break; }
+            inflateReset(zs_);
+        } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+            fail(kErrIo, std::string("gzip stream error: ") + (zs_->msg ? zs_->msg : "corrupt data"), line_);
+            return (size_t)-1;
+        }
+    }
+    return want - zs_->avail_out;
+}
+
+size_t FastxReader::fill()
+{
+    if (eof_) return 0;
+    if (len_ == buf_.size()) make_room_or_grow();
+    size_t added = 0;
+    while (len_ < buf_.size()) {  // fill_buf keeps reading until the buffer is full or EOF (reference utils.rs:34-49)
+        const size_t n = read_plain(buf_.data() + len_, buf_.size() - len_);
+        if (n == (size_t)-1) { eof_ = true; return added; }
+        if (n == 0) { eof_ = true; break; }
+        len_ += n; added += n;
+    }
+    return added;
+}
+
+void FastxReader::make_room_or_grow()
+{
+    if (start_ > 0) {  // make_room: drop consumed records, move the incomplete one to the front
+        memmove(buf_.data(), buf_.data() + start_, len_ - start_);
+        len_ -= start_;
+        start_ = 0;
+    } else {           // grow: a single record does not fit
+        buf_.resize(grow_to(buf_.size()));
+    }
+}
+
+bool FastxReader::sniff()
+{
+    buf_.assign(kBufSize, 0);
+    len_ = start_ = 0;
+    uint8_t two[2];
+    size_t got = read_raw(two, 2);
+    if (got == 1) got += read_raw(two + 1, 1);
+    if (got < 2) return fail(kErrEmptyFile, "Failed to read the first two bytes. Is the file empty?", 0);
+    if (two[0] == 0x1F && two[1] == 0x8B) {  // GZ_MAGIC, reference src/parser/mod.rs:29,95-108
+        gz_ = true;
+        zin_.assign(kBufSize, 0);
+        zin_[0] = two[0]; zin_[1] = two[1];
+        zin_pos_ = 0; zin_len_ = 2;
+        zs_ = new z_stream_s();
+        memset(zs_, 0, sizeof(*zs_));
+        if (inflateInit2(zs_, 15 + 16) != Z_OK) return fail(kErrIo, "zlib initialisation failed", 0);
+    } else {
+        buf_[0] = two[0]; buf_[1] = two[1];
+        len_ = 2;
+    }
+    if (len_ == 0) {
+        fill();
+        if (err_kind_) return false;
+        if (len_ == 0) return fail(kErrEmptyFile, "Failed to read the first two bytes. Is the file empty?", 0);
+    }
+    if (buf_[0] == '>') format_ = kFasta;
+    else if (buf_[0] == '@') format_ = kFastq;
+    else return fail(kErrUnknownFormat, "Expected '@' or '>' at the start of the file but found '" + escape_byte(buf_[0]) + "'.", 0);
+    started_ = true;
+    line_ = 1;
+    return true;
+}
+
+bool FastxReader::open_file(const char *path)
+{
+    fp_ = fopen(path, "rb");
+    if (!fp_) return fail(kErrIo, std::string("cannot open ") + path, 0);
+    return sniff();
+}
+
+bool FastxReader::open_memory(const uint8_t *data, uint64_t n)
+{
+    mem_ = data; mem_n_ = n; mem_pos_ = 0;
+    return sniff();
+}
+
+int FastxReader::next(FastxRecord *rec)
+{
+    if (finished_ || !started_) return err_kind_ ? -1 : 0;
+    // release the previous record
+    start_ += prev_len_; line_ += prev_lines_;
+    prev_len_ = 0; prev_lines_ = 0;
+    return format_ == kFasta ? next_fasta(rec) : next_fastq(rec);
+}
+
+int FastxReader::next_fasta(FastxRecord *rec)
+{
+    if (start_ == len_) {
+        if (!eof_) fill();
+        if (err_kind_) return -1;
+        if (start_ == len_) { finished_ = true; return 0; }
+    }
+    // A record runs from '>' to the last '\n' before the next line that starts with '>' (or to EOF).  Offsets are
+    // relative to start_ so that they survive make_room() / grow() inside fill().
+    size_t scan = 1, first_nl = (size_t)-1, last_nl = (size_t)-1, rec_len = 0;
+    uint64_t n_lines = 0;
+    for (;;) {
+        const uint8_t *base = buf_.data() + start_;
+        const size_t avail = len_ - start_;
+        bool complete = false;
+        while (scan < avail) {
+            const uint8_t *p = (const uint8_t *)memchr(base + scan, '\n', avail - scan);
+            if (!p) { scan = avail; break; }
+            const size_t pos = (size_t)(p - base);
+            if (pos + 1 == avail) {  // cannot look at the next byte (fasta.rs:229-233)
+                if (!eof_) { scan = pos; break; }
+                // at EOF the reference counts this final line end only if an earlier one was pushed (fasta.rs:204-212):
+                // a header line followed by nothing but its newline is a truncated record
+                if (first_nl == (size_t)-1) { fail(kErrUnexpectedEnd, "Unexpected end of input", line_); return -1; }
+            }
+            if (first_nl == (size_t)-1) first_nl = pos;
+            last_nl = pos; n_lines++;   // fasta.rs:235 seq_pos.push(pos)
+            scan = pos + 1;
+            if (scan < avail && base[scan] == '>') { rec_len = scan; complete = true; break; }
+        }
+        if (complete) break;
+        if (!eof_) {
+            fill();
+            if (err_kind_) return -1;
+            continue;
+        }
+        // EOF: the record ends with the input (fasta.rs:204-212)
+        if (base[avail - 1] != '\n') {
+            if (first_nl == (size_t)-1) {  // a header line and nothing else: seq_pos stays empty -> fasta.rs:342-350
+                fail(kErrUnexpectedEnd, "Unexpected end of input", line_);
+                return -1;
+            }
+            last_nl = avail; n_lines++;  // the last line has no line ending; fasta.rs:208 pushes the buffer end
+        }
+        rec_len = avail;
+        break;
+    }
+    const uint8_t *base = buf_.data() + start_;
+    rec->format = kFasta;
+    rec->line = line_;
+    rec->id = base + 1;
+    rec->id_len = trim_cr_len(base + 1, first_nl - 1);
+    if (last_nl > first_nl) {  // fasta.rs:55-63 raw_seq
+        rec->seq = base + first_nl + 1;
+        rec->seq_len = trim_cr_len(rec->seq, last_nl - first_nl - 1);
+    } else {
+        rec->seq = base + first_nl; rec->seq_len = 0;
+    }
+    rec->qual = nullptr; rec->qual_len = 0;
+    uint64_t nb = rec->seq_len;  // fasta.rs:102-107
+    for (uint64_t i = 0; i < rec->seq_len; i++) nb -= (rec->seq[i] == '\n' || rec->seq[i] == '\r');
+    rec->num_bases = nb;
+    prev_len_ = rec_len; prev_lines_ = n_lines;
+    return 1;
+}
+
+int FastxReader::next_fastq(FastxRecord *rec)
+{
+    size_t nl[4];
+    int found = 0;
+    for (;;) {
+        const uint8_t *base = buf_.data() + start_;
+        const size_t avail = len_ - start_;
+        found = 0;
+        size_t from = 0;
+        while (found < 4 && from < avail) {
+            const uint8_t *p = (const uint8_t *)memchr(base + from, '\n', avail - from);
+            if (!p) break;
+            nl[found++] = (size_t)(p - base);
+            from = nl[found - 1] + 1;
+        }
+        if (found == 4) break;
+        if (!eof_) {
+            fill();
+            if (err_kind_) return -1;
+            continue;
+        }
+        // EOF with an incomplete record: reference check_end, src/parser/fastq.rs:335-355
+        if (found == 3) { nl[3] = avail; break; }  // no line ending at the end of the last record
+        bool blank = true;
+        for (size_t i = 0, ls = 0; i <= avail && blank; i++) {
+            if (i == avail || base[i] == '\n') { blank = trim_cr_len(base + ls, i - ls) == 0; ls = i + 1; }
+        }
+        finished_ = true;
+        if (blank) return 0;
+        std::string id;
+        if (found > 0 && nl[0] > 1) id = first_word(base + 1, trim_cr_len(base + 1, nl[0] - 1));
+        fail(kErrUnexpectedEnd, "Unexpected end of input", line_ + (uint64_t)found, id);
+        return -1;
+    }
+    const uint8_t *base = buf_.data() + start_;
+    const size_t seq0 = nl[0] + 1, sep0 = nl[1] + 1, qual0 = nl[2] + 1, end = nl[3];
+    // validate, reference src/parser/fastq.rs:240-285
+    if (base[0] != '@') {
+        fail(kErrInvalidStart, "Expected '@' but found '" + escape_byte(base[0]), line_);
+        return -1;
+    }
+    std::string id;
+    if (seq0 > 1) id = first_word(base + 1, trim_cr_len(base + 1, nl[0] - 1));
+    if (base[sep0] != '+') {
+        fail(kErrInvalidSeparator, "Expected '+' separator but found '" + escape_byte(base[sep0]), line_ + 2, id);
+        return -1;
+    }
+    const size_t seq_len = trim_cr_len(base + seq0, nl[1] - seq0);
+    const size_t qual_len = trim_cr_len(base + qual0, end - qual0);
+    if (seq_len != qual_len) {
+        fail(kErrUnequalLengths, "Sequence length is " + std::to_string(seq_len) + " but quality length is " + std::to_string(qual_len), line_, id);
+        return -1;
+    }
+    rec->format = kFastq;
+    rec->line = line_;
+    rec->id = base + 1; rec->id_len = trim_cr_len(base + 1, nl[0] - 1);
+    rec->seq = base + seq0; rec->seq_len = seq_len;
+    rec->qual = base + qual0; rec->qual_len = qual_len;
+    rec->num_bases = seq_len;
+    prev_len_ = end < len_ - start_ ? end + 1 : end;
+    prev_lines_ = 4;
+    return 1;
+}
+
+}  // namespace ntk

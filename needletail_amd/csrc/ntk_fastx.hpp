@@ -1,0 +1,82 @@
+// ntk_fastx.hpp — the CPU producer of the hot path: a streaming FASTA/FASTQ record reader with needletail's
+// FastxReader semantics (reference src/parser/{mod,fasta,fastq,utils}.rs), kept on the CPU as BASELINE.json's north_star
+// says.  It hands out one borrowed record at a time (valid until the next call, like reference
+// src/parser/utils.rs:123) so that the caller can copy the sequence into a pinned batch (ntk_batch_append).
+//
+// What is mirrored (and tested against the reference's own data files):
+//   * parse_fastx_reader's sniffing: fewer than 2 bytes -> EmptyFile; gzip magic 1F 8B -> concatenated-member inflate
+//     (MultiGzDecoder); first byte '>' -> FASTA, '@' -> FASTQ, else UnknownFormat   (reference src/parser/mod.rs:85-147)
+//   * FASTA: records split at "\n>", raw sequence = everything between the header's '\n' and the record's last '\n'
+//     (interior line breaks kept, one trailing '\r' trimmed); header without any newline at EOF -> UnexpectedEnd
+//     (reference src/parser/fasta.rs:55-63,196-243,291-367)
+//   * FASTQ: strict 4-line records, '@' / '+' checks, equal sequence/quality lengths, last record may lack its newline,
+//     trailing blank lines allowed, otherwise UnexpectedEnd   (reference src/parser/fastq.rs:155-187,240-285,335-355)
+//   * buffer policy: 64 KiB, doubling to 8 MiB, then +8 MiB steps (reference src/parser/utils.rs:8,24-30)
+// Not mirrored (out of scope): bz2/xz/zstd, stdin, record writers, header masking.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+struct z_stream_s;
+
+namespace ntk {
+
+enum FastxFormat { kFasta = 0, kFastq = 1 };
+enum FastxErrorKind {  // reference src/errors.rs:26-44
+    kErrNone = 0, kErrIo = 1, kErrUnknownFormat = 2, kErrInvalidStart = 3, kErrInvalidSeparator = 4,
+    kErrUnequalLengths = 5, kErrUnexpectedEnd = 6, kErrEmptyFile = 7
+};
+
+struct FastxRecord {
+    const uint8_t *id = nullptr; uint64_t id_len = 0;      // header line without '>'/'@', trailing '\r' trimmed
+    const uint8_t *seq = nullptr; uint64_t seq_len = 0;    // raw_seq(): FASTA keeps interior line breaks
+    const uint8_t *qual = nullptr; uint64_t qual_len = 0;  // FASTQ only (nullptr for FASTA)
+    int format = kFasta;
+    uint64_t line = 0;        // start_line_number()
+    uint64_t num_bases = 0;   // reference src/parser/fasta.rs:102-107 / fastq.rs:52
+};
+
+class FastxReader {
+public:
+    FastxReader() = default;
+    ~FastxReader();
+    FastxReader(const FastxReader &) = delete;
+    FastxReader &operator=(const FastxReader &) = delete;
+
+    bool open_file(const char *path);                    // parse_fastx_file
+    bool open_memory(const uint8_t *data, uint64_t n);   // parse_fastx_reader over a byte slice (data must outlive the reader)
+    // 1 = record, 0 = end of input, -1 = error (see error_*)
+    int next(FastxRecord *rec);
+
+    int error_kind() const { return err_kind_; }
+    const std::string &error_msg() const { return err_msg_; }
+    uint64_t error_line() const { return err_line_; }
+    const std::string &error_id() const { return err_id_; }
+    int format() const { return format_; }
+
+private:
+    // raw source
+    FILE *fp_ = nullptr;
+    const uint8_t *mem_ = nullptr; uint64_t mem_n_ = 0, mem_pos_ = 0;
+    size_t read_raw(uint8_t *dst, size_t cap);
+    // gzip layer
+    bool gz_ = false; z_stream_s *zs_ = nullptr; std::vector<uint8_t> zin_; size_t zin_pos_ = 0, zin_len_ = 0; bool z_eof_ = false;
+    size_t read_plain(uint8_t *dst, size_t cap);   // after optional inflate; 0 = EOF; (size_t)-1 = error
+    // record buffer
+    std::vector<uint8_t> buf_; size_t len_ = 0, start_ = 0; bool eof_ = false;
+    size_t fill();             // appends to buf_, returns bytes added (0 at EOF)
+    void make_room_or_grow();
+    int format_ = kFasta; bool started_ = false, finished_ = false;
+    uint64_t line_ = 1;        // line number of the record about to be parsed
+    size_t prev_len_ = 0; uint64_t prev_lines_ = 0;
+    bool fail(int kind, const std::string &msg, uint64_t line, const std::string &id = std::string());
+    int next_fasta(FastxRecord *rec);
+    int next_fastq(FastxRecord *rec);
+    bool sniff();
+    int err_kind_ = kErrNone; std::string err_msg_, err_id_; uint64_t err_line_ = 0;
+};
+
+}  // namespace ntk

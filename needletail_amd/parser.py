@@ -1,0 +1,151 @@
+"""Host-side mirror of needletail's entry points (reference src/parser/mod.rs:85-163, src/python.rs:293-340):
+`parse_fastx_file` / `parse_fastx_string` give an iterator of records with the reference Python API's shape
+(`id`, `seq`, `qual`, `name`, `description`, `is_fasta()`, `is_fastq()`, `normalize()`); parsing runs on the CPU in the
+library's C++ reader, everything sequence-related goes to the GPU through the same C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterator, Optional
+
+from . import _lib as L
+from . import sequence as S
+
+KIND_NAMES = {1: "Io", 2: "UnknownFormat", 3: "InvalidStart", 4: "InvalidSeparator", 5: "UnequalLengths",
+              6: "UnexpectedEnd", 7: "EmptyFile"}
+
+
+class NeedletailError(Exception):
+    """reference src/python.rs:20 (NeedletailError); carries the ParseErrorKind name, line and record id."""
+
+    def __init__(self, kind: int, msg: str, line: int, record_id: str):
+        self.kind = KIND_NAMES.get(kind, str(kind))
+        self.line = line
+        self.record_id = record_id
+        where = (f"record '{record_id}' at " if record_id else "") + f"line {line}"
+        super().__init__(f"{msg} ({self.kind} at {where})")
+
+
+class Record:
+    """reference src/python.rs:100-290 / needletail.pyi: id, seq (line breaks stripped), qual, name, description."""
+
+    def __init__(self, id: str, seq: str, qual: Optional[str] = None, raw_seq: bytes = None, line: int = 0,
+                 num_bases: int = None):
+        self.id = id
+        self.seq = seq
+        self.qual = qual
+        self.raw_seq = raw_seq if raw_seq is not None else seq.encode()
+        self.line = line
+        self.num_bases = len(seq) if num_bases is None else num_bases
+
+    @property
+    def name(self) -> str:
+        return self.id.split(" ", 1)[0] if self.id else self.id
+
+    @property
+    def description(self) -> Optional[str]:
+        parts = self.id.split(" ", 1)
+        return parts[1] if len(parts) > 1 else None
+
+    def is_fasta(self) -> bool:
+        return self.qual is None
+
+    def is_fastq(self) -> bool:
+        return self.qual is not None
+
+    def normalize(self, iupac: bool = False) -> None:
+        self.seq = S.normalize_seq(self.seq, iupac)
+
+    def __repr__(self):
+        return f"Record(id={self.id!r}, seq={self.seq[:30]!r}{'...' if len(self.seq) > 30 else ''}, qual={'yes' if self.qual else None})"
+
+
+class FastxReader:
+    """Iterator over records (FastxReader::next, reference src/parser/utils.rs:119-130)."""
+
+    def __init__(self, path: str = None, data: bytes = None):
+        self._h = C.c_void_p()
+        self._keep = data
+        if path is not None:
+            rc = L.lib().ntk_reader_open_file(str(path).encode(), C.byref(self._h))
+        else:
+            rc = L.lib().ntk_reader_open_memory(data, len(data), C.byref(self._h))
+        if rc != L.NTK_OK:
+            err = self._error() if self._h else None
+            self.close()
+            if err is not None and rc == 8:
+                raise err
+            L.check(rc, "ntk_reader_open")
+
+    def _error(self) -> NeedletailError:
+        kind, line = C.c_int(0), C.c_uint64(0)
+        msg, rid = C.create_string_buffer(512), C.create_string_buffer(256)
+        L.lib().ntk_reader_error(self._h, C.byref(kind), C.byref(line), msg, 512, rid, 256)
+        return NeedletailError(kind.value, msg.value.decode(errors="replace"), line.value, rid.value.decode(errors="replace"))
+
+    def next_raw(self):
+        """(id, raw_seq, qual, line, num_bases) as bytes, or None at the end."""
+        rec = L.Record()
+        rc = L.lib().ntk_reader_next(self._h, C.byref(rec))
+        if rc == 100:
+            return None
+        if rc == 8:
+            raise self._error()
+        L.check(rc, "ntk_reader_next")
+        rid = C.string_at(rec.id, rec.id_len)
+        seq = C.string_at(rec.seq, rec.seq_len)
+        qual = C.string_at(rec.qual, rec.qual_len) if rec.qual else None
+        return rid, seq, qual, rec.line, rec.num_bases
+
+    def __iter__(self) -> Iterator[Record]:
+        return self
+
+    def __next__(self) -> Record:
+        r = self.next_raw()
+        if r is None:
+            raise StopIteration
+        rid, raw, qual, line, nb = r
+        # SequenceRecord::seq(): raw_seq minus CR/LF (reference src/parser/record.rs:85-92, fasta.rs:65-99)
+        seq = raw.replace(b"\n", b"").replace(b"\r", b"") if qual is None else raw
+        return Record(rid.decode("utf-8", "replace"), seq.decode("utf-8", "replace"),
+                      qual.decode("utf-8", "replace") if qual is not None else None, raw, line, nb)
+
+    def close(self):
+        if self._h:
+            L.lib().ntk_reader_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_fastx_file(path) -> FastxReader:
+    """needletail.parse_fastx_file (reference src/parser/mod.rs:161, src/python.rs:293)."""
+    return FastxReader(path=path)
+
+
+def parse_fastx_string(content) -> FastxReader:
+    """needletail.parse_fastx_string (reference src/python.rs:326)."""
+    return FastxReader(data=content.encode() if isinstance(content, str) else bytes(content))
+
+
+def scan_file(ctx, path, k: int, path_kind: int, pre: int, batch_bytes: int = 64 << 20, n_batches: int = 3) -> dict:
+    """The README program on the GPU: parse -> pinned batches -> overlapped H2D + scan; returns the reduced result plus
+    n_records / n_bases (reference src/lib.rs:15-35)."""
+    from .engine import result_to_dict
+    rd = FastxReader(path=path)
+    try:
+        ctx.accum_reset()
+        p = L.Params(k, path_kind, pre, 0)
+        nrec, nb = C.c_uint64(0), C.c_uint64(0)
+        rc = L.lib().ntk_scan_reader(ctx._h, rd._h, C.byref(p), batch_bytes, n_batches, C.byref(nrec), C.byref(nb))
+        if rc == 8:
+            raise rd._error()
+        L.check(rc, "ntk_scan_reader")
+        out = ctx.accum_read()
+        out["n_records"], out["n_bases"] = int(nrec.value), int(nb.value)
+        return out
+    finally:
+        rd.close()

@@ -244,6 +244,27 @@ def test_fastq_head_pins(ctx, golden_dir):
     assert st["n_total"] == 209_965 and st["sum"] == 0x047AD82A7ED0CABA
 
 
+def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
+    """The README program end to end (reference src/lib.rs:15-35): CPU parser -> pinned batches -> overlapped H2D + scan."""
+    import gzip
+    fa = os.path.join(golden_dir, "28S.fasta")
+    recs = fasta_raw_seqs(open(fa, "rb").read())
+    for batch_bytes in (1 << 14, 1 << 20):   # tiny batches force many submit/wait rotations
+        st = nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=batch_bytes, n_batches=3)
+        assert st["n_records"] == 570 and st["n_bases"] == 738_580 and st["hist"][0] == 8_108
+        assert_stats_equal(st, O.reduce_records(recs, 4, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), "scan_file 28S")
+    st = nt.scan_file(ctx, fa, 31, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS)
+    assert (st["n_total"], st["n_fwd"]) == (718_007, 350_983)
+    fq = os.path.join(golden_dir, "PRJNA271013_head.fq")
+    gz = tmp_path / "head.fq.gz"
+    gz.write_bytes(gzip.compress(open(fq, "rb").read()))
+    st = nt.scan_file(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 16)
+    assert st["n_records"] == 2000 and st["n_bases"] == 250_000 and st["n_total"] == 209_965 and st["sum"] == 0x047AD82A7ED0CABA
+    with pytest.raises(nt.NtkError) as e:   # a record longer than a batch is an error, not a silent truncation
+        nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1024)
+    assert e.value.status == 5
+
+
 # ---- materialise mode ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("k,path", [(5, nt.PATH_BITS), (16, nt.PATH_BITS_CANONICAL), (21, nt.PATH_BITS_CANONICAL), (32, nt.PATH_BITS_CANONICAL)])

@@ -1,0 +1,169 @@
+"""The CPU producer (needletail_amd/csrc/ntk_fastx.cpp) against the reference reader's own unit tests, restated
+(reference src/parser/fasta.rs:378-483, src/parser/fastq.rs:460-629, src/parser/mod.rs:169-254, tests/test_compressed.rs)
+and against the reference's data files.  No GPU needed: parsing stays on the CPU."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import needletail_amd as nt
+from _fastx import fasta_raw_seqs, fastq_raw_seqs
+
+
+def recs(data: bytes):
+    rd = nt.parse_fastx_string(data)
+    out = []
+    while True:
+        r = rd.next_raw()
+        if r is None:
+            return out
+        out.append(r)
+
+
+def kinds(data: bytes):
+    """(n_ok_records, error kind or None)"""
+    n = 0
+    try:
+        rd = nt.parse_fastx_string(data)
+        while rd.next_raw() is not None:
+            n += 1
+    except nt.NeedletailError as e:
+        return n, e.kind
+    return n, None
+
+
+# ---- FASTA: reference src/parser/fasta.rs:388-482 ----------------------------------------------
+
+def test_fasta_basic():
+    r = recs(b">test\nACGT\n>test2\nTGCA\n")
+    assert [(x[0], x[1]) for x in r] == [(b"test", b"ACGT"), (b"test2", b"TGCA")]
+
+
+def test_wrapped_fasta():
+    r = recs(b">test\nACGT\nACGT\n>test2\nTGCA\nTG")
+    assert [(x[0], x[1], x[4]) for x in r] == [(b"test", b"ACGT\nACGT", 8), (b"test2", b"TGCA\nTG", 6)]
+
+
+def test_wrapped_fasta_windows_newlines():
+    r = recs(b">test\r\nACGT\r\nACGT\r\n>test2\r\nTGCA\r\nTG")
+    assert [(x[0], x[1], x[4], x[3]) for x in r] == [(b"test", b"ACGT\r\nACGT", 8, 1), (b"test2", b"TGCA\r\nTG", 6, 4)]
+
+
+def test_fasta_premature_ending():
+    assert kinds(b">test\nAGCT\n>test2") == (1, "UnexpectedEnd")
+    assert kinds(b">test\r\nAGCT\r\n>test2\r\n") == (1, "UnexpectedEnd")
+
+
+def test_fasta_empty_records():
+    for data in (b">\n\n>shine\nAGGAGGU", b">\r\n\r\n>shine\r\nAGGAGGU"):
+        r = recs(data)
+        assert [(x[0], x[1]) for x in r] == [(b"", b""), (b"shine", b"AGGAGGU")]
+
+
+# ---- FASTQ: reference src/parser/fastq.rs:473-628 ------------------------------------------------
+
+def test_simple_fastq_both_line_endings():
+    for data in (b"@test\nAGCT\n+test\n~~a!\n@test2\nTGCA\n+test\nWUI9",
+                 b"@test\r\nAGCT\r\n+test\r\n~~a!\r\n@test2\r\nTGCA\r\n+test\r\nWUI9"):
+        r = recs(data)
+        assert [(x[0], x[1], x[2]) for x in r] == [(b"test", b"AGCT", b"~~a!"), (b"test2", b"TGCA", b"WUI9")]
+
+
+def test_fastq_eof_cases():
+    assert kinds(b"@test\nACGT\n+\nIII") == (0, "UnequalLengths")             # test_eof_in_qual
+    assert kinds(b"@test\nAGCT\n+test\n~~a!\n@test2\nTGCA") == (1, "UnexpectedEnd")   # test_eof_in_seq
+    assert kinds(b"@test\nAGCT\n+test\n~~a!\n\n") == (1, None)                 # extra empty newlines are ok
+    assert kinds(b"@test\nAGCT\n+test\n~~a!\n\n@TEST\nA\n+TEST\n~") == (1, "InvalidStart")
+    assert kinds(b"@test\nAGCT\n+\nIII\n@TEST\nA\n+\nI") == (0, "UnequalLengths")   # test_mismatched_lengths
+
+
+def test_fastq_empty_records_and_line_numbers():
+    r = recs(b"@\n\n+\n\n@test2\nTGCA\n+test2\n~~~~\n")
+    assert [(x[0], x[1], x[2]) for x in r] == [(b"", b"", b""), (b"test2", b"TGCA", b"~~~~")]
+    s = b"ACGTACGATCGTACGTAGCTGCTAGCTAGCATGCATGACACACACGTACGATCGTACGTAGCTGCTAGCTAGCATGCATGACACAC"
+    q = b"0" * len(s)
+    data = b"@NCBI actually has files like this\n" + s + b"\n+\n" + q + b"\n@NCBI actually has files like this\n\n+\n\n" \
+           b"@NCBI actually has files like this\n" + s + b"\n+\n" + q
+    assert [x[3] for x in recs(data)] == [1, 5, 9]   # start_line_number, test_weird_ncbi_file
+
+
+def test_reference_bad_files(golden_dir):
+    def file_kinds(name):
+        n = 0
+        try:
+            for _ in nt.parse_fastx_file(os.path.join(golden_dir, name)):
+                n += 1
+        except nt.NeedletailError as e:
+            return n, e.kind
+        return n, None
+    assert file_kinds("bad_header.fastq") == (1, "UnexpectedEnd")       # fastq.rs:604-614
+    assert file_kinds("random_tsv.fq") == (1, "InvalidSeparator")        # fastq.rs:617-627
+
+
+# ---- entry point: reference src/parser/mod.rs:185-210, tests/test_compressed.rs --------------------
+
+def test_sniffing_errors():
+    assert kinds(b"") == (0, "EmptyFile")
+    assert kinds(b"@") == (0, "EmptyFile")
+    assert kinds(gzip.compress(b"")) == (0, "EmptyFile")
+    assert kinds(b"hello") == (0, "UnknownFormat")
+    with pytest.raises(nt.NeedletailError):
+        nt.parse_fastx_file("/nonexistent/file.fa")
+
+
+def test_gzip_roundtrip_and_multi_member(golden_dir):
+    plain = open(os.path.join(golden_dir, "test.fa"), "rb").read()
+    want = [(b"test", b"AGCTGATCGA"), (b"test2", b"TAGC")]
+    assert [(x[0], x[1]) for x in recs(plain)] == want
+    assert [(r.id.encode(), r.seq.encode()) for r in nt.parse_fastx_file(os.path.join(golden_dir, "test.fa.gz"))] == want
+    # concatenated members decode as one stream (MultiGzDecoder)
+    two = gzip.compress(b">a\nACGT\n") + gzip.compress(b">b\nTTTT\nGG\n")
+    assert [(x[0], x[1]) for x in recs(two)] == [(b"a", b"ACGT"), (b"b", b"TTTT\nGG")]
+
+
+def test_python_record_shape():
+    r = list(nt.parse_fastx_string(">test description here\nAGCT\nGA\n@bad"))  # '@' inside FASTA is sequence text
+    assert r[0].id == "test description here" and r[0].name == "test" and r[0].description == "description here"
+    assert r[0].seq == "AGCTGA@bad" and r[0].qual is None and r[0].is_fasta()
+    q = list(nt.parse_fastx_string("@r1\nACGT\n+\nIIII\n"))[0]
+    assert q.is_fastq() and q.qual == "IIII" and q.seq == "ACGT"
+
+
+# ---- whole files + buffer-boundary stress against an independent splitter -------------------------
+
+def test_golden_files_match_independent_splitter(golden_dir):
+    data = open(os.path.join(golden_dir, "28S.fasta"), "rb").read()
+    got = [x[1] for x in recs(data)]
+    assert got == fasta_raw_seqs(data) and len(got) == 570
+    assert sum(x[4] for x in recs(data)) == 738_580       # benches/benchmark.rs:151
+    data = open(os.path.join(golden_dir, "PRJNA271013_head.fq"), "rb").read()
+    got = [x[1] for x in recs(data)]
+    assert got == fastq_raw_seqs(data) and sum(len(s) for s in got) == 250_000   # benches/benchmark.rs:97
+    assert [x[1] for x in recs(gzip.compress(data))] == got
+
+
+def test_records_across_buffer_boundaries():
+    rng = np.random.default_rng(1)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    # FASTA: records from tiny to far beyond the 64 KiB initial buffer, wrapped at 70 columns, mixed line endings
+    parts, want = [], []
+    for i, n in enumerate([0, 1, 69, 70, 71, 5000, 65_000, 66_000, 200_000, 3, 1_300_000, 10]):
+        seq = bytes(letters[rng.integers(0, 5, n)])
+        nl = b"\r\n" if i % 3 == 1 else b"\n"
+        body = nl.join(seq[j:j + 70] for j in range(0, len(seq), 70)) if n else b""
+        parts.append(b">rec%d some description" % i + nl + body + nl)
+        want.append(seq)
+    data = b"".join(parts)
+    got = recs(data)
+    assert [x[1].replace(b"\n", b"").replace(b"\r", b"") for x in got] == want
+    assert [x[4] for x in got] == [len(s) for s in want]
+    # FASTQ: 20k records whose sizes make record boundaries hit every buffer offset
+    parts, want = [], []
+    for i in range(20_000):
+        n = int(rng.integers(0, 300))
+        seq = bytes(letters[rng.integers(0, 5, n)])
+        parts.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * n + b"\n")
+        want.append(seq)
+    got = recs(b"".join(parts))
+    assert [x[1] for x in got] == want and [x[3] for x in got] == [1 + 4 * i for i in range(20_000)]
