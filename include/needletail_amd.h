@@ -203,6 +203,19 @@ int ntk_canonical_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k
 int ntk_bit_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k, int canonical,
                   uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *count);
 
+/* ---- minimizers and quality masking ------------------------------------------------ */
+/* Windowed minimizers, reduce mode (BASELINE.json configs[4], "minimizers (w, k)"): for every window of w+k-1 good
+ * bases the smallest canonical k-mer in it = sequence::minimizer(window, k) (reference src/sequence.rs:139-152).
+ * Accumulates n_total (windows), n_fwd (minimizer drawn from the forward strand), sum/xor/histogram of the
+ * minimizer values into the ctx accumulators.  p->path must be a canonical path.  Async on the ctx stream. */
+int ntk_minimizers_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p, uint32_t w);
+/* sequence::minimizer (reference src/sequence.rs:139-152) for one sequence; out holds m bytes; n >= m >= 1. */
+int ntk_minimizer(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t m, uint8_t *out);
+/* bitkmer::minimizer (reference src/bitkmer.rs:146-162), element-wise over n packed k-mers (host arrays). */
+int ntk_bit_minimizers(ntk_ctx *ctx, const uint64_t *values, uint64_t n, uint32_t k, uint32_t m, uint64_t *out);
+/* QualitySequence::quality_mask (reference src/sequence.rs:285-296): out[i] = qual[i] < score ? 'N' : seq[i]. */
+int ntk_quality_mask(ntk_ctx *ctx, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint8_t score, uint8_t *out);
+
 /* ---- device utilities (bench / parity properties; records stay resident in HBM) ----------------- */
 /* Synthetic read set of SURVEY.md §8d generated straight into HBM: reads first_read..+n_reads, each
  * read_len bases + '\n'; d_out holds n_reads*(read_len+1) bytes (+ padding to 16). */

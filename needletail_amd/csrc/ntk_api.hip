@@ -660,6 +660,92 @@ int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int ca
     return mcount > cap ? NTK_ERR_CAPACITY : NTK_OK;
 }
 
+/* ---- minimizers, quality mask --------------------------------------------------------------------------------- */
+
+int ntk_minimizers_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, uint32_t w)
+{
+    if (!c || w < 1 || w > 256) return NTK_ERR_BAD_ARG;
+    Mode m;
+    int rc = resolve_mode(p, true, &m);
+    if (rc) return rc;
+    if (!m.canon) return NTK_ERR_BAD_ARG;
+    if (n == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t nt = (n + 15) / 16 * 16;
+    if ((rc = ensure_scratch(c, 3, nt * 8))) return rc;
+    if ((rc = ensure_scratch(c, 4, nt / 8 + 16))) return rc;
+    if ((rc = ensure_scratch(c, 5, nt / 8 + 16))) return rc;
+    uint64_t *d_val = (uint64_t *)c->scratch[3].p;
+    uint16_t *d_v16 = (uint16_t *)c->scratch[4].p, *d_r16 = (uint16_t *)c->scratch[5].p;
+    if ((rc = run_scan(c, d_seq, n, p, m, false, d_val, d_v16, d_r16))) return rc;
+    const int blocks = c->n_cu * 4;
+    if ((rc = ensure_partials(c, blocks))) return rc;
+    ScanArgs a; memset(&a, 0, sizeof(a)); scan_args_set_k(a, p->k);
+    hipLaunchKernelGGL(window_min_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)d_val,
+                       (const uint16_t *)d_v16, (const uint16_t *)d_r16, n, w, a.bin_shift, c->d_part_hist, c->d_part_scalars);
+    hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
+                       (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
+    HIPCHK(hipGetLastError());
+    return NTK_OK;
+}
+
+int ntk_minimizer(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t m, uint8_t *out)
+{
+    if (!c || !seq || !out || m < 1 || n < m) return NTK_ERR_BAD_ARG;  // the reference panics on n < m (sequence.rs:141)
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n))) return rc;
+    if ((rc = ensure_scratch(c, 1, (size_t)m + 64))) return rc;
+    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_out = (uint8_t *)c->scratch[1].p;
+    uint64_t *d_best = (uint64_t *)(d_out + ((m + 15) & ~15u));
+    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(minimizer_bytes_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint8_t *)d_in, n, m,
+                       (const uint16_t *)(c->d_lut + 768), d_best);
+    hipLaunchKernelGGL(minimizer_emit_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, (const uint8_t *)d_in, n, m,
+                       (const uint16_t *)(c->d_lut + 768), (const uint64_t *)d_best, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
+int ntk_bit_minimizers(ntk_ctx *c, const uint64_t *values, uint64_t n, uint32_t k, uint32_t m, uint64_t *out)
+{
+    if (!c || (!values && n) || (!out && n)) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 32 || m < 1 || m > k) return NTK_ERR_BAD_K;
+    if (n == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n * 8))) return rc;
+    if ((rc = ensure_scratch(c, 1, n * 8))) return rc;
+    uint64_t *d_in = (uint64_t *)c->scratch[0].p, *d_out = (uint64_t *)c->scratch[1].p;
+    HIPCHK(hipMemcpyAsync(d_in, values, n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bit_minimizer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t *)d_in, n, k, m, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
+int ntk_quality_mask(ntk_ctx *c, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint8_t score, uint8_t *out)
+{
+    if (!c || (n && (!seq || !qual || !out))) return NTK_ERR_BAD_ARG;
+    if (n == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n))) return rc;
+    if ((rc = ensure_scratch(c, 1, n))) return rc;
+    if ((rc = ensure_scratch(c, 2, n))) return rc;
+    uint8_t *d_s = (uint8_t *)c->scratch[0].p, *d_q = (uint8_t *)c->scratch[1].p, *d_o = (uint8_t *)c->scratch[2].p;
+    HIPCHK(hipMemcpyAsync(d_s, seq, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_q, qual, n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(quality_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d_s, (const uint8_t *)d_q, n, score, d_o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_o, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
 /* ---- device utilities ---------------------------------------------------------------------------- */
 
 int ntk_synth_reads_device(ntk_ctx *c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,

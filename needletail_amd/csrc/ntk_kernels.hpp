@@ -370,6 +370,137 @@ __global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// minimizers and quality masking
+// ---------------------------------------------------------------------------------------------
+
+// Windowed minimizers over a materialised canonical k-mer plane: the window of w+k-1 good bases ending at byte e holds
+// the w k-mers ending at e-w+1 .. e; its minimizer (reference sequence::minimizer, src/sequence.rs:139-152, applied to
+// that window) is the smallest of their canonical values.  One thread per window end; per-block partials like the scan.
+__device__ __forceinline__ uint32_t plane_bit(const uint16_t *plane, uint64_t e) { return (plane[e >> 4] >> (15 - (e & 15))) & 1u; }
+
+__global__ __launch_bounds__(256) void window_min_reduce_kernel(const uint64_t *values, const uint16_t *valid16, const uint16_t *rc16,
+                                                                uint64_t n, uint32_t w, uint32_t bin_shift,
+                                                                uint32_t *part_hist, uint64_t *part_scalars)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint64_t s_red[4][4];
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    uint64_t sum = 0, xr = 0, nv = 0, nf = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        if (e + 1 < w) continue;
+        bool ok = true;
+        uint64_t best = ~0ull;
+        uint32_t flag = 0;
+        for (uint32_t t = w; t-- > 0;) {  // leftmost window position first: a strict '<' keeps the leftmost minimum
+            const uint64_t q = e - t;
+            ok = ok && plane_bit(valid16, q);
+            const uint64_t v = values[q];
+            if (v < best) { best = v; flag = plane_bit(rc16, q); }
+        }
+        if (ok) {
+            sum += best; xr ^= best; nv++; nf += flag ? 0 : 1;
+            atomicAdd(&s_hist[(uint32_t)(best >> bin_shift)], 1u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o, 64); xr ^= __shfl_xor(xr, o, 64); nv += __shfl_xor(nv, o, 64); nf += __shfl_xor(nf, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = nv; s_red[threadIdx.x >> 6][1] = nf; s_red[threadIdx.x >> 6][2] = sum; s_red[threadIdx.x >> 6][3] = xr; }
+    __syncthreads();
+    uint32_t *ph = part_hist + (size_t)blockIdx.x * kHistBins;
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
+    if (threadIdx.x == 0) {
+        uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+        for (int q = 0; q < 4; q++) { tv += s_red[q][0]; tf += s_red[q][1]; ts += s_red[q][2]; tx ^= s_red[q][3]; }
+        uint64_t *ps = part_scalars + (size_t)blockIdx.x * 4;
+        ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
+    }
+}
+
+// bitkmer::reverse_complement / bitkmer::minimizer on device (reference src/bitkmer.rs:112-132,146-162), element-wise.
+// The reference takes the reverse complement of the m-mer at length k (not m) - reproduced as written.
+__device__ __forceinline__ uint64_t bit_revcomp(uint64_t x, uint32_t k)
+{
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    x = ~x;
+    return x >> (2 * (32 - k));
+}
+__global__ void bit_minimizer_kernel(const uint64_t *in, uint64_t n, uint32_t k, uint32_t m, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t v = in[i], lowest = ~0ull;
+    const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1);
+    for (uint32_t t = 0; t <= k - m; t++) {
+        const uint64_t cur = v & mask;
+        lowest = cur < lowest ? cur : lowest;
+        const uint64_t r = bit_revcomp(cur, k);
+        lowest = r < lowest ? r : lowest;
+        v >>= 2;
+    }
+    out[i] = lowest;
+}
+
+// sequence::minimizer (reference src/sequence.rs:139-152) for one sequence: the lexicographically smallest length-m
+// byte string among all windows of the sequence and of its reverse complement.  One block; candidates are compared
+// as raw bytes exactly like the reference.  best[0] = candidate index (window start), best[1] = 1 if from the rc.
+__device__ __forceinline__ uint8_t cand_byte(const uint8_t *seq, uint64_t n, const uint16_t *comp, uint64_t idx, uint32_t strand, uint32_t j)
+{
+    return strand ? (uint8_t)comp[seq[n - 1 - (idx + j)]] : seq[idx + j];
+}
+__device__ __forceinline__ bool cand_less(const uint8_t *seq, uint64_t n, const uint16_t *comp, uint32_t m,
+                                          uint64_t ia, uint32_t sa, uint64_t ib, uint32_t sb)
+{
+    for (uint32_t j = 0; j < m; j++) {
+        const uint8_t a = cand_byte(seq, n, comp, ia, sa, j), b = cand_byte(seq, n, comp, ib, sb, j);
+        if (a != b) return a < b;
+    }
+    return false;
+}
+__global__ __launch_bounds__(1024) void minimizer_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t m, const uint16_t *comp, uint64_t *best)
+{
+    __shared__ uint64_t s_idx[1024];
+    __shared__ uint32_t s_str[1024];
+    const uint64_t ncand = n - m + 1;
+    uint64_t bi = 0; uint32_t bs = 0;
+    bool have = false;
+    for (uint64_t c = threadIdx.x; c < 2 * ncand; c += blockDim.x) {
+        const uint64_t i = c >> 1; const uint32_t st = (uint32_t)(c & 1);
+        if (!have || cand_less(seq, n, comp, m, i, st, bi, bs)) { bi = i; bs = st; have = true; }
+    }
+    s_idx[threadIdx.x] = have ? bi : ~0ull; s_str[threadIdx.x] = bs;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const uint64_t oi = s_idx[threadIdx.x + o]; const uint32_t os = s_str[threadIdx.x + o];
+            if (oi != ~0ull && (s_idx[threadIdx.x] == ~0ull || cand_less(seq, n, comp, m, oi, os, s_idx[threadIdx.x], s_str[threadIdx.x]))) {
+                s_idx[threadIdx.x] = oi; s_str[threadIdx.x] = os;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { best[0] = s_idx[0]; best[1] = s_str[0]; }
+}
+__global__ void minimizer_emit_kernel(const uint8_t *seq, uint64_t n, uint32_t m, const uint16_t *comp, const uint64_t *best, uint8_t *out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) out[j] = cand_byte(seq, n, comp, best[0], (uint32_t)best[1], j);
+}
+
+// QualitySequence::quality_mask (reference src/sequence.rs:285-296)
+__global__ void quality_mask_kernel(const uint8_t *seq, const uint8_t *qual, uint64_t n, uint8_t score, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = qual[i] < score ? (uint8_t)'N' : seq[i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // synthetic reads: counter-based SplitMix64, one thread per 16 output bytes
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)

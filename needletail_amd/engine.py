@@ -97,6 +97,12 @@ class Context:
                                                C.c_void_p(_ptr(d_valid16)), C.c_void_p(_ptr(d_rc16))),
                 "ntk_materialize_device")
 
+    def minimizers_reduce_device(self, d_seq, n_bytes: int, k: int, w: int, path: int, pre: int):
+        """Windowed minimizers (w k-mers per window) reduced into the accumulators."""
+        p = L.Params(k, path, pre, 0)
+        L.check(L.lib().ntk_minimizers_reduce_device(self._h, C.c_void_p(_ptr(d_seq)), n_bytes, C.byref(p), w),
+                "ntk_minimizers_reduce_device")
+
     # -- device utilities ------------------------------------------------------------------------------
     def synth_reads_device(self, seed: int, first_read: int, n_reads: int, read_len: int, n_per_1024: int, d_out):
         L.check(L.lib().ntk_synth_reads_device(self._h, seed, first_read, n_reads, read_len, n_per_1024,

@@ -106,3 +106,31 @@ def bit_kmers(seq: bytes, k: int, canonical: bool, ctx: Context = None) -> List[
     """Sequence::bit_kmers(k, canonical) (reference src/sequence.rs:250-252, src/bitkmer.rs:72-109)."""
     pos, val, flg = bit_kmers_arrays(seq, k, canonical, ctx)
     return [(p, (v, k), bool(f)) for p, v, f in zip(pos.tolist(), val.tolist(), flg.tolist())]
+
+
+def minimizer(seq: bytes, length: int, ctx: Context = None) -> bytes:
+    """sequence::minimizer (reference src/sequence.rs:139-152)."""
+    c = _ctx(ctx)
+    if length < 1 or len(seq) < length:
+        raise ValueError("need 1 <= length <= len(seq)")
+    out = C.create_string_buffer(length)
+    L.check(L.lib().ntk_minimizer(c._h, seq, len(seq), length, out), "ntk_minimizer")
+    return out.raw[:length]
+
+
+def bit_minimizers(values, k: int, m: int, ctx: Context = None) -> np.ndarray:
+    """bitkmer::minimizer (reference src/bitkmer.rs:146-162) over an array of packed k-mers."""
+    c = _ctx(ctx)
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    out = np.empty_like(v)
+    L.check(L.lib().ntk_bit_minimizers(c._h, v.ctypes.data, v.size, k, m, out.ctypes.data), "ntk_bit_minimizers")
+    return out
+
+
+def quality_mask(seq: bytes, qual: bytes, score: int, ctx: Context = None) -> bytes:
+    """QualitySequence::quality_mask (reference src/sequence.rs:285-296); zip semantics: min(len(seq), len(qual))."""
+    c = _ctx(ctx)
+    n = min(len(seq), len(qual))
+    out = C.create_string_buffer(max(n, 1))
+    L.check(L.lib().ntk_quality_mask(c._h, seq[:n], qual[:n], n, score, out), "ntk_quality_mask")
+    return out.raw[:n]

@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
         L.ntko_count_batch_mt.argtypes = [u64p, u64p, C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
         L.ntko_reduce_fused.restype = C.c_int
         L.ntko_reduce_fused.argtypes = [C.POINTER(Stats), C.c_void_p, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
+        L.ntko_minimizers_reduce.restype = C.c_int
+        L.ntko_minimizers_reduce.argtypes = [C.POINTER(Stats), C.c_void_p, sz, C.c_uint8, C.c_uint32, C.c_int, C.c_int]
         L.ntko_splitmix64_at.restype = C.c_uint64
         L.ntko_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
         L.ntko_synth_reads.restype = None
@@ -283,6 +285,16 @@ def reduce_fused(buf, k: int, canonical: bool, tie_rc: bool, accept_u: bool) -> 
     rc = lib().ntko_reduce_fused(C.byref(st), buf.ctypes.data, buf.size, k, int(canonical), int(tie_rc), int(accept_u))
     if rc:
         raise ValueError("ntko_reduce_fused failed")
+    return st.as_dict()
+
+
+def minimizers_reduce(buf, k: int, w: int, accept_u: bool = True, tie_rc: bool = True) -> dict:
+    buf = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf,
+                               dtype=np.uint8)
+    st = Stats()
+    lib().ntko_stats_clear(C.byref(st))
+    if lib().ntko_minimizers_reduce(C.byref(st), buf.ctypes.data, buf.size, k, w, int(accept_u), int(tie_rc)):
+        raise ValueError("ntko_minimizers_reduce failed")
     return st.as_dict()
 
 

@@ -612,3 +612,46 @@ void ntko_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint
         o[read_len] = '\n';
     }
 }
+
+/* ======================================================================================== *
+ *  windowed minimizers (BASELINE.json configs[4]: "minimizers (w=11,k=21)")
+ * ======================================================================================== */
+
+/* The reference has no windowed-minimizer iterator; the nearest defined semantics is
+ * sequence::minimizer(window, k) (src/sequence.rs:139-152) applied to every window of w+k-1 good bases of a
+ * normalised sequence.  For each such window this calls the restated minimizer literally and folds the 2-bit
+ * value of the returned k bytes into the statistic; the flag is the strand flag CanonicalKmers (tie_rc = 1) or
+ * BitNuclKmer (tie_rc = 0) reports for the leftmost k-mer of the window whose canonical form is the minimizer. */
+int ntko_minimizers_reduce(ntko_stats *s, const uint8_t *buf, size_t n, uint8_t k, uint32_t w, int accept_u, int tie_rc)
+{
+    if (k < 1 || k > 32 || w < 1) return -1;
+    const size_t span = (size_t)w + k - 1;
+    unsigned shift = hist_shift(k);
+    uint8_t *win = (uint8_t *)malloc(span), *mn = (uint8_t *)malloc(k);
+    size_t run = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t c = buf[i];
+        int good = ntko_is_good_base(c) || (accept_u && (c == 'U' || c == 'u'));
+        run = good ? run + 1 : 0;
+        if (run < span) continue;
+        /* normalise the window bytes as sequence::normalize would (upper-case, U -> T) */
+        for (size_t t = 0; t < span; t++) {
+            uint8_t b = buf[i + 1 - span + t];
+            b = (uint8_t)(b & 0xDF);
+            win[t] = b == 'U' ? (uint8_t)'T' : b;
+        }
+        ntko_minimizer(win, span, k, mn);
+        uint64_t v = ntko_bytes_to_bitmer(mn, k).seq;
+        /* strand of the leftmost window position whose canonical k-mer equals the minimizer */
+        int flag = 0;
+        for (size_t t = 0; t + k <= span; t++) {
+            uint64_t f = ntko_bytes_to_bitmer(win + t, k).seq;
+            ntko_bitkmer fk = { f, k };
+            uint64_t r = ntko_bit_reverse_complement(fk).seq;
+            if (f == v || r == v) { flag = tie_rc ? !(f < r) : (f > r); break; }  /* that k-mer's own iterator flag */
+        }
+        stats_emit(s, v, flag, shift);
+    }
+    free(win); free(mn);
+    return 0;
+}

@@ -166,6 +166,10 @@ int ntko_reduce_batch_mt(ntko_stats *s, const uint8_t *seq, const uint64_t *offs
 int ntko_reduce_fused(ntko_stats *s, const uint8_t *buf, size_t n, uint8_t k, int canonical,
                       int tie_rc, int accept_u);
 
+/* Windowed minimizers: sequence::minimizer(window, k) (src/sequence.rs:139-152) for every window of w+k-1 good
+ * bases; value folded like the k-mer statistic, flag = the iterator flag of the leftmost minimal k-mer. */
+int ntko_minimizers_reduce(ntko_stats *s, const uint8_t *buf, size_t n, uint8_t k, uint32_t w, int accept_u, int tie_rc);
+
 /* ---- deterministic synthetic inputs, SplitMix64, counter-based ---------- */
 
 uint64_t ntko_splitmix64_at(uint64_t seed, uint64_t index);

@@ -265,6 +265,42 @@ def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
     assert e.value.status == 5
 
 
+# ---- minimizers and quality mask ---------------------------------------------------------
+
+def test_minimizer_and_quality_mask_kats(ctx):
+    assert nt.minimizer(b"ATTTCG", 3, ctx) == b"AAA"                       # reference src/sequence.rs:363-367
+    assert nt.quality_mask(b"AGCT", b"AAA0", ord("5"), ctx) == b"AGCN"     # reference src/sequence.rs:369-374
+    got = nt.bit_minimizers([0b001011, 0b001011, 0b110001], 3, 2, ctx)      # reference src/bitkmer.rs:261-267
+    assert list(got) == [0b0010, 0b0010, 1]
+    assert list(nt.bit_minimizers([0b001011], 3, 1, ctx)) == [0] and list(nt.bit_minimizers([0b11000011], 4, 2, ctx)) == [0]
+    rng = np.random.default_rng(21)
+    alphabet = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    for trial in range(25):
+        n = int(rng.integers(1, 4000))
+        seq = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        m = int(rng.integers(1, min(n, 40) + 1))
+        assert nt.minimizer(seq, m, ctx) == O.minimizer(seq, m), (trial, n, m)
+        q = bytes(rng.integers(33, 80, n, dtype=np.uint8))
+        assert nt.quality_mask(seq, q, 53, ctx) == O.quality_mask(seq, q, 53)
+    vals = rng.integers(0, 1 << 62, 5000, dtype=np.uint64)
+    for k, m in ((31, 21), (32, 32), (21, 1), (16, 9)):
+        v = vals & np.uint64((1 << (2 * k)) - 1 if k < 32 else 0xFFFFFFFFFFFFFFFF)
+        want = np.array([O.bit_minimizer(int(x), k, m) for x in v[:300]], dtype=np.uint64)
+        assert np.array_equal(nt.bit_minimizers(v, k, m, ctx)[:300], want), (k, m)
+
+
+@pytest.mark.parametrize("k,w", [(21, 11), (5, 3), (31, 1), (16, 20)])
+def test_windowed_minimizers_reduce(ctx, k, w):
+    buf = O.synth_reads(0x5EED0005, 3, 300, 150, 6).tobytes()
+    t = to_dev(buf)
+    ctx.accum_reset()
+    ctx.minimizers_reduce_device(t, len(buf), k, w, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, k, w, True, True), (k, w))
+    ctx.accum_reset()
+    ctx.minimizers_reduce_device(t, len(buf), k, w, nt.PATH_BITS_CANONICAL, nt.PRE_NONE)
+    assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, k, w, False, False), (k, w, "bits"))
+
+
 # ---- materialise mode ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("k,path", [(5, nt.PATH_BITS), (16, nt.PATH_BITS_CANONICAL), (21, nt.PATH_BITS_CANONICAL), (32, nt.PATH_BITS_CANONICAL)])
