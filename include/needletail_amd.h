@@ -69,7 +69,9 @@ typedef struct ntk_params {
     uint32_t k;    /* 1..32 on the batch face (values are packed into a u64)          */
     uint32_t path; /* NTK_PATH_*                                                       */
     uint32_t pre;  /* NTK_PRE_*                                                        */
-    uint32_t flags;/* reserved, must be 0                                              */
+    uint32_t flags;/* bits 7:0 = minimizer window w (k-mers per window; 0 = plain k-mers):  */
+                   /* reduce entry points then fold windowed minimizers instead of k-mers; */
+                   /* other bits reserved, must be 0                                      */
 } ntk_params;
 
 /* Reduced result of a scan.  `value` is the emitted k-mer in the reference's

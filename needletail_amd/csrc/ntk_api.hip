@@ -17,6 +17,10 @@ namespace {
 
 thread_local int g_last_hip = 0;
 
+// HIP caps gridDim.x * blockDim.x below 2^32 and silently wraps beyond it: element-wise kernels are grid-stride and are
+// launched with at most 2^20 blocks.
+inline unsigned grid_for(uint64_t items, unsigned block) { const uint64_t b = (items + block - 1) / block; return (unsigned)(b > (1u << 20) ? (1u << 20) : (b ? b : 1)); }
+
 #define HIPCHK(expr)                                     \
     do {                                                 \
         hipError_t e__ = (expr);                         \
@@ -136,7 +140,7 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 {
     if (!p) return NTK_ERR_BAD_ARG;
     if (p->k < 1 || p->k > 32) return NTK_ERR_BAD_K;
-    if (p->flags != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
+    if ((p->flags & ~0xFFu) != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
     m->kw = p->k > 16 ? 2 : 1;
     m->accept_u = p->pre >= NTK_PRE_NORMALIZE;
     switch (p->path) {
@@ -372,6 +376,7 @@ int ntk_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_pa
     int rc = resolve_mode(p, true, &m);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
+    if (p->flags & 0xFFu) return ntk_minimizers_reduce_device(c, d_seq, n, p, p->flags & 0xFFu);
     return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr);
 }
 
@@ -480,7 +485,8 @@ int ntk_batch_submit(ntk_ctx *c, ntk_batch *b, const ntk_params *p)
         HIPCHK(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, c->copy_stream));
         HIPCHK(hipEventRecord(b->ev_copied, c->copy_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, b->ev_copied, 0));
-        rc = run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr);
+        rc = (p->flags & 0xFFu) ? ntk_minimizers_reduce_device(c, b->d_seq, b->n_bytes, p, p->flags & 0xFFu)
+                               : run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(b->ev_done, c->stream));
@@ -578,7 +584,7 @@ int ntk_reverse_complement(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *
     if ((rc = ensure_scratch(c, 1, n))) return rc;
     uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_out = (uint8_t *)c->scratch[1].p;
     HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(map_reverse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(map_reverse_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
                        (const uint8_t *)d_in, d_out, n, (const uint16_t *)(c->d_lut + 768));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
@@ -599,7 +605,7 @@ int ntk_canonical_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, 
     if ((rc = ensure_scratch(c, 1, n))) return rc;
     uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_flags = (uint8_t *)c->scratch[1].p;
     HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(canonical_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
                        (const uint8_t *)d_in, n, k, (const uint16_t *)(c->d_lut + 768), d_flags);
     HIPCHK(hipGetLastError());
     std::vector<uint8_t> flags(n);
@@ -720,7 +726,7 @@ int ntk_bit_minimizers(ntk_ctx *c, const uint64_t *values, uint64_t n, uint32_t 
     if ((rc = ensure_scratch(c, 1, n * 8))) return rc;
     uint64_t *d_in = (uint64_t *)c->scratch[0].p, *d_out = (uint64_t *)c->scratch[1].p;
     HIPCHK(hipMemcpyAsync(d_in, values, n * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(bit_minimizer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t *)d_in, n, k, m, d_out);
+    hipLaunchKernelGGL(bit_minimizer_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint64_t *)d_in, n, k, m, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -739,7 +745,7 @@ int ntk_quality_mask(ntk_ctx *c, const uint8_t *seq, const uint8_t *qual, uint64
     uint8_t *d_s = (uint8_t *)c->scratch[0].p, *d_q = (uint8_t *)c->scratch[1].p, *d_o = (uint8_t *)c->scratch[2].p;
     HIPCHK(hipMemcpyAsync(d_s, seq, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_q, qual, n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(quality_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)d_s, (const uint8_t *)d_q, n, score, d_o);
+    hipLaunchKernelGGL(quality_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint8_t *)d_s, (const uint8_t *)d_q, n, score, d_o);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_o, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -756,7 +762,7 @@ int ntk_synth_reads_device(ntk_ctx *c, uint64_t seed, uint64_t first_read, uint6
     HIPCHK(hipSetDevice(c->device));
     const uint64_t total = n_reads * ((uint64_t)read_len + 1);
     const uint64_t threads = (total + 15) / 16;
-    hipLaunchKernelGGL(synth_reads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(threads, 256)), dim3(256), 0, c->stream,
                        seed, first_read, n_reads, read_len, n_per_1024, d_out);
     HIPCHK(hipGetLastError());
     return NTK_OK;
@@ -769,7 +775,7 @@ int ntk_reverse_complement_records_device(ntk_ctx *c, const uint8_t *d_in, uint8
     if (n_records == 0) return NTK_OK;
     HIPCHK(hipSetDevice(c->device));
     const uint64_t total = n_records * stride;
-    hipLaunchKernelGGL(revcomp_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(revcomp_records_kernel, dim3(grid_for(total, 256)), dim3(256), 0, c->stream,
                        d_in, d_out, n_records, record_len, stride, (const uint16_t *)(c->d_lut + 768));
     HIPCHK(hipGetLastError());
     return NTK_OK;

@@ -255,19 +255,20 @@ __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part
 // byte LUT map (normalize / complement): out[i] = lut[in[i]] & 0xFF
 __global__ void map_reverse_kernel(const uint8_t *in, uint8_t *out, uint64_t n, const uint16_t *lut)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint8_t)lut[in[n - 1 - i]];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (uint8_t)lut[in[n - 1 - i]];
 }
 
 // Fixed-stride records, reverse-complemented record by record; bytes outside records are copied.
 __global__ void revcomp_records_kernel(const uint8_t *in, uint8_t *out, uint64_t n_records, uint32_t len,
                                        uint32_t stride, const uint16_t *lut)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_records * stride) return;
-    const uint64_t r = g / stride;
-    const uint32_t j = (uint32_t)(g - r * stride);
-    out[g] = j < len ? (uint8_t)lut[in[r * stride + (len - 1 - j)]] : in[g];
+    const uint64_t total = n_records * stride;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = g / stride;
+        const uint32_t j = (uint32_t)(g - r * stride);
+        out[g] = j < len ? (uint8_t)lut[in[r * stride + (len - 1 - j)]] : in[g];
+    }
 }
 
 // Stream compaction with a byte map: lut low byte = mapped char, bit 8 = "changed", bit 9 = "deleted".
@@ -348,8 +349,7 @@ __global__ __launch_bounds__(kCompactThreads) void compact_write_kernel(const ui
 // One thread per window start; flags8[p]: bit0 = emitted, bit1 = is_rc.  cls: 1 = good base; comp LUT.
 __global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t k, const uint16_t *comp_lut, uint8_t *flags8)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
     uint8_t f = 0;
     if (p + k <= n) {
         bool good = true;
@@ -367,6 +367,7 @@ __global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t 
         }
     }
     flags8[p] = f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,18 +434,18 @@ __device__ __forceinline__ uint64_t bit_revcomp(uint64_t x, uint32_t k)
 }
 __global__ void bit_minimizer_kernel(const uint64_t *in, uint64_t n, uint32_t k, uint32_t m, uint64_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t v = in[i], lowest = ~0ull;
     const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1);
-    for (uint32_t t = 0; t <= k - m; t++) {
-        const uint64_t cur = v & mask;
-        lowest = cur < lowest ? cur : lowest;
-        const uint64_t r = bit_revcomp(cur, k);
-        lowest = r < lowest ? r : lowest;
-        v >>= 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = in[i], lowest = ~0ull;
+        for (uint32_t t = 0; t <= k - m; t++) {
+            const uint64_t cur = v & mask;
+            lowest = cur < lowest ? cur : lowest;
+            const uint64_t r = bit_revcomp(cur, k);
+            lowest = r < lowest ? r : lowest;
+            v >>= 2;
+        }
+        out[i] = lowest;
     }
-    out[i] = lowest;
 }
 
 // sequence::minimizer (reference src/sequence.rs:139-152) for one sequence: the lexicographically smallest length-m
@@ -496,8 +497,8 @@ __global__ void minimizer_emit_kernel(const uint8_t *seq, uint64_t n, uint32_t m
 // QualitySequence::quality_mask (reference src/sequence.rs:285-296)
 __global__ void quality_mask_kernel(const uint8_t *seq, const uint8_t *qual, uint64_t n, uint8_t score, uint8_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = qual[i] < score ? (uint8_t)'N' : seq[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = qual[i] < score ? (uint8_t)'N' : seq[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,8 +516,7 @@ __global__ void synth_reads_kernel(uint64_t seed, uint64_t first_read, uint64_t 
                                    uint32_t n_per_1024, uint8_t *out)
 {
     const uint64_t total = n_reads * ((uint64_t)read_len + 1);
-    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (g0 >= total) return;
+  for (uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; g0 < total; g0 += (uint64_t)gridDim.x * blockDim.x * 16) {
     const uint32_t wpr = (read_len + 31) / 32, npr = (read_len + 5) / 6;
     uint64_t r = g0 / (read_len + 1);
     uint32_t j = (uint32_t)(g0 - r * (read_len + 1));
@@ -543,6 +543,7 @@ __global__ void synth_reads_kernel(uint64_t seed, uint64_t first_read, uint64_t 
     } else {
         for (int i = 0; i < 16 && g0 + i < total; i++) out[g0 + i] = buf[i];
     }
+  }
 }
 
 }  // namespace ntk

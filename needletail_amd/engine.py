@@ -70,8 +70,9 @@ class Context:
     def accum_reset(self):
         L.check(L.lib().ntk_accum_reset(self._h), "ntk_accum_reset")
 
-    def reduce_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int):
-        p = L.Params(k, path, pre, 0)
+    def reduce_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int, w: int = 0):
+        """w > 0: fold windowed minimizers (w k-mers per window) instead of every k-mer."""
+        p = L.Params(k, path, pre, w)
         L.check(L.lib().ntk_reduce_device(self._h, C.c_void_p(_ptr(d_seq)), n_bytes, C.byref(p)), "ntk_reduce_device")
 
     def accum_read(self) -> dict:
@@ -142,8 +143,8 @@ class Batch:
         o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(int(nr.value) + 1,))
         return s, o
 
-    def submit(self, k: int, path: int, pre: int):
-        p = L.Params(k, path, pre, 0)
+    def submit(self, k: int, path: int, pre: int, w: int = 0):
+        p = L.Params(k, path, pre, w)
         L.check(L.lib().ntk_batch_submit(self.ctx._h, self._h, C.byref(p)), "ntk_batch_submit")
 
     def wait(self):

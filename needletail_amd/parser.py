@@ -131,14 +131,14 @@ def parse_fastx_string(content) -> FastxReader:
     return FastxReader(data=content.encode() if isinstance(content, str) else bytes(content))
 
 
-def scan_file(ctx, path, k: int, path_kind: int, pre: int, batch_bytes: int = 64 << 20, n_batches: int = 3) -> dict:
+def scan_file(ctx, path, k: int, path_kind: int, pre: int, batch_bytes: int = 64 << 20, n_batches: int = 3, w: int = 0) -> dict:
     """The README program on the GPU: parse -> pinned batches -> overlapped H2D + scan; returns the reduced result plus
     n_records / n_bases (reference src/lib.rs:15-35)."""
     from .engine import result_to_dict
     rd = FastxReader(path=path)
     try:
         ctx.accum_reset()
-        p = L.Params(k, path_kind, pre, 0)
+        p = L.Params(k, path_kind, pre, w)
         nrec, nb = C.c_uint64(0), C.c_uint64(0)
         rc = L.lib().ntk_scan_reader(ctx._h, rd._h, C.byref(p), batch_bytes, n_batches, C.byref(nrec), C.byref(nb))
         if rc == 8:

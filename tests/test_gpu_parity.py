@@ -17,7 +17,8 @@ from _fastx import fasta_raw_seqs, fastq_raw_seqs  # noqa: E402
 @pytest.fixture(scope="module")
 def ctx():
     assert torch.cuda.is_available(), "these tests need a GPU"
-    c = nt.Context(0)
+    # kernels are enqueued on torch's current stream so that tensor initialisation (torch) and scans (library) are ordered
+    c = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     yield c
     c.close()
 
@@ -260,6 +261,10 @@ def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
     gz.write_bytes(gzip.compress(open(fq, "rb").read()))
     st = nt.scan_file(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 16)
     assert st["n_records"] == 2000 and st["n_bases"] == 250_000 and st["n_total"] == 209_965 and st["sum"] == 0x047AD82A7ED0CABA
+    # BASELINE.json configs[4]: gzip FASTQ stream + minimizers (w=11, k=21) through the same pipeline
+    recs_fq = fastq_raw_seqs(open(fq, "rb").read())
+    st = nt.scan_file(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 16, w=11)
+    assert_stats_equal(st, O.minimizers_reduce(b"".join(r + b"\n" for r in recs_fq), 21, 11, True, True), "gz minimizers")
     with pytest.raises(nt.NtkError) as e:   # a record longer than a batch is an error, not a silent truncation
         nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1024)
     assert e.value.status == 5
@@ -331,6 +336,33 @@ def test_materialize_dense(ctx, k, path):
         assert np.array_equal(vals[ends], val)
         assert np.array_equal(rcb[ends].astype(np.uint8), flg)
         start += len(r) + 1
+
+
+def test_full_size_properties_config3(ctx):
+    """BASELINE.json configs[2]: 1M x 10 kb contigs, k=31 bit path (strip_returns -> bit_kmers(31, true)); sample prefix vs
+    the oracle, linearity, reverse-complement invariance."""
+    n_contigs, L, k = 1_000_000, 10_000, 31
+    stride = L + 1
+    nbytes = n_contigs * stride
+    t = torch.empty(nbytes + 1024, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0003, 0, n_contigs, L, 1, t)
+    path, pre = nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS
+    ctx.accum_reset(); ctx.reduce_device(t, nbytes, k, path, pre); whole = ctx.accum_read()
+    assert whole["n_total"] == whole["n_fwd"] + whole["n_rc"] == int(whole["hist"].sum())
+    assert 0 < whole["n_total"] <= n_contigs * (L - k + 1)
+    sample = 300
+    ctx.accum_reset(); ctx.reduce_device(t, sample * stride, k, path, pre)
+    assert_stats_equal(ctx.accum_read(), O.reduce_fused(O.synth_reads(0x5EED0003, 0, sample, L, 1), k, True, False, False), "sample")
+    a, b = 16 * 7_001, 16 * 40_003
+    ctx.accum_reset()
+    for lo, hi in ((0, a), (a, b), (b, n_contigs)):
+        ctx.reduce_device(t.data_ptr() + lo * stride, (hi - lo) * stride, k, path, pre)
+    assert_stats_equal(ctx.accum_read(), whole, "linearity")
+    t2 = torch.empty_like(t)
+    ctx.reverse_complement_records_device(t, t2, n_contigs, L, stride)
+    ctx.accum_reset(); ctx.reduce_device(t2, nbytes, k, path, pre); rcst = ctx.accum_read()
+    assert rcst["n_total"] == whole["n_total"] and rcst["n_fwd"] == whole["n_rc"] and rcst["sum"] == whole["sum"]
+    assert rcst["xor"] == whole["xor"] and np.array_equal(rcst["hist"], whole["hist"])
 
 
 # ---- synthetic generator and BASELINE-size properties ----------------------------------------------------
