@@ -106,7 +106,7 @@ struct MaterializeSink {
 // bytes each) with the next tile's load in flight while the current one is processed; no byte is fetched from HBM
 // twice (the 32 halo bytes of a tile come back from L2).
 // ---------------------------------------------------------------------------------------------
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE>
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0>
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
     using Sink = typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
             u32x4 nxt = cur;
             if (t + 1 < t1) nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);  // wave-uniform
             const bool tail = (t + 1) * kTileStride > a.n_bytes;
-            lane_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
+            lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
             cur = nxt; voff += kTileStride; lane_base += kTileStride;
         }
         next = __builtin_amdgcn_readfirstlane(next);

@@ -188,9 +188,9 @@ constexpr int kHaloLanes = 2;
 constexpr int kTileSlots = 64 - kHaloLanes;         // emitting 16-byte slots per tile
 constexpr int kTileStride = kTileSlots * 16;        // 992 bytes
 
-enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 = 20, kNumSlots = 21 };
+enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 = 20, kSlotCode1 = 21, kNumSlots = 22 };
 
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, class Sink, class XL>
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX, class Sink, class XL>
 NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t lane_base, bool halo_lane, bool tail_tile)
 {
 #ifdef NTK_ABL_NOENC
@@ -207,19 +207,43 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
     const uint32_t b1 = xl.prev(kSlotBad, en.bad);
     const uint32_t b2 = xl.prev(kSlotBad1, b1);
 
+    // k-specialised builds (KFIX = 21, 31): every k-derived quantity is an immediate, and the hi word of a value is a
+    // plain shift of the lo word computed D = k-16 positions away (see below) instead of its own funnel shift + mask.
+    constexpr bool FIX = KFIX > 16 && KW == 2;
+    const uint32_t sh_r = FIX ? (uint32_t)(64 - 2 * KFIX) : a.sh_r;
+    const uint32_t mask_hi = FIX ? (KFIX == 32 ? 0xFFFFFFFFu : ((1u << ((2 * KFIX - 32) & 31)) - 1u)) : a.mask_hi;
+
     // windows containing a break: OR every break bit over the k window-end positions that follow it
     uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;
+    if (FIX) {
+        int len = 1;
 #pragma unroll
-    for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+        for (int i = 0; i < 5; i++) { const int sft = len < KFIX ? (len < KFIX - len ? len : KFIX - len) : 0; bw |= bw >> sft; len += sft; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+    }
     const uint32_t inval = halo_lane ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
     sink.begin_tile(lane_base, inval, halo_lane);
 
     uint32_t Q[3];
-    Q[0] = en.rcode >> a.sh_r;
-    Q[1] = alignbit(en.rcode, r1, a.sh_r);
+    Q[0] = en.rcode >> sh_r;
+    Q[1] = alignbit(en.rcode, r1, sh_r);
     Q[2] = KW == 2 ? xl.prev(kSlotQ1, Q[1]) : 0u;  // == alignbit(R[lane-1], R[lane-2], sh_r)
     uint32_t vbits = inval << 16;  // bit 31 = window ending at own base 0; one flag is shifted out per position
-    const uint32_t mask_hi_v = a.mask_hi;
+    const uint32_t mask_hi_v = mask_hi;
+    // FIX: all lo words first.  hi of the forward value at j = top 2k-32 bits of the lo word at j-D (same lane for
+    // j >= D); hi of the reverse-complement value at j = top bits of its lo word at j+D (same lane for j+D <= 15).
+    constexpr int D = FIX ? KFIX - 16 : 0, S = FIX ? 64 - 2 * KFIX : 0;
+    uint32_t fls[16], rls[16], W2[3] = {0u, c1, en.code};
+    if (FIX) {
+        W2[0] = xl.prev(kSlotCode1, c1);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            fls[j] = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
+            rls[j] = win32(Q, 32 + 2 * (15 - j));
+        }
+    }
 #ifdef NTK_ABL_NOPOS
     sink.emit(0, (vbits ^ Q[0] ^ Q[1] ^ Q[2] ^ c1) == 0x12345u, true, mask_hi_v, c1);  // ablation: no per-position work
     sink.end_tile();
@@ -228,12 +252,17 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         uint32_t fh = 0, fl, rh = 0, rl;
-        fl = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
-        if (KW == 2) {
+        if (FIX) {
+            fl = fls[j]; rl = rls[j];
+            fh = j >= D ? (S ? fls[j >= D ? j - D : 0] >> S : fls[j >= D ? j - D : 0]) : (win32(W2, 2 + 2 * j) & mask_hi);
+            rh = j + D <= 15 ? (S ? rls[j + D <= 15 ? j + D : 0] >> S : rls[j + D <= 15 ? j + D : 0]) : (win32(Q, 2 * (15 - j)) & mask_hi);
+        } else if (KW == 2) {
+            fl = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
             fh = xl.prev_and(j, fl, mask_hi_v);
-            rh = win32(Q, 2 * (15 - j)) & a.mask_hi;
+            rh = win32(Q, 2 * (15 - j)) & mask_hi;
             rl = win32(Q, 32 + 2 * (15 - j));
         } else {
+            fl = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
             fl &= a.mask_lo;
             rl = win32(Q, 2 * (15 - j)) & a.mask_lo;
         }

@@ -64,7 +64,7 @@ Raw16 load16(const uint8_t *buf, uint64_t n_padded, int64_t off)
     return r;
 }
 
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U>
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX = 0>
 void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st, uint64_t *values,
          uint16_t *valid16, uint16_t *rc16)
 {
@@ -79,7 +79,7 @@ void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStat
             for (int l = 0; l < 64; l++) {
                 xl.next_lane(l == 0);
                 const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
-                lane_tile<KW, CANON, TIE_RC, ACCEPT_U>(a, sinks[l], xl, load16(buf, n_padded, lane_base), lane_base,
+                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sinks[l], xl, load16(buf, n_padded, lane_base), lane_base,
                                                        l < kHaloLanes, tail);
             }
         }
@@ -102,6 +102,12 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     a.n_bytes = n; (void)tiles_per_wave;
     HostStats *st = new HostStats();
     const int kw = k > 16 ? 2 : 1;
+    // tiles_per_wave doubles as a switch in this emulation: an odd value selects the k-specialised build when one exists
+    const bool fix = (tiles_per_wave & 1) && canon && (k == 21 || k == 31);
+#define EMU_FIX(KF, T, U) if (fix && k == KF && !!tie_rc == T && !!accept_u == U) { run<2, true, T, U, KF>(buf, n, n_padded, a, st, values, valid16, rc16); } else
+    EMU_FIX(21, false, false) EMU_FIX(21, false, true) EMU_FIX(21, true, false) EMU_FIX(21, true, true)
+    EMU_FIX(31, false, false) EMU_FIX(31, false, true) EMU_FIX(31, true, false) EMU_FIX(31, true, true)
+    {
 #define EMU_CASE(KW, C, T, U) \
     if (kw == KW && !!canon == C && !!tie_rc == T && !!accept_u == U) run<KW, C, T, U>(buf, n, n_padded, a, st, values, valid16, rc16);
     EMU_CASE(1, false, false, false) EMU_CASE(1, false, false, true)
@@ -112,6 +118,7 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     EMU_CASE(2, true, false, false) EMU_CASE(2, true, false, true)
     EMU_CASE(2, true, true, false) EMU_CASE(2, true, true, true)
     EMU_CASE(2, false, true, false) EMU_CASE(2, false, true, true)
+    }
     out[0] = st->n_total; out[1] = st->n_fwd; out[2] = st->sum; out[3] = st->xr;
     memcpy(out + 4, st->hist, sizeof(st->hist));
     delete st;

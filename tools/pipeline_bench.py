@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""End-to-end (host-buffer, PCIe-inclusive) rate of the pinned-batch face: FASTQ text in host memory -> C++ reader ->
+pinned batches -> hipMemcpyAsync (copy stream) overlapped with the scan kernels.  Also the materialise-mode rate.
+Not the headline metric (bench.py times device-resident batches); DESIGN.md quotes these numbers."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import needletail_amd as nt
+from needletail_amd import _lib as L
+import ctypes as C
+
+reads, RL, k = int(os.environ.get("READS", 2_000_000)), 150, 21
+ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+dev = torch.empty(reads * (RL + 1) + 1024, dtype=torch.uint8, device="cuda")
+ctx.synth_reads_device(0x5EED0002, 0, reads, RL, 1, dev)
+torch.cuda.synchronize()
+seqs = dev[: reads * (RL + 1)].cpu().numpy().reshape(reads, RL + 1)
+# FASTQ text: "@r<i>\n" + seq + "\n+\n" + 'I'*150 + "\n" with fixed-width ids so that numpy can build it
+idw = 9
+rec = np.empty((reads, 1 + idw + 1 + RL + 1 + 2 + RL + 1), dtype=np.uint8)
+rec[:, 0] = ord("@")
+ids = np.char.zfill(np.arange(reads).astype(str), idw)
+rec[:, 1:1 + idw] = np.frombuffer("".join(ids).encode(), dtype=np.uint8).reshape(reads, idw)
+rec[:, 1 + idw] = 10
+rec[:, 2 + idw:2 + idw + RL] = seqs[:, :RL]
+rec[:, 2 + idw + RL] = 10
+rec[:, 3 + idw + RL] = ord("+")
+rec[:, 4 + idw + RL] = 10
+rec[:, 5 + idw + RL:5 + idw + 2 * RL] = ord("I")
+rec[:, 5 + idw + 2 * RL] = 10
+text = rec.tobytes()
+del rec
+
+def run(batch_bytes, n_batches):
+    rd = nt.FastxReader(data=text)
+    ctx.accum_reset()
+    p = L.Params(k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, 0)
+    nrec, nb = C.c_uint64(0), C.c_uint64(0)
+    t0 = time.perf_counter()
+    rc = L.lib().ntk_scan_reader(ctx._h, rd._h, C.byref(p), batch_bytes, n_batches, C.byref(nrec), C.byref(nb))
+    st = ctx.accum_read()
+    dt = time.perf_counter() - t0
+    assert rc == 0 and nrec.value == reads
+    return dt, st
+
+# reference result from the device-resident path
+ctx.accum_reset(); ctx.reduce_device(dev, reads * (RL + 1), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE); want = ctx.accum_read()
+out = {"reads": reads, "fastq_text_bytes": len(text)}
+for bb, nbat in ((8 << 20, 3), (64 << 20, 3)):
+    best = None
+    for _ in range(3):
+        dt, st = run(bb, nbat)
+        assert st["n_total"] == want["n_total"] and st["sum"] == want["sum"] and st["xor"] == want["xor"]
+        best = dt if best is None else min(best, dt)
+    out[f"pipeline_batch{bb >> 20}MiB"] = {"seconds": round(best, 4), "Gbases_s": round(reads * RL / best / 1e9, 3),
+                                           "fastq_GB_s": round(len(text) / best / 1e9, 3)}
+# parser alone (no GPU work): upper bound of the single-threaded producer
+t0 = time.perf_counter(); rd = nt.FastxReader(data=text); n = 0
+rec_ = L.Record()
+while L.lib().ntk_reader_next(rd._h, C.byref(rec_)) == 0:
+    n += 1
+dt = time.perf_counter() - t0
+out["parser_only"] = {"seconds": round(dt, 4), "fastq_GB_s": round(len(text) / dt / 1e9, 3)}
+# materialise mode on the device-resident batch
+nbytes = reads * (RL + 1)
+vals = torch.empty((nbytes + 15) // 16 * 16, dtype=torch.int64, device="cuda")
+v16 = torch.empty((nbytes + 15) // 16, dtype=torch.int16, device="cuda"); r16 = torch.empty_like(v16)
+for _ in range(2):
+    ctx.materialize_device(dev, nbytes, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, vals, v16, r16)
+torch.cuda.synchronize(); ctx.scan_time_ms(); ctx.enable_timing(True)
+for _ in range(5):
+    ctx.materialize_device(dev, nbytes, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, vals, v16, r16)
+ms, nl = ctx.scan_time_ms(); ctx.enable_timing(False)
+out["materialize"] = {"kernel_ms": round(ms / nl, 4), "Gbases_s": round(reads * RL / (ms / nl * 1e-3) / 1e9, 1),
+                      "GB_s_read_plus_write": round((nbytes + nbytes * 8 + nbytes / 4) / (ms / nl * 1e-3) / 1e9, 1)}
+print(json.dumps(out))

@@ -86,6 +86,46 @@ BENCH_KERNEL(k_mulu64u32, {
                  "v_mad_u64_u32 %0, vcc, %5, 1, %0\n v_mad_u64_u32 %1, vcc, %6, 1, %1\n v_mad_u64_u32 %2, vcc, %7, 1, %2\n v_mad_u64_u32 %3, vcc, %4, 1, %3\n"
                  : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc"); })
 
+
+BENCH_KERNEL(k_cmp_sdwa, {
+    asm volatile("v_cmp_ne_u32_sdwa s[20:21], %0, %1 src0_sel:BYTE_0 src1_sel:BYTE_0\n v_cmp_ne_u32_sdwa s[22:23], %0, %1 src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+                 "v_cmp_ne_u32_sdwa s[24:25], %0, %1 src0_sel:BYTE_2 src1_sel:BYTE_2\n v_cmp_ne_u32_sdwa s[26:27], %0, %1 src0_sel:BYTE_3 src1_sel:BYTE_3\n"
+                 "v_cmp_ne_u32_sdwa s[20:21], %2, %3 src0_sel:BYTE_0 src1_sel:BYTE_0\n v_cmp_ne_u32_sdwa s[22:23], %2, %3 src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+                 "v_cmp_ne_u32_sdwa s[24:25], %2, %3 src0_sel:BYTE_2 src1_sel:BYTE_2\n v_cmp_ne_u32_sdwa s[26:27], %2, %3 src0_sel:BYTE_3 src1_sel:BYTE_3\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27"); })
+BENCH_KERNEL(k_salu_or64, {
+    asm volatile("s_or_b64 s[20:21], s[20:21], s[22:23]\n s_lshl_b64 s[22:23], s[22:23], 1\n s_or_b64 s[24:25], s[24:25], s[26:27]\n s_lshl_b64 s[26:27], s[26:27], 1\n"
+                 "s_or_b64 s[20:21], s[20:21], s[26:27]\n s_bcnt1_i32_b64 s28, s[22:23]\n s_or_b64 s[24:25], s[24:25], s[22:23]\n s_add_u32 s29, s29, s28\n"
+                 : "+v"(a0) : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "scc"); })
+BENCH_KERNEL(k_mixed_valu_salu, {
+    asm volatile("v_add_u32 %0, %0, %1\n s_or_b64 s[20:21], s[20:21], s[22:23]\n v_add_u32 %2, %2, %3\n s_lshl_b64 s[22:23], s[22:23], 1\n"
+                 "v_add_u32 %1, %1, %0\n s_bcnt1_i32_b64 s28, s[22:23]\n v_add_u32 %3, %3, %2\n s_add_u32 s29, s29, s28\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "s21", "s22", "s23", "s28", "s29", "scc"); })
+BENCH_KERNEL(k_mixed_valu_2salu, {
+    asm volatile("v_add_u32 %0, %0, %1\n s_or_b64 s[20:21], s[20:21], s[22:23]\n s_lshl_b64 s[22:23], s[22:23], 1\n s_bcnt1_i32_b64 s28, s[22:23]\n"
+                 "v_add_u32 %1, %1, %0\n s_add_u32 s29, s29, s28\n s_or_b64 s[24:25], s[24:25], s[22:23]\n s_andn2_b64 s[26:27], s[24:25], s[20:21]\n"
+                 : "+v"(a0), "+v"(a1) : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "scc"); })
+BENCH_KERNEL(k_lshl_or, {
+    asm volatile("v_lshl_or_b32 %0, %0, 2, %1\n v_lshl_or_b32 %2, %2, 2, %3\n v_lshl_or_b32 %4, %4, 2, %5\n v_lshl_or_b32 %6, %6, 2, %7\n"
+                 "v_lshl_or_b32 %1, %1, 2, %0\n v_lshl_or_b32 %3, %3, 2, %2\n v_lshl_or_b32 %5, %5, 2, %4\n v_lshl_or_b32 %7, %7, 2, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_bfe, {
+    asm volatile("v_bfe_u32 %0, %1, 3, 10\n v_bfe_u32 %2, %3, 3, 10\n v_bfe_u32 %4, %5, 3, 10\n v_bfe_u32 %6, %7, 3, 10\n"
+                 "v_bfe_u32 %1, %0, 5, 10\n v_bfe_u32 %3, %2, 5, 10\n v_bfe_u32 %5, %4, 5, 10\n v_bfe_u32 %7, %6, 5, 10\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_cndmask, {
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n"
+                 "v_cndmask_b32 %1, %1, %0, vcc\n v_cndmask_b32 %3, %3, %2, vcc\n v_cndmask_b32 %5, %5, %4, vcc\n v_cndmask_b32 %7, %7, %6, vcc\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3) : : ); })
+BENCH_KERNEL(k_lshr32, {
+    asm volatile("v_lshrrev_b32 %0, 3, %1\n v_lshrrev_b32 %2, 3, %3\n v_lshrrev_b32 %4, 3, %5\n v_lshrrev_b32 %6, 3, %7\n"
+                 "v_lshrrev_b32 %1, 5, %0\n v_lshrrev_b32 %3, 5, %2\n v_lshrrev_b32 %5, 5, %4\n v_lshrrev_b32 %7, 5, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_and_or, {
+    asm volatile("v_and_or_b32 %0, %0, %1, %2\n v_and_or_b32 %2, %2, %3, %4\n v_and_or_b32 %4, %4, %5, %6\n v_and_or_b32 %6, %6, %7, %0\n"
+                 "v_and_or_b32 %1, %1, %0, %3\n v_and_or_b32 %3, %3, %2, %5\n v_and_or_b32 %5, %5, %4, %7\n v_and_or_b32 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+
 __global__ __launch_bounds__(256) void k_ldsadd(uint32_t *out, uint32_t seed)
 {
     __shared__ uint32_t h[4096];
@@ -125,7 +165,9 @@ int main()
                 {"v_mov_dpp wave_shr", k_dpp_shr}, {"v_mov_dpp row_shr", k_dpp_rowshr}, {"v_lshrrev_b64", k_lshr64},
                 {"v_lshl_add_u64", k_lshladd64}, {"v_cmp_lt_u64", k_cmp64}, {"v_cmp_lt_u32", k_cmp32},
                 {"cmp32+cndmask pair", k_cmp_cndmask}, {"v_add_co_u32", k_addco}, {"addco+saveexec+add+restore (per 4)", k_saveexec},
-                {"v_mad_u64_u32", k_mulu64u32}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
+                {"v_mad_u64_u32", k_mulu64u32}, {"v_cmp_ne_u32_sdwa (byte sel)", k_cmp_sdwa}, {"SALU only (or/lshl/bcnt/add b64)", k_salu_or64},
+                {"VALU add + SALU 1:1", k_mixed_valu_salu}, {"VALU add + SALU 1:3", k_mixed_valu_2salu}, {"v_lshl_or_b32", k_lshl_or}, {"v_bfe_u32", k_bfe},
+                {"v_cndmask_b32", k_cndmask}, {"v_lshrrev_b32", k_lshr32}, {"v_and_or_b32", k_and_or}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     for (auto &b : list) {
