@@ -66,7 +66,23 @@ inline void scan_args_set_k(ScanArgs &a, uint32_t k)
 // ---------------------------------------------------------------------------------------------
 // instruction-level helpers: gfx950 builtins on device, portable C on the host
 // ---------------------------------------------------------------------------------------------
-NTK_HD uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// v_bitop3_b32: any 3-input bitwise function in ONE full-rate VALU op (v_bfi/v_and_or/v_or3/v_lshl_or are half-rate
+// on gfx950, tools/ubench.hip).  TT bit (a<<2 | b<<1 | c) is the result for that input combination.
+template <int TT>
+NTK_HD uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 8; i++)
+        if ((TT >> i) & 1) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+    return r;
+#endif
+}
+NTK_HD uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return bitop3<0xCA>(mask, a, b); }  // (a & mask) | (b & ~mask)
+NTK_HD uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0xEA>(a, b, c); }      // (a & b) | c
+NTK_HD uint32_t or_and(uint32_t a, uint32_t b, uint32_t c) { return bitop3<0xA8>(a, b, c); }      // (a | b) & c
 
 NTK_HD uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)  // v_perm_b32: selector 0-3 -> lo bytes, 4-7 -> hi bytes
 {
@@ -152,15 +168,15 @@ NTK_HD Enc encode16(Raw16 d)
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         uint32_t u = e[s] & 0xDFDFDFDFu;
-        if (ACCEPT_U) u |= (u >> 4) & 0x01010101u;
+        if (ACCEPT_U) u = and_or(u >> 4, 0x01010101u, u);
         const uint32_t sel = (e[s] >> 1) & 0x03030303u;
         const uint32_t dif = perm(0u, kTable, sel) ^ u;
         h[s] = ((dif & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | dif;  // bit 7 of every byte: byte differs
     }
     uint32_t g = bfi(0x80808080u, h[0], bfi(0x40404040u, h[1] >> 1, bfi(0x20202020u, h[2] >> 2, h[3] >> 3)));
     g = (g >> 4) & 0x0F0F0F0Fu;
-    g = (g | (g >> 4)) & 0x00FF00FFu;
-    r.bad = (g | (g >> 8)) & 0xFFFFu;
+    g = or_and(g, g >> 4, 0x00FF00FFu);
+    r.bad = or_and(g, g >> 8, 0xFFFFu);
     return r;
 }
 
