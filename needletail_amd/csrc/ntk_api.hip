@@ -160,14 +160,16 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 template <bool REDUCE>
 hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, hipStream_t st)
 {
-    // k-specialised build for the headline k = 21 (measured -5 %; at k = 31 the generic build is faster because only one of
-    // the 16 hi words can be derived from a lo word in the same lane, tools/kbench.hip A/B in profiles/)
+    // k-specialised builds for the two k of the reference's own workloads (21: headline; 31: benches/benchmark.rs:15).
+    // Reduce mode runs the scalar-validity variant (-10 %); materialise mode the k = 21 per-lane variant (-5 %; at k = 31
+    // the generic build is faster there: only one of the 16 hi words can be derived from a lo word of the same lane).
 #define NTK_LAUNCH_FIX(KF, T, U)                                                                \
     if (m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {                \
-        hipLaunchKernelGGL((scan_kernel<2, true, T, U, REDUCE, KF>), grid, block, 0, st, a);    \
+        hipLaunchKernelGGL((scan_kernel<2, true, T, U, REDUCE, KF, REDUCE>), grid, block, 0, st, a);  /* reduce: scalar validity */ \
         return hipGetLastError();                                                               \
     }
     NTK_LAUNCH_FIX(21, false, false) NTK_LAUNCH_FIX(21, false, true) NTK_LAUNCH_FIX(21, true, false) NTK_LAUNCH_FIX(21, true, true)
+    if (REDUCE) { NTK_LAUNCH_FIX(31, false, false) NTK_LAUNCH_FIX(31, false, true) NTK_LAUNCH_FIX(31, true, false) NTK_LAUNCH_FIX(31, true, true) }
 #undef NTK_LAUNCH_FIX
 #define NTK_LAUNCH(KW, C, T, U)                                                                 \
     if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U) {                       \

@@ -101,15 +101,68 @@ struct MaterializeSink {
 };
 
 // ---------------------------------------------------------------------------------------------
+// "sv" reduce path (k-specialised, 17 <= k <= 32): break flags and window validity in scalar registers (ntk_tile.hpp)
+// ---------------------------------------------------------------------------------------------
+struct ReduceSinkSV {
+    uint64_t sum = 0, xr = 0;
+    uint32_t *hist;
+    uint32_t bin_shift;
+    __device__ __forceinline__ void add(uint32_t hi, uint32_t lo)
+    {
+        const uint64_t v = ((uint64_t)hi << 32) | lo;
+        sum += v;
+        xr ^= v;
+        atomicAdd(&hist[(uint32_t)(v >> bin_shift)], 1u);
+    }
+};
+
+// 64-bit lane mask "byte BSEL of a == byte BSEL of b" in one SDWA compare, written straight to an SGPR pair.
+#define NTK_SDWA_EQ(dst, a, b, BSEL) \
+    asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:" #BSEL " src1_sel:" #BSEL : "=s"(dst) : "v"(a), "v"(b))
+
+struct DevMasks {
+    uint64_t V[16];  // lane masks: window ending at byte j is emitted
+    uint32_t n_fwd_lane = 0;
+
+    template <int K>
+    __device__ __forceinline__ void compute(const EncSV &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
+    {
+        uint64_t B[16];
+        // base i <-> byte (3 - i/4) of word i%4
+        NTK_SDWA_EQ(B[0], en.ex[0], en.uu[0], BYTE_3);  NTK_SDWA_EQ(B[1], en.ex[1], en.uu[1], BYTE_3);
+        NTK_SDWA_EQ(B[2], en.ex[2], en.uu[2], BYTE_3);  NTK_SDWA_EQ(B[3], en.ex[3], en.uu[3], BYTE_3);
+        NTK_SDWA_EQ(B[4], en.ex[0], en.uu[0], BYTE_2);  NTK_SDWA_EQ(B[5], en.ex[1], en.uu[1], BYTE_2);
+        NTK_SDWA_EQ(B[6], en.ex[2], en.uu[2], BYTE_2);  NTK_SDWA_EQ(B[7], en.ex[3], en.uu[3], BYTE_2);
+        NTK_SDWA_EQ(B[8], en.ex[0], en.uu[0], BYTE_1);  NTK_SDWA_EQ(B[9], en.ex[1], en.uu[1], BYTE_1);
+        NTK_SDWA_EQ(B[10], en.ex[2], en.uu[2], BYTE_1); NTK_SDWA_EQ(B[11], en.ex[3], en.uu[3], BYTE_1);
+        NTK_SDWA_EQ(B[12], en.ex[0], en.uu[0], BYTE_0); NTK_SDWA_EQ(B[13], en.ex[1], en.uu[1], BYTE_0);
+        NTK_SDWA_EQ(B[14], en.ex[2], en.uu[2], BYTE_0); NTK_SDWA_EQ(B[15], en.ex[3], en.uu[3], BYTE_0);
+        if (tail_tile) {  // wave-uniform: bytes at or beyond n_bytes are breaks (the last 16-B line may carry padding)
+#pragma unroll
+            for (int i = 0; i < 16; i++) B[i] &= __builtin_amdgcn_ballot_w64(lane_base + i < (int64_t)n_bytes);
+        }
+        window_masks<K>(B, V);
+    }
+
+    __device__ __forceinline__ void emit(ReduceSinkSV &sink, int j, bool take_fwd, uint32_t hi, uint32_t lo)
+    {
+        // the forward-strand count stays a per-lane v_addc: a scalar popcount would cost three more SALU instructions
+        // per position and the scalar unit (one per CU) is the co-bottleneck of this variant (tools/kbench.hip A/B)
+        if (__builtin_amdgcn_inverse_ballot_w64(V[j])) { sink.add(hi, lo); n_fwd_lane += take_fwd ? 1u : 0u; }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // the scan kernel (template flags: see lane_tile in ntk_tile.hpp; ACCEPT_U: U/u is a base coding T because the
 // records went through normalize).  Work split: every wave streams its own contiguous run of tiles (992 emitting
 // bytes each) with the next tile's load in flight while the current one is processed; no byte is fetched from HBM
 // twice (the 32 halo bytes of a tile come back from L2).
 // ---------------------------------------------------------------------------------------------
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0>
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0, bool SV = false>
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
-    using Sink = typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type;
+    static_assert(!SV || (REDUCE && KW == 2 && KFIX >= 17), "the scalar-validity path is a k-specialised reduce path");
+    using Sink = typename std::conditional<SV, ReduceSinkSV, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
     __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
     __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
 
@@ -141,6 +194,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     uint32_t *ctr = a.work_counters + shard * 16;
     const uint32_t shard_tiles = shard_begin < shard_end ? (uint32_t)(shard_end - shard_begin) : 0u;
     DevXL xl;
+    DevMasks mp;
     const bool halo_lane = lane < (uint32_t)kHaloLanes;
 
     uint32_t next = 0;
@@ -171,7 +225,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
             u32x4 nxt = cur;
             if (t + 1 < t1) nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);  // wave-uniform
             const bool tail = (t + 1) * kTileStride > a.n_bytes;
-            lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
+            if constexpr (SV) {
+                const EncSV en = encode16_sv<ACCEPT_U>(Raw16{cur.x, cur.y, cur.z, cur.w});
+                mp.template compute<KFIX>(en, tail, lane_base, a.n_bytes);
+                lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
+            } else {
+                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
+            }
             cur = nxt; voff += kTileStride; lane_base += kTileStride;
         }
         next = __builtin_amdgcn_readfirstlane(next);
@@ -189,7 +249,17 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 #endif
     if constexpr (REDUCE) {
         // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
-        uint64_t sum = sink.sum, xr = sink.xr, nf = sink.n_fwd, nv = sink.n_valid;
+        uint64_t sum = sink.sum, xr = sink.xr, nf, nv;
+        uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
+        if constexpr (SV) {
+            // the sv path does not count emitted windows one by one: every emit increments exactly one bin, so the
+            // block's n_total is the sum of its histogram, taken while the histogram is copied out
+            nf = mp.n_fwd_lane; nv = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) { const uint32_t h = s_hist[i]; ph[i] = h; nv += h; }
+        } else {
+            nf = sink.n_fwd; nv = sink.n_valid;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sum += __shfl_xor(sum, o, 64);
@@ -199,8 +269,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         }
         if (lane == 0) { s_red[wave * 4 + 0] = nv; s_red[wave * 4 + 1] = nf; s_red[wave * 4 + 2] = sum; s_red[wave * 4 + 3] = xr; }
         __syncthreads();
-        uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
-        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
+        if constexpr (!SV)
+            for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
         if (threadIdx.x == 0) {
             uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
             for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {

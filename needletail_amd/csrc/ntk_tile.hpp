@@ -297,4 +297,105 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
     sink.end_tile();
 }
 
+// ---------------------------------------------------------------------------------------------
+// "sv" variant of the tile logic: window validity lives in SCALAR registers.
+//
+// On the device the 16 per-byte break flags are produced directly as 64-bit lane masks B[i] (bit l = byte i of lane l
+// is a break) by 16 SDWA byte compares, and the "window ending at byte j of lane l contains a break" masks V[j] follow
+// from them with scalar OR / shift only: the window covers bytes j-k+1..j, i.e. (for k >= 17) bytes 0..j of the lane,
+// bytes a..15 of the previous lane (a = max(0, 17+j-k); a lane shift is a 1-bit shift of the mask) and, when 17+j-k < 0,
+// bytes 33+j-k..15 of the lane before.  The mask then gates the emit through exec with no VALU work per position.
+// k is a compile-time constant here.
+// The host emulation computes B from the same per-lane expected/actual bytes and runs the same mask algebra.
+// ---------------------------------------------------------------------------------------------
+struct EncSV {
+    uint32_t code, rcode;
+    uint32_t ex[4];  // expected letter per byte: byte (3-u) of word s belongs to base 4u+s
+    uint32_t uu[4];  // the byte as read, case-folded (and with T/U merged when ACCEPT_U)
+};
+
+template <bool ACCEPT_U>
+NTK_HD EncSV encode16_sv(Raw16 d)
+{
+    const uint32_t x0 = perm(d.x, d.y, 0x04000501u), x1 = perm(d.x, d.y, 0x06020703u);
+    const uint32_t y0 = perm(d.z, d.w, 0x04000501u), y1 = perm(d.z, d.w, 0x06020703u);
+    const uint32_t e[4] = {perm(x0, y0, 0x07060302u), perm(x0, y0, 0x05040100u), perm(x1, y1, 0x07060302u), perm(x1, y1, 0x05040100u)};
+    const uint32_t m = bfi(0xC0C0C0C0u, e[0] << 5, bfi(0x30303030u, e[1] << 3, bfi(0x0C0C0C0Cu, e[2] << 1, e[3] >> 1)));
+    EncSV r;
+    r.code = m ^ ((m >> 1) & 0x55555555u);
+    const uint32_t t = brev32(~r.code);
+    r.rcode = bfi(0x55555555u, t >> 1, t << 1);
+    constexpr uint32_t kTable = ACCEPT_U ? 0x47554341u : 0x47544341u;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        uint32_t u = e[s] & 0xDFDFDFDFu;
+        if (ACCEPT_U) u = and_or(u >> 4, 0x01010101u, u);
+        r.uu[s] = u;
+        r.ex[s] = perm(0u, kTable, (e[s] >> 1) & 0x03030303u);
+    }
+    return r;
+}
+
+// break bit of base i of one lane (host side of the SDWA compare): byte (3 - i/4) of word i%4
+NTK_HD bool sv_base_is_break(const EncSV &e, int i)
+{
+    const int s = i & 3, sh = 8 * (3 - (i >> 2));
+    return ((e.ex[s] >> sh) & 0xFFu) != ((e.uu[s] >> sh) & 0xFFu);
+}
+
+// OK[j] (window ending at byte j is emitted) from G[i] (byte i is a base), as lane masks; K >= 17.  Positive logic so
+// that the result feeds s_and_saveexec directly; a lane shift fills lane 0 with "not a base", and lanes 0 and 1 (halo
+// lanes) are cleared: all their windows are invalid.
+template <int K>
+NTK_HD void window_masks(const uint64_t (&G)[16], uint64_t (&OK)[16])
+{
+    static_assert(K >= 17 && K <= 32, "sv path is built for 17 <= k <= 32");
+    uint64_t P[16], S[16];
+    P[0] = G[0];
+#pragma unroll
+    for (int j = 1; j < 16; j++) P[j] = P[j - 1] & G[j];
+    S[15] = G[15];
+#pragma unroll
+    for (int i = 14; i >= 0; i--) S[i] = S[i + 1] & G[i];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int c = 17 + j - K, a_ = c > 0 ? c : 0;
+        uint64_t v = P[j] & (S[a_] << 1);
+        if (c < 0) v &= S[(33 + j - K) & 15] << 2;
+        OK[j] = v & ~3ull;
+    }
+}
+
+template <bool CANON, bool TIE_RC, int KFIX, class Sink, class XL, class MP>
+NTK_HD void lane_tile_sv(Sink &sink, XL &xl, MP &mp, const EncSV &en)
+{
+    constexpr int D = KFIX - 16, S = 64 - 2 * KFIX;
+    constexpr uint32_t mask_hi = KFIX == 32 ? 0xFFFFFFFFu : ((1u << ((2 * KFIX - 32) & 31)) - 1u);
+    const uint32_t c1 = xl.prev(kSlotCode, en.code);
+    const uint32_t r1 = xl.prev(kSlotRcode, en.rcode);
+    uint32_t Q[3];
+    Q[0] = S ? en.rcode >> S : en.rcode;
+    Q[1] = alignbit(en.rcode, r1, S);
+    Q[2] = xl.prev(kSlotQ1, Q[1]);
+    uint32_t W2[3] = {xl.prev(kSlotCode1, c1), c1, en.code};
+    uint32_t fls[16], rls[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        fls[j] = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
+        rls[j] = win32(Q, 32 + 2 * (15 - j));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t fl = fls[j], rl = rls[j];
+        const uint32_t fh = j >= D ? (S ? fls[j >= D ? j - D : 0] >> S : fls[j >= D ? j - D : 0]) : (win32(W2, 2 + 2 * j) & mask_hi);
+        const uint32_t rh = j + D <= 15 ? (S ? rls[j + D <= 15 ? j + D : 0] >> S : rls[j + D <= 15 ? j + D : 0]) : (win32(Q, 2 * (15 - j)) & mask_hi);
+        bool take_fwd = true;
+        if (CANON) {
+            const uint64_t f = ((uint64_t)fh << 32) | fl, r = ((uint64_t)rh << 32) | rl;
+            take_fwd = TIE_RC ? (f < r) : (f <= r);
+        }
+        mp.emit(sink, j, take_fwd, take_fwd ? fh : rh, take_fwd ? fl : rl);
+    }
+}
+
 }  // namespace ntk

@@ -86,6 +86,46 @@ void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStat
     }
 }
 
+// Scalar-validity ("sv") variant: break flags as lane masks, window validity by mask algebra (ntk_tile.hpp).  On the device
+// the masks come from SDWA compares + SALU ops; here they are assembled from the same per-lane expected/actual bytes.
+struct EmuMP {
+    uint64_t V[16];
+    int lane = 0;
+    template <class S>
+    void emit(S &sink, int j, bool take_fwd, uint32_t hi, uint32_t lo) { sink.emit(j, (V[j] >> lane) & 1, take_fwd, hi, lo); }
+};
+
+template <bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX>
+void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st)
+{
+    const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
+    HostSink<2> sink;
+    sink.st = st; sink.bin_shift = a.bin_shift; sink.values = nullptr; sink.valid16 = nullptr; sink.rc16 = nullptr; sink.n_bytes = n;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        const bool tail = (t + 1) * kTileStride > n;
+        EncSV en[64];
+        uint64_t G[16] = {0};
+        for (int l = 0; l < 64; l++) {
+            const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
+            en[l] = encode16_sv<ACCEPT_U>(load16(buf, n_padded, lane_base));
+            for (int i = 0; i < 16; i++) {
+                bool good = !sv_base_is_break(en[l], i);
+                if (tail && lane_base + i >= (int64_t)n) good = false;
+                if (good) G[i] |= 1ull << l;
+            }
+        }
+        EmuMP mp;
+        window_masks<KFIX>(G, mp.V);
+        EmuXL xl;
+        for (int l = 0; l < 64; l++) {
+            xl.next_lane(l == 0);
+            mp.lane = l;
+            sink.skip = true;
+            lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en[l]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -104,6 +144,11 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     const int kw = k > 16 ? 2 : 1;
     // tiles_per_wave doubles as a switch in this emulation: an odd value selects the k-specialised build when one exists
     const bool fix = (tiles_per_wave & 1) && canon && (k == 21 || k == 31);
+    // bit 1 of tiles_per_wave: the scalar-validity variant (statistics only)
+    const bool sv = fix && (tiles_per_wave & 2) && !values;
+#define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
+    EMU_SV(21, false, false) EMU_SV(21, false, true) EMU_SV(21, true, false) EMU_SV(21, true, true)
+    EMU_SV(31, false, false) EMU_SV(31, false, true) EMU_SV(31, true, false) EMU_SV(31, true, true)
 #define EMU_FIX(KF, T, U) if (fix && k == KF && !!tie_rc == T && !!accept_u == U) { run<2, true, T, U, KF>(buf, n, n_padded, a, st, values, valid16, rc16); } else
     EMU_FIX(21, false, false) EMU_FIX(21, false, true) EMU_FIX(21, true, false) EMU_FIX(21, true, true)
     EMU_FIX(31, false, false) EMU_FIX(31, false, true) EMU_FIX(31, true, false) EMU_FIX(31, true, true)

@@ -76,7 +76,7 @@ def test_emu_vs_oracle_synthetic(emu, k):
     buf = O.synth_reads(0x5EED0002, 0, 40, 150, 8).tobytes()  # ~0.8% N, '\n' separators
     for canon, tie_rc, accept_u in ((1, 1, 1), (1, 0, 0), (0, 0, 0)):
         want = O.reduce_fused(buf, k, bool(canon), bool(tie_rc), bool(accept_u))
-        for tpw in (1, 2, 7):
+        for tpw in (1, 2, 3, 7):  # bit 0: k-specialised build (k = 21, 31), bit 1: scalar-validity variant
             got = emu_scan(emu, buf, k, canon, tie_rc, accept_u, tpw)
             assert_stats_equal(got, want, (k, canon, tie_rc, accept_u, tpw))
 
