@@ -207,7 +207,7 @@ def main():
             "result": {"n_total": res["n_total"], "n_fwd": res["n_fwd"], "sum": hex(res["sum"]), "xor": hex(res["xor"])},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntk::scan_kernel<2,true,true,true,true,21>" if args.k == 21 else "ntk::scan_kernel<KW,true,true,true,true>",
+                "kernel": "ntk::scan_kernel<2,true,true,true,true,21,true>" if args.k == 21 else "ntk::scan_kernel<KW,true,true,true,true,...>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

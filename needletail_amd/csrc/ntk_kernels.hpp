@@ -110,9 +110,15 @@ struct ReduceSinkSV {
     __device__ __forceinline__ void add(uint32_t hi, uint32_t lo)
     {
         const uint64_t v = ((uint64_t)hi << 32) | lo;
+#ifndef NTK_ABL_NODIGEST
         sum += v;
         xr ^= v;
+#endif
+#ifndef NTK_ABL_NOHIST
         atomicAdd(&hist[(uint32_t)(v >> bin_shift)], 1u);
+#else
+        sum += (uint32_t)(v >> bin_shift);
+#endif
     }
 };
 

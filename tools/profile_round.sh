@@ -15,7 +15,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_L
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 if [ -x tools/kb_v2 ]; then
-  ( cd tools; for v in dyn nohist nodigest nohistdig nopos noencpos; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 512 1024 10 $v 16; done ) > $O/ablation.txt 2>&1
+  ( cd tools; for v in dyn nohist nodigest nopos noencpos; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 512 1024 10 $v 16; done ) > $O/ablation.txt 2>&1
   ( cd tools; ./ubench ) > $O/ubench.txt 2>&1
 fi
 ls $O
