@@ -215,6 +215,11 @@ int ntk_minimizers_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_
 int ntk_minimizer(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t m, uint8_t *out);
 /* bitkmer::minimizer (reference src/bitkmer.rs:146-162), element-wise over n packed k-mers (host arrays). */
 int ntk_bit_minimizers(ntk_ctx *ctx, const uint64_t *values, uint64_t n, uint32_t k, uint32_t m, uint64_t *out);
+/* bitkmer::reverse_complement (reference src/bitkmer.rs:112-132) / bitkmer::canonical (:136-143), element-wise over n
+ * packed k-mers (host arrays).  canonical = 0: out = reverse complement, was_rc_out ignored; canonical != 0: out =
+ * canonical k-mer, was_rc_out[i] = 1 when the reverse complement was chosen (ties keep the forward k-mer). */
+int ntk_bit_canonical(ntk_ctx *ctx, const uint64_t *values, uint64_t n, uint32_t k, int canonical, uint64_t *out,
+                      uint8_t *was_rc_out);
 /* QualitySequence::quality_mask (reference src/sequence.rs:285-296): out[i] = qual[i] < score ? 'N' : seq[i]. */
 int ntk_quality_mask(ntk_ctx *ctx, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint8_t score, uint8_t *out);
 

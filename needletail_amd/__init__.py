@@ -8,7 +8,8 @@ from ._lib import (PATH_BITS, PATH_BITS_CANONICAL, PATH_BYTES_CANONICAL, PRE_NON
 from .engine import Batch, Context, default_context
 from .parser import FastxReader, NeedletailError, Record, parse_fastx_file, parse_fastx_string, scan_file
 from .sequence import (bit_kmers, bit_kmers_arrays, canonical_kmers, canonical_kmers_arrays, kmers, normalize,
-                       normalize_opt, normalize_seq, reverse_complement, strip_returns, minimizer, bit_minimizers, quality_mask)
+                       normalize_opt, normalize_seq, reverse_complement, strip_returns, minimizer, bit_minimizers, quality_mask, bit_reverse_complement, bit_canonical,
+                       bitmer_to_bytes, bytes_to_bitmer)
 
 __all__ = [
     "Context", "Batch", "default_context", "NtkError",
@@ -16,6 +17,7 @@ __all__ = [
     "PRE_NONE", "PRE_STRIP_RETURNS", "PRE_NORMALIZE", "PRE_NORMALIZE_IUPAC",
     "parse_fastx_file", "parse_fastx_string", "FastxReader", "Record", "NeedletailError", "scan_file",
     "normalize", "normalize_opt", "normalize_seq", "strip_returns", "reverse_complement",
-    "minimizer", "bit_minimizers", "quality_mask",
+    "minimizer", "bit_minimizers", "quality_mask", "bit_reverse_complement", "bit_canonical", "bitmer_to_bytes",
+    "bytes_to_bitmer",
     "kmers", "canonical_kmers", "canonical_kmers_arrays", "bit_kmers", "bit_kmers_arrays",
 ]

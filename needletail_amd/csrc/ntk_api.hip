@@ -744,6 +744,27 @@ int ntk_bit_minimizers(ntk_ctx *c, const uint64_t *values, uint64_t n, uint32_t 
     return NTK_OK;
 }
 
+int ntk_bit_canonical(ntk_ctx *c, const uint64_t *values, uint64_t n, uint32_t k, int canonical, uint64_t *out, uint8_t *was_rc_out)
+{
+    if (!c || (n && (!values || !out || (canonical && !was_rc_out)))) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 32) return NTK_ERR_BAD_K;
+    if (n == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, n * 8))) return rc;
+    if ((rc = ensure_scratch(c, 1, n * 8))) return rc;
+    if ((rc = ensure_scratch(c, 2, n))) return rc;
+    uint64_t *d_in = (uint64_t *)c->scratch[0].p, *d_out = (uint64_t *)c->scratch[1].p;
+    uint8_t *d_f = (uint8_t *)c->scratch[2].p;
+    HIPCHK(hipMemcpyAsync(d_in, values, n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bit_canonical_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, (const uint64_t *)d_in, n, k, canonical, d_out, d_f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (canonical) HIPCHK(hipMemcpyAsync(was_rc_out, d_f, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
 int ntk_quality_mask(ntk_ctx *c, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint8_t score, uint8_t *out)
 {
     if (!c || (n && (!seq || !qual || !out))) return NTK_ERR_BAD_ARG;

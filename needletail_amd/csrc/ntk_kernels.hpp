@@ -524,6 +524,19 @@ __global__ void bit_minimizer_kernel(const uint64_t *in, uint64_t n, uint32_t k,
     }
 }
 
+// bitkmer::reverse_complement / bitkmer::canonical (reference src/bitkmer.rs:112-143), element-wise.
+// flags may be null (reverse complement only: out = rc); otherwise out = min-by-the-reference's-rule, flags = was_rc.
+__global__ void bit_canonical_kernel(const uint64_t *in, uint64_t n, uint32_t k, int canonical, uint64_t *out, uint8_t *flags)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = in[i], r = bit_revcomp(v, k);
+        if (!canonical) { out[i] = r; continue; }
+        const bool was_rc = v > r;  // ties keep the forward k-mer (reference src/bitkmer.rs:138-142)
+        out[i] = was_rc ? r : v;
+        flags[i] = was_rc ? 1 : 0;
+    }
+}
+
 // sequence::minimizer (reference src/sequence.rs:139-152) for one sequence: the lexicographically smallest length-m
 // byte string among all windows of the sequence and of its reverse complement.  One block; candidates are compared
 // as raw bytes exactly like the reference.  best[0] = candidate index (window start), best[1] = 1 if from the rc.

@@ -134,3 +134,35 @@ def quality_mask(seq: bytes, qual: bytes, score: int, ctx: Context = None) -> by
     out = C.create_string_buffer(max(n, 1))
     L.check(L.lib().ntk_quality_mask(c._h, seq[:n], qual[:n], n, score, out), "ntk_quality_mask")
     return out.raw[:n]
+
+
+def bit_reverse_complement(values, k: int, ctx: Context = None) -> np.ndarray:
+    """bitkmer::reverse_complement (reference src/bitkmer.rs:112-132) over an array of packed k-mers."""
+    c = _ctx(ctx)
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    out = np.empty_like(v)
+    L.check(L.lib().ntk_bit_canonical(c._h, v.ctypes.data, v.size, k, 0, out.ctypes.data, None), "ntk_bit_canonical")
+    return out
+
+
+def bit_canonical(values, k: int, ctx: Context = None):
+    """bitkmer::canonical (reference src/bitkmer.rs:136-143): (canonical values, was_rc flags)."""
+    c = _ctx(ctx)
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    out = np.empty_like(v)
+    flg = np.empty(v.size, dtype=np.uint8)
+    L.check(L.lib().ntk_bit_canonical(c._h, v.ctypes.data, v.size, k, 1, out.ctypes.data, flg.ctypes.data), "ntk_bit_canonical")
+    return out, flg.astype(bool)
+
+
+def bitmer_to_bytes(value: int, k: int) -> bytes:
+    """bitkmer::bitmer_to_bytes (reference src/bitkmer.rs:164-186): pure formatting of one packed k-mer (host side)."""
+    return bytes(b"ACGT"[(value >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def bytes_to_bitmer(kmer: bytes):
+    """Inverse of bitmer_to_bytes, the reference's test helper (src/bitkmer.rs:288-296): (value, k)."""
+    v = 0
+    for ch in kmer:
+        v = (v << 2) | {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}[ch]
+    return v & ((1 << (2 * len(kmer))) - 1), len(kmer)

@@ -294,6 +294,22 @@ def test_minimizer_and_quality_mask_kats(ctx):
         assert np.array_equal(nt.bit_minimizers(v, k, m, ctx)[:300], want), (k, m)
 
 
+def test_bit_reverse_complement_and_canonical_kats(ctx):
+    # reference src/bitkmer.rs:253-259, 270-286
+    assert list(nt.bit_reverse_complement([0b000000, 0b111111], 3, ctx)) == [0b111111, 0]
+    assert list(nt.bit_reverse_complement([0, 0b00011011], 4, ctx)) == [0b11111111, 0b00011011]
+    assert nt.bytes_to_bitmer(b"C") == (1, 1) and nt.bytes_to_bitmer(b"TTA") == (60, 3) and nt.bytes_to_bitmer(b"AAA") == (0, 3)
+    assert nt.bitmer_to_bytes(1, 1) == b"C" and nt.bitmer_to_bytes(60, 3) == b"TTA" and nt.bitmer_to_bytes(0, 3) == b"AAA"
+    rng = np.random.default_rng(8)
+    for k in (1, 4, 21, 31, 32):
+        v = rng.integers(0, 1 << 63, 2000, dtype=np.uint64) & np.uint64((1 << (2 * k)) - 1 if k < 32 else 0xFFFFFFFFFFFFFFFF)
+        rc = nt.bit_reverse_complement(v, k, ctx)
+        can, flg = nt.bit_canonical(v, k, ctx)
+        for i in range(200):
+            assert int(rc[i]) == O.bit_reverse_complement(int(v[i]), k)
+            assert (int(can[i]), bool(flg[i])) == O.bit_canonical(int(v[i]), k)
+
+
 @pytest.mark.parametrize("k,w", [(21, 11), (5, 3), (31, 1), (16, 20)])
 def test_windowed_minimizers_reduce(ctx, k, w):
     buf = O.synth_reads(0x5EED0005, 3, 300, 150, 6).tobytes()
@@ -406,3 +422,20 @@ def test_full_size_properties_config2(ctx):
     ctx.accum_reset(); ctx.reduce_device(t2, nbytes, k, path, pre); rcst = ctx.accum_read()
     assert rcst["n_total"] == whole["n_total"] and rcst["n_fwd"] == whole["n_rc"] and rcst["n_rc"] == whole["n_fwd"]
     assert rcst["sum"] == whole["sum"] and rcst["xor"] == whole["xor"] and np.array_equal(rcst["hist"], whole["hist"])
+
+
+# ---- property-based differential test on the GPU (hypothesis) ---------------------------------------------------------
+from hypothesis import given, settings, strategies as st_  # noqa: E402
+
+_ALPHABET = b"ACGT" * 6 + b"acgt" + b"NnUuRYKM-.* \t\r\n\x00\x7f\x80\xff0@>"
+_HCTX = []
+
+
+@settings(max_examples=60, deadline=None)
+@given(data=st_.lists(st_.sampled_from(list(_ALPHABET)), min_size=0, max_size=5000).map(bytes), k=st_.integers(1, 32),
+       mode=st_.sampled_from(MODES))
+def test_reduce_matches_oracle_property(data, k, mode):
+    if not _HCTX:
+        _HCTX.append(nt.Context(0, stream=torch.cuda.current_stream().cuda_stream))
+    path, pre, canon, tie, u = mode
+    assert_stats_equal(gpu_reduce(_HCTX[0], data, k, path, pre), O.reduce_fused(data, k, canon, tie, u), (k, path, pre, len(data)))

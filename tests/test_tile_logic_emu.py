@@ -14,8 +14,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, "emu")
 
 
+_EMU = None
+
+
+def _emu_lib():
+    global _EMU
+    if _EMU is None:
+        _EMU = _load_emu()
+    return _EMU
+
+
 @pytest.fixture(scope="module")
 def emu():
+    return _emu_lib()
+
+
+def _load_emu():
     so = os.path.join(EMU_DIR, "libntk_emu.so")
     src = os.path.join(EMU_DIR, "emu_scan.cpp")
     hdr = os.path.join(HERE, "..", "needletail_amd", "csrc", "ntk_tile.hpp")
@@ -119,3 +133,21 @@ def test_emu_materialize_matches_bit_kmers(emu):
         assert np.array_equal(ends - (k - 1), pos.astype(np.int64))
         assert np.array_equal(vals[ends], val)
         assert np.array_equal(rcb[ends].astype(np.uint8), flg)
+
+
+# ---- property-based differential test (the reference has no randomised k-mer tests) -------------------
+from hypothesis import given, settings, strategies as st_  # noqa: E402
+
+_ALPHABET = b"ACGT" * 6 + b"acgt" + b"NnUuRYKM-.* \t\r\n\x00\x7f\x80\xff0@>"
+
+
+@settings(max_examples=150, deadline=None)
+@given(data=st_.lists(st_.sampled_from(list(_ALPHABET)), min_size=0, max_size=1400).map(bytes),
+       k=st_.integers(1, 32), mode=st_.sampled_from([(1, 1, 1), (1, 0, 0), (0, 0, 0), (1, 0, 1), (1, 1, 0)]),
+       variant=st_.integers(0, 3))
+def test_emu_matches_oracle_property(data, k, mode, variant):
+    L = _emu_lib()
+    canon, tie_rc, accept_u = mode
+    want = O.reduce_fused(data, k, bool(canon), bool(tie_rc), bool(accept_u))
+    got = emu_scan(L, data, k, canon, tie_rc, accept_u, variant)
+    assert_stats_equal(got, want, (k, mode, variant, len(data)))
