@@ -160,12 +160,13 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 template <bool REDUCE>
 hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, hipStream_t st)
 {
+    const size_t lds = REDUCE ? 0 : (size_t)(block.x / 64) * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
     // k-specialised builds for the two k of the reference's own workloads (21: headline; 31: benches/benchmark.rs:15).
     // Reduce mode runs the scalar-validity variant (-10 %); materialise mode the k = 21 per-lane variant (-5 %; at k = 31
     // the generic build is faster there: only one of the 16 hi words can be derived from a lo word of the same lane).
 #define NTK_LAUNCH_FIX(KF, T, U)                                                                \
     if (m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {                \
-        hipLaunchKernelGGL((scan_kernel<2, true, T, U, REDUCE, KF, REDUCE>), grid, block, 0, st, a);  /* reduce: scalar validity */ \
+        hipLaunchKernelGGL((scan_kernel<2, true, T, U, REDUCE, KF, REDUCE>), grid, block, lds, st, a);  /* reduce: scalar validity */ \
         return hipGetLastError();                                                               \
     }
     NTK_LAUNCH_FIX(21, false, false) NTK_LAUNCH_FIX(21, false, true) NTK_LAUNCH_FIX(21, true, false) NTK_LAUNCH_FIX(21, true, true)
@@ -173,7 +174,7 @@ hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, 
 #undef NTK_LAUNCH_FIX
 #define NTK_LAUNCH(KW, C, T, U)                                                                 \
     if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U) {                       \
-        hipLaunchKernelGGL((scan_kernel<KW, C, T, U, REDUCE>), grid, block, 0, st, a);          \
+        hipLaunchKernelGGL((scan_kernel<KW, C, T, U, REDUCE>), grid, block, lds, st, a);          \
         return hipGetLastError();                                                               \
     }
     NTK_LAUNCH(1, false, false, false) NTK_LAUNCH(1, false, false, true)
@@ -200,10 +201,11 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
 {
     if (n == 0) return NTK_OK;
     if (!d_seq || ((uintptr_t)d_seq & 15)) return NTK_ERR_BAD_ARG;
-    const int threads = c->launch_threads;
+    // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
+    const int threads = reduce ? c->launch_threads : 256;
     const int waves_per_block = threads / 64;
     // auto: 32 waves per CU (the kernel needs <= 64 VGPRs), e.g. 2 x 1024-thread blocks - measured best (profiles/r01_launch_sweep_first.jsonl)
-    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : c->n_cu * 2 * (1024 / threads);
+    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : (reduce ? c->n_cu * 2 * (1024 / threads) : c->n_cu * 4);
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     scan_args_set_k(a, p->k);

@@ -76,27 +76,51 @@ struct ReduceSink {
     __device__ __forceinline__ void end_tile() {}
 };
 
+// Values are staged through LDS so that the global stores are whole contiguous 1-KiB pieces (a lane owns 16
+// CONSECUTIVE positions, so direct stores would be 64 scattered 8-byte pieces per instruction: measured 1.7x slower).
+// Stage layout: row = emitting lane (0..61), 18 u64 per row (16 values + 2 pad: rows stay 16-byte aligned and the
+// 16 lanes of a ds_write_b64 group spread over the banks).
+constexpr int kStageRow = 18;
+constexpr int kStageWaveU64 = kTileSlots * kStageRow;  // 1116 u64 = 8928 B per wave
+
 template <int KW>
 struct MaterializeSink {
     uint64_t *values;
     uint16_t *valid16, *rc16;
+    uint64_t *stage;      // this wave's LDS staging area
+    uint32_t lane = 0;
     int64_t base = 0;     // global byte index of this lane's first base in the current tile
     uint64_t n_bytes = 0;
     uint32_t inval = 0, rcbits = 0;
-    bool skip = true;     // halo lanes and slots past the end of the input own no output
+    bool halo = true;     // halo lanes own no output slot
 
-    __device__ __forceinline__ void begin_tile(int64_t lane_base, uint32_t inval16, bool halo) { base = lane_base; inval = inval16; rcbits = 0; skip = halo || lane_base >= (int64_t)n_bytes; }
+    __device__ __forceinline__ void begin_tile(int64_t lane_base, uint32_t inval16, bool halo_lane) { base = lane_base; inval = inval16; rcbits = 0; halo = halo_lane; }
     __device__ __forceinline__ void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
     {
-        if (values && !skip) values[base + j] = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+        if (values && !halo) stage[(lane - kHaloLanes) * kStageRow + j] = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
         rcbits |= (take_fwd ? 0u : 1u) << (15 - j);
     }
     __device__ __forceinline__ void end_tile()
     {
-        if (skip) return;
-        const uint32_t v = ~inval & 0xFFFFu;
-        valid16[base >> 4] = (uint16_t)v;
-        rc16[base >> 4] = (uint16_t)(rcbits & v);
+        if (!halo && base < (int64_t)n_bytes) {
+            const uint32_t v = ~inval & 0xFFFFu;
+            valid16[base >> 4] = (uint16_t)v;
+            rc16[base >> 4] = (uint16_t)(rcbits & v);
+        }
+        if (!values) return;
+        // copy the tile's 992 values out: instruction s moves positions [128 s, 128 s + 128), 16 bytes per lane
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes above are complete and ordered
+        const int64_t tile_pos0 = base - (int64_t)lane * 16 + kHaloLanes * 16;  // position of emitting lane 0, slot 0
+        const int64_t limit = (int64_t)((n_bytes + 15) & ~(uint64_t)15);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int q = 128 * s + 2 * (int)lane;
+            if (q < kTileSlots * 16 && tile_pos0 + q < limit) {
+                const ulonglong2 two = *reinterpret_cast<const ulonglong2 *>(&stage[(q >> 4) * kStageRow + (q & 15)]);
+                *reinterpret_cast<ulonglong2 *>(&values[tile_pos0 + q]) = two;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile overwrites the stage
     }
 };
 
@@ -171,6 +195,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     using Sink = typename std::conditional<SV, ReduceSinkSV, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
     __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
     __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_stage[];  // materialise mode: kStageWaveU64 u64 per wave (dynamic)
 
 #ifdef NTK_V_CLOCKS
     const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         sink.bin_shift = a.bin_shift;
     } else {
         sink.values = a.values; sink.valid16 = a.valid16; sink.rc16 = a.rc16; sink.n_bytes = a.n_bytes;
+        sink.stage = s_stage + (threadIdx.x >> 6) * kStageWaveU64; sink.lane = threadIdx.x & 63u;
     }
 
     const uint32_t lane = threadIdx.x & 63u;
