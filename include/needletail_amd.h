@@ -186,6 +186,17 @@ void ntk_reader_close(ntk_reader *r);
 int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t batch_bytes, uint32_t n_batches,
                     uint64_t *n_records, uint64_t *n_bases);
 
+/* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into n_threads pieces,
+ * each parsed by its own thread into its own pinned batches (record order across pieces is not preserved; the reduced
+ * result does not depend on it).  gzip input is NTK_ERR_UNSUPPORTED here - a gzip stream is sequential, use
+ * ntk_scan_reader.  Parse errors return NTK_ERR_PARSE without position detail. */
+/* The cut points the parallel producer uses: cuts[0] = 0 <= cuts[1] <= ... <= cuts[n_pieces] = n, every cut a record start. */
+int ntk_fastx_split_points(const uint8_t *data, uint64_t n, uint32_t n_pieces, uint64_t *cuts);
+int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, const ntk_params *p, uint64_t batch_bytes,
+                             uint32_t n_threads, uint64_t *n_records, uint64_t *n_bases);
+int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads,
+                           uint64_t *n_records, uint64_t *n_bases);
+
 /* ---- compat face: the reference's per-sequence functions, eager ---------------------------------
  * Caller-allocated outputs; *_len out-params; outputs need capacity n unless stated. */
 /* sequence::normalize (src/sequence.rs:19-62): *changed == 0 <=> the reference returns None. */

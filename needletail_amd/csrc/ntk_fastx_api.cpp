@@ -2,7 +2,15 @@
 // batch face only (include/needletail_amd.h).
 #include "../../include/needletail_amd.h"
 
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 #include <new>
 #include <string>
@@ -104,6 +112,141 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *h, const ntk_params *p, uint64_t b
     }
     if (n_records) *n_records = nrec;
     if (n_bases) *n_bases = nbases;
+    return rc;
+}
+
+
+/* ---- parallel producer: one parser thread per file range ------------------------------------------------ */
+namespace {
+
+// First record start at or after `from` in a plain FASTA/FASTQ byte range (chunked parsing).
+// FASTA: the byte after "\n" that is '>'.  FASTQ: a line starting with '@' whose line+2 starts with '+' (a quality line
+// may start with '@', but then its line+2 is a sequence line, which cannot start with '+').
+uint64_t next_record_start(const uint8_t *d, uint64_t n, uint64_t from, int format)
+{
+    if (from == 0) return 0;
+    uint64_t p = from;
+    while (p < n) {
+        const uint8_t *nl = (const uint8_t *)memchr(d + p, '\n', n - p);
+        if (!nl) return n;
+        p = (uint64_t)(nl - d) + 1;
+        if (p >= n) return n;
+        if (format == ntk::kFasta) { if (d[p] == '>') return p; continue; }
+        if (d[p] != '@') continue;
+        const uint8_t *l1 = (const uint8_t *)memchr(d + p, '\n', n - p);
+        if (!l1) return n;
+        const uint8_t *l2 = (const uint8_t *)memchr(l1 + 1, '\n', n - (uint64_t)(l1 + 1 - d));
+        if (!l2 || (uint64_t)(l2 + 1 - d) >= n) return n;
+        if (l2[1] == '+') return p;
+    }
+    return n;
+}
+
+struct Shared {
+    ntk_ctx *ctx; const ntk_params *p; uint64_t batch_bytes;
+    std::mutex mu;                       // the ctx is not thread-safe: submit / wait / acquire are serialised
+    std::atomic<int> rc{NTK_OK};
+    std::atomic<uint64_t> nrec{0}, nbases{0};
+};
+
+void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
+{
+    if (n == 0) return;
+    ntk_reader *rd = nullptr;
+    int rc = ntk_reader_open_memory(d, n, &rd);
+    ntk_batch *b[2] = {nullptr, nullptr};
+    const uint64_t max_records = sh->batch_bytes / 32 + 16;
+    // acquire / release touch no ctx state (pinned + device allocations only): not serialised
+    for (int i = 0; i < 2 && rc == NTK_OK; i++) rc = ntk_batch_acquire(sh->ctx, sh->batch_bytes, max_records, &b[i]);
+    uint64_t nrec = 0, nbases = 0;
+    int cur = 0;
+    ntk_record rec;
+    while (rc == NTK_OK && sh->rc.load() == NTK_OK) {
+        const int s = ntk_reader_next(rd, &rec);
+        if (s == NTK_EOF) break;
+        if (s != NTK_OK) { rc = s; break; }
+        int a = ntk_batch_append(b[cur], rec.seq, rec.seq_len, sh->p->pre);
+        if (a == NTK_ERR_CAPACITY) {
+            {
+                std::lock_guard<std::mutex> g(sh->mu);
+                rc = ntk_batch_submit(sh->ctx, b[cur], sh->p);
+            }
+            if (rc != NTK_OK) break;
+            cur ^= 1;
+            if ((rc = ntk_batch_wait(sh->ctx, b[cur])) != NTK_OK) break;  // event wait only: no ctx state touched
+            a = ntk_batch_append(b[cur], rec.seq, rec.seq_len, sh->p->pre);
+        }
+        if (a != NTK_OK) { rc = a; break; }
+        nrec++; nbases += rec.num_bases;
+    }
+    {
+        std::lock_guard<std::mutex> g(sh->mu);
+        if (rc == NTK_OK && b[cur]) rc = ntk_batch_submit(sh->ctx, b[cur], sh->p);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (!b[i]) continue;
+        const int w = ntk_batch_wait(sh->ctx, b[i]);
+        if (rc == NTK_OK && w != NTK_OK) rc = w;
+        ntk_batch_release(sh->ctx, b[i]);
+    }
+    if (rd) ntk_reader_close(rd);
+    if (rc != NTK_OK) { int ok = NTK_OK; sh->rc.compare_exchange_strong(ok, rc); }
+    sh->nrec += nrec; sh->nbases += nbases;
+}
+
+}  // namespace
+
+int ntk_fastx_split_points(const uint8_t *data, uint64_t n, uint32_t n_pieces, uint64_t *cuts)
+{
+    if ((!data && n) || !cuts || n_pieces < 1) return NTK_ERR_BAD_ARG;
+    if (n < 2) return NTK_ERR_PARSE;
+    const int format = data[0] == '>' ? ntk::kFasta : (data[0] == '@' ? ntk::kFastq : -1);
+    if (format < 0) return NTK_ERR_PARSE;
+    cuts[0] = 0; cuts[n_pieces] = n;
+    for (uint32_t i = 1; i < n_pieces; i++) {
+        const uint64_t c = next_record_start(data, n, n / n_pieces * i, format);
+        cuts[i] = c < cuts[i - 1] ? cuts[i - 1] : c;
+    }
+    return NTK_OK;
+}
+
+int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, const ntk_params *p, uint64_t batch_bytes,
+                             uint32_t n_threads, uint64_t *n_records, uint64_t *n_bases)
+{
+    if (!ctx || (!data && n) || !p || batch_bytes < 1024 || n_threads < 1 || n_threads > 1024) return NTK_ERR_BAD_ARG;
+    if (n_records) *n_records = 0;
+    if (n_bases) *n_bases = 0;
+    if (n < 2) return NTK_ERR_PARSE;                       // EmptyFile (reference src/parser/mod.rs:88-91)
+    if (data[0] == 0x1F && data[1] == 0x8B) return NTK_ERR_UNSUPPORTED;  // gzip is a sequential stream: use ntk_scan_reader
+    // a thread is only worth its two pinned batches if it has several batches of input to parse
+    const uint64_t worth = n / (4 * batch_bytes) + 1;
+    if (n_threads > worth) n_threads = (uint32_t)worth;
+    std::vector<uint64_t> cut(n_threads + 1, n);
+    if (ntk_fastx_split_points(data, n, n_threads, cut.data()) != NTK_OK) return NTK_ERR_PARSE;
+    Shared sh;
+    sh.ctx = ctx; sh.p = p; sh.batch_bytes = batch_bytes;
+    std::vector<std::thread> th;
+    for (uint32_t i = 0; i < n_threads; i++)
+        if (cut[i + 1] > cut[i]) th.emplace_back(range_worker, &sh, data + cut[i], cut[i + 1] - cut[i]);
+    for (auto &t : th) t.join();
+    if (n_records) *n_records = sh.nrec.load();
+    if (n_bases) *n_bases = sh.nbases.load();
+    return sh.rc.load();
+}
+
+int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads,
+                           uint64_t *n_records, uint64_t *n_bases)
+{
+    if (!ctx || !path || !p) return NTK_ERR_BAD_ARG;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return NTK_ERR_PARSE;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 2) { close(fd); return NTK_ERR_PARSE; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return NTK_ERR_NOMEM;
+    const int rc = ntk_scan_buffer_parallel(ctx, (const uint8_t *)m, (uint64_t)st.st_size, p, batch_bytes, n_threads, n_records, n_bases);
+    munmap(m, (size_t)st.st_size);
     return rc;
 }
 

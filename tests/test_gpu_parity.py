@@ -265,6 +265,16 @@ def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
     recs_fq = fastq_raw_seqs(open(fq, "rb").read())
     st = nt.scan_file(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 16, w=11)
     assert_stats_equal(st, O.minimizers_reduce(b"".join(r + b"\n" for r in recs_fq), 21, 11, True, True), "gz minimizers")
+    # parallel producer (one parser thread per file range) gives the same reduced result
+    for threads in (1, 3, 16):
+        stp = nt.scan_file_parallel(ctx, fq, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=threads, batch_bytes=1 << 16)
+        assert stp["n_records"] == 2000 and stp["n_bases"] == 250_000
+        assert_stats_equal(stp, O.reduce_records(recs_fq, 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), ("parallel", threads))
+    stp = nt.scan_file_parallel(ctx, fa, 31, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS, threads=8, batch_bytes=1 << 18)
+    assert (stp["n_records"], stp["n_total"], stp["n_fwd"]) == (570, 718_007, 350_983)
+    with pytest.raises(nt.NtkError) as e:   # gzip streams are sequential: the parallel entry point refuses them
+        nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    assert e.value.status == 6
     with pytest.raises(nt.NtkError) as e:   # a record longer than a batch is an error, not a silent truncation
         nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1024)
     assert e.value.status == 5

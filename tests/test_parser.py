@@ -167,3 +167,29 @@ def test_records_across_buffer_boundaries():
         want.append(seq)
     got = recs(b"".join(parts))
     assert [x[1] for x in got] == want and [x[3] for x in got] == [1 + 4 * i for i in range(20_000)]
+
+
+def test_parallel_split_points_are_record_starts():
+    """The parallel producer cuts a plain file at record starts; FASTQ quality lines that start with '@' must not fool it."""
+    import ctypes as C
+    from needletail_amd import _lib as L
+    rng = np.random.default_rng(4)
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    parts, starts, off = [], set(), 0
+    for i in range(3000):
+        n = int(rng.integers(1, 120))
+        seq = bytes(letters[rng.integers(0, 5, n)])
+        qual = bytes(rng.choice(np.frombuffer(b"@+I#5@@", dtype=np.uint8), n))  # many '@' and '+' at line starts
+        rec = b"@r%d some text\n" % i + seq + b"\n+\n" + qual + b"\n"
+        starts.add(off); off += len(rec); parts.append(rec)
+    data = b"".join(parts)
+    for pieces in (2, 7, 64, 500):
+        cuts = (C.c_uint64 * (pieces + 1))()
+        assert L.lib().ntk_fastx_split_points(data, len(data), pieces, cuts) == 0
+        cl = list(cuts)
+        assert cl[0] == 0 and cl[-1] == len(data) and cl == sorted(cl)
+        assert all(c in starts or c == len(data) for c in cl)
+    fa = b"".join(b">c%d\n" % i + b"ACGT>ACGT\nAC\n" for i in range(500))   # '>' inside sequence lines is not a start
+    cuts = (C.c_uint64 * 9)()
+    assert L.lib().ntk_fastx_split_points(fa, len(fa), 8, cuts) == 0
+    assert all(fa[c:c + 2] == b">c" or c == len(fa) for c in cuts)

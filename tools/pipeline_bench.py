@@ -60,6 +60,16 @@ for bb, nbat in ((8 << 20, 3), (64 << 20, 3)):
         best = dt if best is None else min(best, dt)
     out[f"pipeline_batch{bb >> 20}MiB"] = {"seconds": round(best, 4), "Gbases_s": round(reads * RL / best / 1e9, 3),
                                            "fastq_GB_s": round(len(text) / best / 1e9, 3)}
+for th in (8, 32, 128):
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        st = nt.scan_file_parallel(ctx, None, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=th, batch_bytes=8 << 20, data=text)
+        dt = time.perf_counter() - t0
+        assert st["n_total"] == want["n_total"] and st["sum"] == want["sum"] and st["xor"] == want["xor"] and st["n_records"] == reads
+        best = dt if best is None else min(best, dt)
+    out[f"pipeline_parallel_{th}threads"] = {"seconds": round(best, 4), "Gbases_s": round(reads * RL / best / 1e9, 3),
+                                            "fastq_GB_s": round(len(text) / best / 1e9, 3)}
 # parser alone (no GPU work): upper bound of the single-threaded producer
 t0 = time.perf_counter(); rd = nt.FastxReader(data=text); n = 0
 rec_ = L.Record()
