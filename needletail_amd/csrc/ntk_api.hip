@@ -224,6 +224,10 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         const uint64_t want_blocks = (tiles + chunk * waves_per_block - 1) / (chunk * waves_per_block);
         const int blocks = (int)(want_blocks < (uint64_t)blocks_max ? want_blocks : (uint64_t)blocks_max);
         a.tile_begin = tb; a.tile_end = te;
+        {   // tiles t with (t + 1) * 992 > n_bytes touch the end of the input: t >= n_bytes / 992
+            const uint64_t first_tail = n / kTileStride;
+            a.tail_tile_rel = first_tail < tb ? 0u : (first_tail - tb > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)(first_tail - tb));
+        }
         a.n_shards = blocks < 8 ? (uint32_t)blocks : 8u;
         a.tiles_per_shard = (uint32_t)((tiles + a.n_shards - 1) / a.n_shards);
         a.chunk_tiles = (uint32_t)chunk;

@@ -219,12 +219,15 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     // times spread over 0.25..0.92 ms of a 0.92 ms kernel).  Instead every wave pulls chunks of tiles from a
     // per-shard counter (8 shards ~ one per XCD, <= ~20 pulls/us each) until the shard is empty; tiles carry no
     // state from their predecessor (halo lanes), so any wave can take any chunk.
+    // All tile indices inside the loop are 32-bit and relative to the launch (a launch covers <= 2^25 tiles) so that the
+    // loop control stays on the scalar unit (there are no 64-bit ordered scalar compares).
     const uint32_t shard = blockIdx.x % a.n_shards;
-    const uint64_t shard_begin = a.tile_begin + (uint64_t)shard * a.tiles_per_shard;
-    uint64_t shard_end = shard_begin + a.tiles_per_shard;
-    if (shard_end > a.tile_end) shard_end = a.tile_end;
+    const uint32_t launch_tiles = (uint32_t)(a.tile_end - a.tile_begin);
+    const uint32_t shard_begin = shard * a.tiles_per_shard;
+    uint32_t shard_end = shard_begin + a.tiles_per_shard;
+    if (shard_end > launch_tiles) shard_end = launch_tiles;
     uint32_t *ctr = a.work_counters + shard * 16;
-    const uint32_t shard_tiles = shard_begin < shard_end ? (uint32_t)(shard_end - shard_begin) : 0u;
+    const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
     DevXL xl;
     DevMasks mp;
     const bool halo_lane = lane < (uint32_t)kHaloLanes;
@@ -233,12 +236,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
     next = __builtin_amdgcn_readfirstlane(next);
     while (next < shard_tiles) {
-        const uint64_t t0 = shard_begin + next;
-        uint64_t t1 = t0 + a.chunk_tiles;
-        if (t1 > shard_end) t1 = shard_end;
+        const uint32_t r0 = shard_begin + next;                 // first tile of the chunk, launch-relative
+        uint32_t r1 = r0 + a.chunk_tiles;
+        if (r1 > shard_end) r1 = shard_end;
         if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);  // in flight while this chunk is processed
         // wave-uniform buffer descriptor starting 32 bytes (the halo) before the chunk; hardware bounds checking
         // returns 0 (a break byte) past the padded end, and for the "negative" halo offsets of tile 0.
+        const uint64_t t0 = a.tile_begin + r0;
         const uint64_t run_byte = t0 * kTileStride;
         const uint32_t halo = t0 ? 32u : 0u;
         const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
@@ -251,20 +255,21 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
             (void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
 
         uint32_t voff = lane * 16u - (32u - halo);  // wraps (out of range -> 0) for the halo lanes of tile 0
-        int64_t lane_base = (int64_t)run_byte - 32 + lane * 16;
+        uint64_t tile_byte = run_byte;              // wave-uniform: first emitting byte of the current tile
         u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-        for (uint64_t t = t0; t < t1; t++) {
+        for (uint32_t r = r0; r < r1; r++) {
             u32x4 nxt = cur;
-            if (t + 1 < t1) nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);  // wave-uniform
-            const bool tail = (t + 1) * kTileStride > a.n_bytes;
+            if (r + 1 < r1) nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);  // wave-uniform
+            const bool tail = r >= a.tail_tile_rel;  // this tile reaches the end of the input
             if constexpr (SV) {
                 const EncSV en = encode16_sv<ACCEPT_U>(Raw16{cur.x, cur.y, cur.z, cur.w});
-                mp.template compute<KFIX>(en, tail, lane_base, a.n_bytes);
+                mp.template compute<KFIX>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
                 lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
             } else {
-                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w}, lane_base, halo_lane, tail);
+                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w},
+                                                             (int64_t)tile_byte - 32 + lane * 16, halo_lane, tail);
             }
-            cur = nxt; voff += kTileStride; lane_base += kTileStride;
+            cur = nxt; voff += kTileStride; tile_byte += kTileStride;
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }

@@ -25,6 +25,7 @@ struct ScanArgs {
     uint32_t n_shards;        // min(8, grid): block b pulls tile chunks from shard b % n_shards
     uint32_t tiles_per_shard; // shard s owns tiles [tile_begin + s*tiles_per_shard, +tiles_per_shard) clipped to tile_end
     uint32_t chunk_tiles;     // tiles handed out per pull
+    uint32_t tail_tile_rel;   // first tile (relative to tile_begin) that reaches n_bytes; 0xFFFFFFFF if beyond this launch
     uint32_t k;
     uint32_t sh_r;        // right shift of the reverse-complement stream: 64-2k (KW=2) / 32-2k (KW=1)
     uint32_t mask_hi;     // KW=2: (1 << (2k-32)) - 1

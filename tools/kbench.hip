@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     const uint32_t chunk = argc > 7 ? atoi(argv[7]) : 16;
     uint32_t *d_work; CHK(hipMalloc(&d_work, 512));
     a.n_shards = blocks < 8 ? blocks : 8; a.tiles_per_shard = (uint32_t)((a.n_tiles + a.n_shards - 1) / a.n_shards);
-    a.chunk_tiles = chunk; a.work_counters = d_work;
+    a.chunk_tiles = chunk; a.work_counters = d_work; a.tail_tile_rel = (uint32_t)(n / kTileStride);
     CHK(hipMalloc(&d_ph, (size_t)blocks * kHistBins * 4)); CHK(hipMalloc(&d_ps, (size_t)blocks * 32)); CHK(hipMalloc(&d_acc, (8 + kHistBins + 64) * 8));
     a.part_hist = d_ph; a.part_scalars = d_ps;
 #ifdef NTK_V_CLOCKS
