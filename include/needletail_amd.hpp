@@ -1,0 +1,149 @@
+// needletail_amd.hpp — header-only C++ mirror of needletail's public surface for the accelerated path, on top of the
+// C ABI (needletail_amd.h).  Names, argument meaning and results follow the reference so that code written against
+//   needletail::{parse_fastx_file, FastxReader::next, SequenceRecord, Sequence::{normalize, strip_returns,
+//   reverse_complement, canonical_kmers, kmers, bit_kmers}}           (reference src/lib.rs:56-57, src/sequence.rs:156-253)
+// ports line by line (see examples/stdin_pipe.cpp, the reference's examples/stdin_pipe.rs).  Where the reference
+// panics (k = 0 ...) or returns Err(ParseError), this throws needletail::Error.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <tuple>
+#include <vector>
+
+#include "needletail_amd.h"
+
+namespace needletail {
+
+using Bytes = std::basic_string<uint8_t>;
+using Slice = std::basic_string_view<uint8_t>;
+
+struct Error : std::runtime_error {
+    int status, kind; uint64_t line; std::string record_id;
+    Error(int st, const std::string &what, int k = 0, uint64_t ln = 0, std::string id = {})
+        : std::runtime_error(what), status(st), kind(k), line(ln), record_id(std::move(id)) {}
+};
+inline void check(int st, const char *what) { if (st != NTK_OK) throw Error(st, std::string(what) + ": " + ntk_strerror(st)); }
+
+// One (thread, device) engine handle; the default one is created on first use (device 0).
+class Context {
+public:
+    explicit Context(int device = 0) { check(ntk_ctx_create(device, &h_), "ntk_ctx_create"); }
+    ~Context() { ntk_ctx_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ntk_ctx *get() const { return h_; }
+    static Context &global() { static Context c(0); return c; }
+private:
+    ntk_ctx *h_ = nullptr;
+};
+
+using BitKmer = std::pair<uint64_t, uint8_t>;  // reference src/bitkmer.rs:2-3
+
+// Sequence trait (reference src/sequence.rs:156-253) over a borrowed byte slice.
+class Sequence {
+public:
+    Sequence(Slice s, Context &c = Context::global()) : s_(s), c_(&c) {}
+    Sequence(const Bytes &b, Context &c = Context::global()) : s_(b), c_(&c) {}
+    Slice sequence() const { return s_; }
+
+    Bytes strip_returns() const {  // src/sequence.rs:165-191
+        Bytes out(s_.size(), 0); uint64_t n = 0; int borrowed = 0;
+        check(ntk_strip_returns(c_->get(), s_.data(), s_.size(), out.data(), &n, &borrowed), "ntk_strip_returns");
+        out.resize(n); return out;
+    }
+    Bytes reverse_complement() const {  // src/sequence.rs:202-208
+        Bytes out(s_.size(), 0);
+        check(ntk_reverse_complement(c_->get(), s_.data(), s_.size(), out.data()), "ntk_reverse_complement");
+        return out;
+    }
+    Bytes normalize(bool iupac) const {  // src/sequence.rs:226-232
+        Bytes out(s_.size(), 0); uint64_t n = 0; int changed = 0;
+        check(ntk_normalize(c_->get(), s_.data(), s_.size(), iupac, out.data(), &n, &changed), "ntk_normalize");
+        out.resize(n); return out;
+    }
+    // (position, canonical k-mer slice, is_rc): slices borrow `*this` or `reverse_complement` exactly like src/kmer.rs:121-128
+    std::vector<std::tuple<size_t, Slice, bool>> canonical_kmers(uint8_t k, Slice reverse_complement) const {
+        std::vector<uint64_t> pos(s_.size() ? s_.size() : 1); std::vector<uint8_t> rc(pos.size()); uint64_t n = 0;
+        check(ntk_canonical_kmers(c_->get(), s_.data(), s_.size(), k, pos.data(), rc.data(), pos.size(), &n), "ntk_canonical_kmers");
+        std::vector<std::tuple<size_t, Slice, bool>> out; out.reserve(n);
+        const Slice r = reverse_complement;
+        for (uint64_t i = 0; i < n; i++)
+            out.emplace_back(pos[i], rc[i] ? r.substr(r.size() - pos[i] - k, k) : s_.substr(pos[i], k), rc[i] != 0);
+        return out;
+    }
+    std::vector<Slice> kmers(uint8_t k) const {  // src/kmer.rs:13-41
+        std::vector<Slice> out;
+        for (size_t i = 0; i + k <= s_.size(); i++) out.push_back(s_.substr(i, k));
+        return out;
+    }
+    std::vector<std::tuple<size_t, BitKmer, bool>> bit_kmers(uint8_t k, bool canonical) const {  // src/bitkmer.rs:72-109
+        std::vector<uint64_t> pos(s_.size() ? s_.size() : 1), val(pos.size()); std::vector<uint8_t> rc(pos.size()); uint64_t n = 0;
+        check(ntk_bit_kmers(c_->get(), s_.data(), s_.size(), k, canonical, pos.data(), val.data(), rc.data(), pos.size(), &n), "ntk_bit_kmers");
+        std::vector<std::tuple<size_t, BitKmer, bool>> out; out.reserve(n);
+        for (uint64_t i = 0; i < n; i++) out.emplace_back(pos[i], BitKmer{val[i], k}, rc[i] != 0);
+        return out;
+    }
+private:
+    Slice s_; Context *c_;
+};
+
+// SequenceRecord (reference src/parser/record.rs:21-179): a view valid until the next FastxReader::next().
+struct SequenceRecord {
+    Slice id_, raw_seq_, qual_; bool has_qual = false; uint64_t line = 0, bases = 0; int fmt = 0;
+    Slice id() const { return id_; }
+    Slice raw_seq() const { return raw_seq_; }
+    Slice sequence() const { return raw_seq_; }  // impl Sequence for SequenceRecord (src/parser/record.rs:181-185)
+    std::optional<Slice> qual() const { return has_qual ? std::optional<Slice>(qual_) : std::nullopt; }
+    size_t num_bases() const { return bases; }
+    uint64_t start_line_number() const { return line; }
+    Bytes normalize(bool iupac) const { return Sequence(raw_seq_).normalize(iupac); }
+};
+
+// FastxReader (reference src/parser/utils.rs:119-130)
+class FastxReader {
+public:
+    explicit FastxReader(ntk_reader *h) : h_(h) {}
+    ~FastxReader() { if (h_) ntk_reader_close(h_); }
+    FastxReader(FastxReader &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    FastxReader(const FastxReader &) = delete;
+    std::optional<SequenceRecord> next() {
+        ntk_record r;
+        const int st = ntk_reader_next(h_, &r);
+        if (st == NTK_EOF) return std::nullopt;
+        if (st != NTK_OK) throw_parse(st);
+        SequenceRecord rec;
+        rec.id_ = Slice(r.id, r.id_len); rec.raw_seq_ = Slice(r.seq, r.seq_len);
+        rec.has_qual = r.qual != nullptr; if (r.qual) rec.qual_ = Slice(r.qual, r.qual_len);
+        rec.line = r.line; rec.bases = r.num_bases; rec.fmt = (int)r.format;
+        return rec;
+    }
+    ntk_reader *get() const { return h_; }
+    [[noreturn]] void throw_parse(int st) const {
+        int kind = 0; uint64_t line = 0; char msg[512] = {0}, id[256] = {0};
+        ntk_reader_error(h_, &kind, &line, msg, sizeof(msg), id, sizeof(id));
+        throw Error(st, msg, kind, line, id);
+    }
+private:
+    ntk_reader *h_;
+};
+
+inline FastxReader parse_fastx_file(const std::string &path) {  // reference src/parser/mod.rs:161
+    ntk_reader *h = nullptr;
+    const int st = ntk_reader_open_file(path.c_str(), &h);
+    FastxReader rd(h);
+    if (st != NTK_OK) { if (h) rd.throw_parse(st); throw Error(st, ntk_strerror(st)); }
+    return rd;
+}
+inline FastxReader parse_fastx_reader(const uint8_t *data, uint64_t n) {  // reference src/parser/mod.rs:85 over a byte slice
+    ntk_reader *h = nullptr;
+    const int st = ntk_reader_open_memory(data, n, &h);
+    FastxReader rd(h);
+    if (st != NTK_OK) { if (h) rd.throw_parse(st); throw Error(st, ntk_strerror(st)); }
+    return rd;
+}
+
+}  // namespace needletail

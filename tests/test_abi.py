@@ -68,3 +68,40 @@ def test_product_never_references_the_oracle():
     assert not bad, bad
     out = subprocess.run(["nm", "-D", "--undefined-only", _ensure_built()], capture_output=True, text=True).stdout
     assert "ntko_" not in out
+
+
+def _build_example():
+    exe = os.path.join(ROOT, "examples", "stdin_pipe")
+    src = os.path.join(ROOT, "examples", "stdin_pipe.cpp")
+    hdr = os.path.join(ROOT, "include", "needletail_amd.hpp")
+    _ensure_built()
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, src, "-L" + os.path.join(ROOT, "needletail_amd"),
+                               "-lneedletail_amd", "-Wl,-rpath,$ORIGIN/../needletail_amd"])
+    return exe
+
+
+def test_cpp_mirror_compiles_and_fails_loudly_without_gpu():
+    """include/needletail_amd.hpp (C++ mirror of the reference surface) + examples/stdin_pipe.cpp build with plain g++."""
+    import torch
+    exe = _build_example()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the example is run by the gpu tests")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "test.fa")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no usable gfx950 device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_example_program_on_gpu():
+    """The reference's example program (examples/stdin_pipe.rs) ported onto the C++ mirror: 28S.fasta -> 738 580 bases
+    (benches/benchmark.rs:151), 8 108 AAAAs; '>id1\\nAGTCGTCA' -> 8 bases, 0 AAAAs (tests/test_stdin.rs:30-31)."""
+    import tempfile
+    exe = _build_example()
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "28S.fasta")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "There are 738580 bases in your file." in r.stdout and "There are 8108 AAAAs in your file." in r.stdout
+    assert "batched: 570 records, 738580 bases, 8108 AAAAs" in r.stdout
+    with tempfile.NamedTemporaryFile(suffix=".fa") as f:
+        f.write(b">id1\nAGTCGTCA\n"); f.flush()
+        r = subprocess.run([exe, f.name], capture_output=True, text=True)
+    assert "There are 8 bases in your file." in r.stdout and "There are 0 AAAAs in your file." in r.stdout
