@@ -391,6 +391,37 @@ def test_full_size_properties_config3(ctx):
     assert rcst["xor"] == whole["xor"] and np.array_equal(rcst["hist"], whole["hist"])
 
 
+def test_materialize_agrees_with_reduce_at_scale(ctx):
+    """The two sinks must describe the same k-mer stream: summing / xoring / counting the dense materialised plane on the
+    device (torch) reproduces the reduce-mode accumulators (2 M reads, k = 21 specialised builds and a generic k)."""
+    n_reads, L = 2_000_000, 150
+    nbytes = n_reads * (L + 1)
+    t = torch.empty(nbytes + 1024, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0002, 77, n_reads, L, 2, t)
+    n16 = (nbytes + 15) // 16
+    vals = torch.empty(n16 * 16, dtype=torch.int64, device="cuda")
+    v16 = torch.empty(n16, dtype=torch.int16, device="cuda")
+    r16 = torch.empty(n16, dtype=torch.int16, device="cuda")
+    shifts = (15 - torch.arange(16, device="cuda", dtype=torch.int32)).view(1, 16)
+    for k, path, pre in ((21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (31, nt.PATH_BITS_CANONICAL, nt.PRE_NONE),
+                         (24, nt.PATH_BITS_CANONICAL, nt.PRE_NONE), (11, nt.PATH_BITS, nt.PRE_NONE)):
+        ctx.accum_reset(); ctx.reduce_device(t, nbytes, k, path, pre); red = ctx.accum_read()
+        ctx.materialize_device(t, nbytes, k, path, pre, vals, v16, r16)
+        valid = ((v16.to(torch.int32).view(-1, 1) & 0xFFFF) >> shifts) & 1
+        rcb = ((r16.to(torch.int32).view(-1, 1) & 0xFFFF) >> shifts) & 1
+        m = valid.view(-1).bool()
+        sel = vals[m]
+        assert int(m.sum()) == red["n_total"] and int((rcb.view(-1).bool() & m).sum()) == red["n_rc"], k
+        assert int(sel.sum()) & 0xFFFFFFFFFFFFFFFF == red["sum"], k            # int64 wrap-around == sum mod 2^64
+        x = sel
+        while x.numel() > 1:                                                    # xor-reduce by halving
+            if x.numel() % 2:
+                x = torch.cat([x, x.new_zeros(1)])
+            x = x[: x.numel() // 2] ^ x[x.numel() // 2:]
+        assert (int(x[0]) & 0xFFFFFFFFFFFFFFFF) == red["xor"], k
+        del sel, x, m, valid, rcb
+
+
 # ---- synthetic generator and BASELINE-size properties ----------------------------------------------------
 
 def test_device_synth_matches_cpu_generator(ctx):
