@@ -116,7 +116,8 @@ int ntk_ctx_scan_time_ms(ntk_ctx *ctx, double *total_ms, uint64_t *launches);
 /* ---- batch face, reduce mode ----------------------------------------------------------------
  * Device batch layout: the records' sequence bytes back to back, each followed by ONE break byte
  * (any non-base byte; the packer writes '\n'), no bytes of the pre-step's "deleted" class inside a
- * record (the packer / ntk_*_device compaction removed them).  d_seq must be 16-byte aligned.
+ * record (the packer, ntk_batch_append, removed them).  d_seq must be 16-byte aligned and readable up to
+ * round_up(n_bytes, 16).
  * Replaces, per record: seq.normalize(..) / strip_returns(), seq.reverse_complement(),
  * seq.canonical_kmers(k,&rc) or seq.bit_kmers(k,canonical) and the user's counting loop
  * (reference src/lib.rs:22-31, benches/benchmark.rs:32-41,55-64). */

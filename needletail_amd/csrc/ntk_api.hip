@@ -161,16 +161,25 @@ template <bool REDUCE>
 hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, hipStream_t st)
 {
     const size_t lds = REDUCE ? 0 : (size_t)(block.x / 64) * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
-    // k-specialised builds for the two k of the reference's own workloads (21: headline; 31: benches/benchmark.rs:15).
-    // Reduce mode runs the scalar-validity variant (-10 %); materialise mode the k = 21 per-lane variant (-5 %; at k = 31
-    // the generic build is faster there: only one of the 16 hi words can be derived from a lo word of the same lane).
+    // k-specialised builds.  Reduce mode: every 17 <= k <= 32 runs the scalar-validity variant (k is a template constant
+    // there: the window-mask algebra indexes lane masks by k), -10..15 % against the generic runtime-k build.
+    // Materialise mode: only k = 21 has a specialised (per-lane) build (-5 %; for larger k the generic build is as fast).
+#define NTK_LAUNCH_SV(KF, T, U)                                                                 \
+    if (REDUCE && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {      \
+        hipLaunchKernelGGL((scan_kernel<2, true, T, U, true, KF, true>), grid, block, lds, st, a); \
+        return hipGetLastError();                                                               \
+    }
+#define NTK_LAUNCH_SV4(KF) NTK_LAUNCH_SV(KF, false, false) NTK_LAUNCH_SV(KF, false, true) NTK_LAUNCH_SV(KF, true, false) NTK_LAUNCH_SV(KF, true, true)
+    NTK_LAUNCH_SV4(17) NTK_LAUNCH_SV4(18) NTK_LAUNCH_SV4(19) NTK_LAUNCH_SV4(20) NTK_LAUNCH_SV4(21) NTK_LAUNCH_SV4(22) NTK_LAUNCH_SV4(23) NTK_LAUNCH_SV4(24)
+    NTK_LAUNCH_SV4(25) NTK_LAUNCH_SV4(26) NTK_LAUNCH_SV4(27) NTK_LAUNCH_SV4(28) NTK_LAUNCH_SV4(29) NTK_LAUNCH_SV4(30) NTK_LAUNCH_SV4(31) NTK_LAUNCH_SV4(32)
+#undef NTK_LAUNCH_SV4
+#undef NTK_LAUNCH_SV
 #define NTK_LAUNCH_FIX(KF, T, U)                                                                \
-    if (m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {                \
-        hipLaunchKernelGGL((scan_kernel<2, true, T, U, REDUCE, KF, REDUCE>), grid, block, lds, st, a);  /* reduce: scalar validity */ \
+    if (!REDUCE && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {     \
+        hipLaunchKernelGGL((scan_kernel<2, true, T, U, false, KF, false>), grid, block, lds, st, a); \
         return hipGetLastError();                                                               \
     }
     NTK_LAUNCH_FIX(21, false, false) NTK_LAUNCH_FIX(21, false, true) NTK_LAUNCH_FIX(21, true, false) NTK_LAUNCH_FIX(21, true, true)
-    if (REDUCE) { NTK_LAUNCH_FIX(31, false, false) NTK_LAUNCH_FIX(31, false, true) NTK_LAUNCH_FIX(31, true, false) NTK_LAUNCH_FIX(31, true, true) }
 #undef NTK_LAUNCH_FIX
 #define NTK_LAUNCH(KW, C, T, U)                                                                 \
     if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U) {                       \

@@ -144,11 +144,12 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     const int kw = k > 16 ? 2 : 1;
     // tiles_per_wave doubles as a switch in this emulation: an odd value selects the k-specialised build when one exists
     const bool fix = (tiles_per_wave & 1) && canon && (k == 21 || k == 31);
-    // bit 1 of tiles_per_wave: the scalar-validity variant (statistics only)
-    const bool sv = fix && (tiles_per_wave & 2) && !values;
+    // bit 1 of tiles_per_wave: the scalar-validity variant (statistics only), built for every 17 <= k <= 32 like the product
+    const bool sv = (tiles_per_wave & 2) && canon && k >= 17 && !values;
 #define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
-    EMU_SV(21, false, false) EMU_SV(21, false, true) EMU_SV(21, true, false) EMU_SV(21, true, true)
-    EMU_SV(31, false, false) EMU_SV(31, false, true) EMU_SV(31, true, false) EMU_SV(31, true, true)
+#define EMU_SV4(KF) EMU_SV(KF, false, false) EMU_SV(KF, false, true) EMU_SV(KF, true, false) EMU_SV(KF, true, true)
+    EMU_SV4(17) EMU_SV4(18) EMU_SV4(19) EMU_SV4(20) EMU_SV4(21) EMU_SV4(22) EMU_SV4(23) EMU_SV4(24)
+    EMU_SV4(25) EMU_SV4(26) EMU_SV4(27) EMU_SV4(28) EMU_SV4(29) EMU_SV4(30) EMU_SV4(31) EMU_SV4(32)
 #define EMU_FIX(KF, T, U) if (fix && k == KF && !!tie_rc == T && !!accept_u == U) { run<2, true, T, U, KF>(buf, n, n_padded, a, st, values, valid16, rc16); } else
     EMU_FIX(21, false, false) EMU_FIX(21, false, true) EMU_FIX(21, true, false) EMU_FIX(21, true, true)
     EMU_FIX(31, false, false) EMU_FIX(31, false, true) EMU_FIX(31, true, false) EMU_FIX(31, true, true)
