@@ -352,7 +352,7 @@ NTK_HD void window_masks(const uint64_t (&G)[16], uint64_t (&OK)[16])
 {
     static_assert(K >= 17 && K <= 32, "sv path is built for 17 <= k <= 32");
     uint64_t P[16], S[16];
-    P[0] = G[0];
+    P[0] = G[0] & ~3ull;  // halo lanes 0/1: cleared once here, inherited by every prefix
 #pragma unroll
     for (int j = 1; j < 16; j++) P[j] = P[j - 1] & G[j];
     S[15] = G[15];
@@ -363,7 +363,7 @@ NTK_HD void window_masks(const uint64_t (&G)[16], uint64_t (&OK)[16])
         const int c = 17 + j - K, a_ = c > 0 ? c : 0;
         uint64_t v = P[j] & (S[a_] << 1);
         if (c < 0) v &= S[(33 + j - K) & 15] << 2;
-        OK[j] = v & ~3ull;
+        OK[j] = v;
     }
 }
 

@@ -480,3 +480,46 @@ def test_reduce_matches_oracle_property(data, k, mode):
         _HCTX.append(nt.Context(0, stream=torch.cuda.current_stream().cuda_stream))
     path, pre, canon, tie, u = mode
     assert_stats_equal(gpu_reduce(_HCTX[0], data, k, path, pre), O.reduce_fused(data, k, canon, tie, u), (k, path, pre, len(data)))
+
+
+# ---- lifecycle / concurrency smoke ----------------------------------------------------------------------------------------
+
+def test_context_lifecycle_and_independent_contexts():
+    """ctx create/destroy in a loop (no leaks that break later work), two independent ctxs interleaved on their own streams,
+    a ctx on a non-default torch stream, and one pinned batch reused many times."""
+    buf = O.synth_reads(0x5EED0009, 0, 500, 150, 3).tobytes()
+    want = O.reduce_fused(buf, 21, True, True, True)
+    t = to_dev(buf)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        with nt.Context(0) as c:
+            c.accum_reset(); c.reduce_device(t, len(buf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+            assert_stats_equal(c.accum_read(), want, "lifecycle")
+    a, b = nt.Context(0), nt.Context(0)
+    a.accum_reset(); b.accum_reset()
+    for _ in range(5):
+        a.reduce_device(t, len(buf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+        b.reduce_device(t, len(buf), 31, nt.PATH_BITS_CANONICAL, nt.PRE_NONE)
+    ra, rb = a.accum_read(), b.accum_read()
+    w31 = O.reduce_fused(buf, 31, True, False, False)
+    assert ra["n_total"] == 5 * want["n_total"] and ra["sum"] == (5 * want["sum"]) & 0xFFFFFFFFFFFFFFFF and ra["xor"] == want["xor"]
+    assert rb["n_total"] == 5 * w31["n_total"] and rb["xor"] == w31["xor"]
+    a.close(); b.close()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with nt.Context(0, stream=s.cuda_stream) as c:
+            c.accum_reset(); c.reduce_device(t, len(buf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+            assert_stats_equal(c.accum_read(), want, "side stream")
+    recs = buf.split(b"\n")[:-1]
+    with nt.Context(0) as c:
+        c.accum_reset()
+        bt = c.batch(1 << 16, 1024)
+        for rep in range(50):
+            for r in recs[:100]:
+                assert bt.append(r, nt.PRE_NORMALIZE)
+            bt.submit(21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+            bt.wait()
+        bt.release()
+        st = c.accum_read()
+        w100 = O.reduce_fused(b"".join(r + b"\n" for r in recs[:100]), 21, True, True, True)
+        assert st["n_total"] == 50 * w100["n_total"] and st["sum"] == (50 * w100["sum"]) & 0xFFFFFFFFFFFFFFFF
