@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--sync-allreduce", action="store_true",
+                    help="keep the per-step all-reduce on the scan's critical path instead of overlapping it")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     args = ap.parse_args()
@@ -102,8 +104,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     stride = args.read_len + 1
@@ -137,15 +143,39 @@ def main():
         if not np.array_equal(got["hist"], want["hist"]):
             raise SystemExit("parity check failed on the histogram")
 
+    # Two accumulator sets: the RCCL all-reduce of step i (on RCCL's own stream) overlaps the scan of step i+1, which
+    # writes the other set.  Every step's accumulators are still all-reduced, and the last one is waited for inside
+    # the timed region.  --sync-allreduce keeps the collective on the scan's critical path (A/B).
+    accs = [acc, torch.zeros_like(acc)]
+    pending = [None, None]
+    state = {"i": 0}
+
     def step():
+        j = state["i"] & 1
+        state["i"] += 1
+        if pending[j] is not None:
+            pending[j].wait()  # the scan stream waits for the older all-reduce of this set
+            pending[j] = None
+        ctx.accum_bind_device(accs[j])
         ctx.accum_reset()
         ctx.reduce_device(seq, n_bytes, args.k, path, pre)
-        if world > 1:
-            nd.allreduce_accumulators(acc)  # ONE RCCL sum all-reduce over xGMI: histogram + counters + digests
+        if use_dist:
+            # ONE RCCL sum all-reduce over xGMI: histogram + counters + digests
+            if args.sync_allreduce:
+                dist.all_reduce(accs[j], op=dist.ReduceOp.SUM)
+            else:
+                pending[j] = dist.all_reduce(accs[j], op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for j in (0, 1):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    drain()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.scan_time_ms()  # drop warm-up events (none recorded yet)
@@ -153,13 +183,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ctx.enable_timing(False)
     kern_ms, launches = ctx.scan_time_ms()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -169,7 +200,9 @@ def main():
     else:
         kern_avg_ms = kern_ms / max(launches, 1)
 
-    res = decode(acc)
+    res = decode(accs[(state["i"] - 1) & 1])
+    if state["i"] >= 2 and not torch.equal(accs[0], accs[1]):
+        raise SystemExit("the two accumulator sets disagree: a step's all-reduce was lost or doubled")
     total_reads = args.reads * world
     ok = res["n_total"] == res["n_fwd"] + res["n_rc"] == int(res["hist"].sum()) and \
         0 < res["n_total"] <= total_reads * (args.read_len - args.k + 1)
@@ -225,7 +258,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
