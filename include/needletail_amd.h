@@ -183,7 +183,8 @@ int ntk_reader_next(ntk_reader *r, ntk_record *rec);  /* NTK_OK, NTK_EOF or NTK_
 int ntk_reader_error(ntk_reader *r, int *kind, uint64_t *line, char *msg, uint64_t msg_cap, char *id, uint64_t id_cap);
 void ntk_reader_close(ntk_reader *r);
 /* Drains the reader through n_batches (>= 2) pinned batches of batch_bytes each; results accumulate in the ctx
- * (ntk_accum_reset / ntk_accum_read around it).  A record longer than a batch is NTK_ERR_CAPACITY. */
+ * (ntk_accum_reset / ntk_accum_read around it).  A record longer than a whole batch is scanned through a one-off batch
+ * of its own size (batch_bytes tunes the overlap, it does not limit the input). */
 int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t batch_bytes, uint32_t n_batches,
                     uint64_t *n_records, uint64_t *n_bases);
 

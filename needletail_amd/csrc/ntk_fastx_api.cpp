@@ -77,6 +77,26 @@ int ntk_reader_error(ntk_reader *h, int *kind, uint64_t *line, char *msg, uint64
 
 void ntk_reader_close(ntk_reader *h) { delete h; }
 
+namespace {
+// A record longer than a whole batch (a chromosome-sized contig against a small batch_bytes): scanned through a one-off
+// batch sized for it, so that the batch size is a tuning knob and never a limit on the input.  The accumulators are sums, so
+// the order relative to the batches still in flight does not matter.
+int scan_oversized_record(ntk_ctx *ctx, std::mutex *mu, const ntk_record &rec, const ntk_params *p)
+{
+    ntk_batch *big = nullptr;
+    int rc = ntk_batch_acquire(ctx, rec.seq_len + 64, 2, &big);
+    if (rc != NTK_OK) return rc;
+    rc = ntk_batch_append(big, rec.seq, rec.seq_len, p->pre);
+    if (rc == NTK_OK) {
+        if (mu) { std::lock_guard<std::mutex> g(*mu); rc = ntk_batch_submit(ctx, big, p); }
+        else rc = ntk_batch_submit(ctx, big, p);
+    }
+    const int w = ntk_batch_wait(ctx, big);
+    ntk_batch_release(ctx, big);
+    return rc != NTK_OK ? rc : w;
+}
+}  // namespace
+
 int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *h, const ntk_params *p, uint64_t batch_bytes, uint32_t n_batches,
                     uint64_t *n_records, uint64_t *n_bases)
 {
@@ -98,7 +118,8 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *h, const ntk_params *p, uint64_t b
             if ((rc = ntk_batch_submit(ctx, batches[cur], p)) != NTK_OK) break;  // async: H2D copy + scan
             cur = (cur + 1) % n_batches;
             if ((rc = ntk_batch_wait(ctx, batches[cur])) != NTK_OK) break;        // the oldest batch in flight
-            a = ntk_batch_append(batches[cur], rec.seq, rec.seq_len, p->pre);     // still too big -> CAPACITY
+            a = ntk_batch_append(batches[cur], rec.seq, rec.seq_len, p->pre);
+            if (a == NTK_ERR_CAPACITY) a = scan_oversized_record(ctx, nullptr, rec, p);  // longer than an empty batch
         }
         if (a != NTK_OK) { rc = a; break; }
         nrec++; nbases += rec.num_bases;
@@ -175,6 +196,7 @@ void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
             cur ^= 1;
             if ((rc = ntk_batch_wait(sh->ctx, b[cur])) != NTK_OK) break;  // event wait only: no ctx state touched
             a = ntk_batch_append(b[cur], rec.seq, rec.seq_len, sh->p->pre);
+            if (a == NTK_ERR_CAPACITY) a = scan_oversized_record(sh->ctx, &sh->mu, rec, sh->p);
         }
         if (a != NTK_OK) { rc = a; break; }
         nrec++; nbases += rec.num_bases;

@@ -275,9 +275,11 @@ def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
     with pytest.raises(nt.NtkError) as e:   # gzip streams are sequential: the parallel entry point refuses them
         nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
     assert e.value.status == 6
-    with pytest.raises(nt.NtkError) as e:   # a record longer than a batch is an error, not a silent truncation
-        nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1024)
-    assert e.value.status == 5
+    # records longer than a whole batch go through a one-off batch of their own: batch_bytes is a knob, not a limit
+    st = nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1024)
+    assert_stats_equal(st, O.reduce_records(recs, 4, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), "oversized records")
+    stp = nt.scan_file_parallel(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=4, batch_bytes=1024)
+    assert_stats_equal(stp, st, "oversized records, parallel")
 
 
 # ---- minimizers and quality mask ---------------------------------------------------------
@@ -523,3 +525,35 @@ def test_context_lifecycle_and_independent_contexts():
         st = c.accum_read()
         w100 = O.reduce_fused(b"".join(r + b"\n" for r in recs[:100]), 21, True, True, True)
         assert st["n_total"] == 50 * w100["n_total"] and st["sum"] == (50 * w100["sum"]) & 0xFFFFFFFFFFFFFFFF
+
+
+def _specimen_files():
+    import tomli
+    spec = os.path.join(os.path.dirname(__file__), "golden", "specimen")
+    out = []
+    for kind, skip in (("FASTA", set()), ("FASTQ", {"wrapping_original_sanger.fastq", "longreads_original_sanger.fastq", "tricky.fastq"})):
+        with open(os.path.join(spec, kind, "index.toml"), "rb") as f:
+            idx = tomli.load(f)
+        for t in idx["valid"]:
+            if "comments" in (t.get("tags") or []) or t["filename"] in skip:
+                continue
+            out.append(os.path.join(spec, kind, t["filename"]))
+    return out
+
+
+def test_specimen_corpus_through_the_pipeline(ctx):
+    """Every valid file of the reference's conformance corpus (reference tests/format_specimens.rs; protein, RNA, IUPAC,
+    gapped, soft-masked, DOS line ends, zero-length records ...) through parser -> pinned batches -> scan, against the
+    literal per-record oracle chain on the parser's raw sequences, for the README mode and both bit modes."""
+    files = _specimen_files()
+    assert len(files) > 80
+    n_kmers = 0
+    for path in files:
+        recs = [r.raw_seq for r in nt.parse_fastx_file(path)]
+        for k, p, pre in ((4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS),
+                          (7, nt.PATH_BITS, nt.PRE_NORMALIZE_IUPAC)):
+            st = nt.scan_file(ctx, path, k, p, pre, batch_bytes=1 << 16)
+            assert st["n_records"] == len(recs), path
+            assert_stats_equal(st, O.reduce_records(recs, k, p, pre), f"{os.path.basename(path)} k={k}")
+            n_kmers += st["n_total"]
+    assert n_kmers > 10_000
