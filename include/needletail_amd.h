@@ -168,9 +168,10 @@ typedef struct ntk_record {
     const uint8_t *seq;  uint64_t seq_len;   /* SequenceRecord::raw_seq()  reference src/parser/record.rs:78-83  */
     const uint8_t *qual; uint64_t qual_len;  /* SequenceRecord::qual(); NULL for FASTA                          */
     uint32_t format;                         /* 0 = FASTA, 1 = FASTQ                                            */
-    uint32_t reserved;
+    uint32_t line_ending;                    /* SequenceRecord::line_ending(): 1 = Unix, 2 = Windows  record.rs:150-153 */
     uint64_t line;                           /* SequenceRecord::start_line_number()                            */
     uint64_t num_bases;                      /* SequenceRecord::num_bases()                                    */
+    uint64_t byte;                           /* SequenceRecord::position().byte()  reference src/parser/record.rs:147-149 */
 } ntk_record;
 enum { /* ParseErrorKind, reference src/errors.rs:26-44 */
     NTK_PARSE_IO = 1, NTK_PARSE_UNKNOWN_FORMAT = 2, NTK_PARSE_INVALID_START = 3, NTK_PARSE_INVALID_SEPARATOR = 4,
@@ -181,6 +182,9 @@ int ntk_reader_open_file(const char *path, ntk_reader **out);
 int ntk_reader_open_memory(const uint8_t *data, uint64_t n, ntk_reader **out); /* data must outlive the reader */
 int ntk_reader_next(ntk_reader *r, ntk_record *rec);  /* NTK_OK, NTK_EOF or NTK_ERR_PARSE */
 int ntk_reader_error(ntk_reader *r, int *kind, uint64_t *line, char *msg, uint64_t msg_cap, char *id, uint64_t id_cap);
+/* FastxReader::position / line_ending (reference src/parser/utils.rs:125-130): line and byte offset of the record handed
+ * out last; *ending = 0 before the first record (the reference's None), 1 = Unix, 2 = Windows.  Out-pointers may be NULL. */
+int ntk_reader_position(ntk_reader *r, uint64_t *line, uint64_t *byte, int *ending);
 void ntk_reader_close(ntk_reader *r);
 /* Drains the reader through n_batches (>= 2) pinned batches of batch_bytes each; results accumulate in the ctx
  * (ntk_accum_reset / ntk_accum_read around it).  A record longer than a whole batch is scanned through a one-off batch

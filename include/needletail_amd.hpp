@@ -91,15 +91,21 @@ private:
     Slice s_; Context *c_;
 };
 
+// Position / LineEnding (reference src/parser/utils.rs:50-104)
+struct Position { uint64_t line_ = 0, byte_ = 0; uint64_t line() const { return line_; } uint64_t byte() const { return byte_; } };
+enum class LineEnding { Windows, Unix };
+
 // SequenceRecord (reference src/parser/record.rs:21-179): a view valid until the next FastxReader::next().
 struct SequenceRecord {
-    Slice id_, raw_seq_, qual_; bool has_qual = false; uint64_t line = 0, bases = 0; int fmt = 0;
+    Slice id_, raw_seq_, qual_; bool has_qual = false; uint64_t line = 0, bases = 0, byte = 0; int fmt = 0, ending = 1;
     Slice id() const { return id_; }
     Slice raw_seq() const { return raw_seq_; }
     Slice sequence() const { return raw_seq_; }  // impl Sequence for SequenceRecord (src/parser/record.rs:181-185)
     std::optional<Slice> qual() const { return has_qual ? std::optional<Slice>(qual_) : std::nullopt; }
     size_t num_bases() const { return bases; }
     uint64_t start_line_number() const { return line; }
+    Position position() const { return Position{line, byte}; }           // src/parser/record.rs:147-149
+    LineEnding line_ending() const { return ending == 2 ? LineEnding::Windows : LineEnding::Unix; }  // :152-154
     Bytes normalize(bool iupac) const { return Sequence(raw_seq_).normalize(iupac); }
 };
 
@@ -118,8 +124,16 @@ public:
         SequenceRecord rec;
         rec.id_ = Slice(r.id, r.id_len); rec.raw_seq_ = Slice(r.seq, r.seq_len);
         rec.has_qual = r.qual != nullptr; if (r.qual) rec.qual_ = Slice(r.qual, r.qual_len);
-        rec.line = r.line; rec.bases = r.num_bases; rec.fmt = (int)r.format;
+        rec.line = r.line; rec.bases = r.num_bases; rec.fmt = (int)r.format; rec.byte = r.byte; rec.ending = (int)r.line_ending;
         return rec;
+    }
+    Position position() const {                                        // src/parser/utils.rs:125-126
+        Position p; ntk_reader_position(h_, &p.line_, &p.byte_, nullptr); return p;
+    }
+    std::optional<LineEnding> line_ending() const {                    // src/parser/utils.rs:127-130
+        int e = 0; ntk_reader_position(h_, nullptr, nullptr, &e);
+        if (!e) return std::nullopt;
+        return e == 2 ? LineEnding::Windows : LineEnding::Unix;
     }
     ntk_reader *get() const { return h_; }
     [[noreturn]] void throw_parse(int st) const {

@@ -28,7 +28,7 @@ SYMBOLS = [
     "ntk_batch_release",
     "ntk_normalize", "ntk_strip_returns", "ntk_reverse_complement", "ntk_canonical_kmers", "ntk_bit_kmers",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
-    "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_close",
+    "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_position", "ntk_reader_close",
     "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points",
     "ntk_minimizers_reduce_device", "ntk_minimizer", "ntk_bit_minimizers", "ntk_quality_mask", "ntk_bit_canonical",
 ]
@@ -45,8 +45,8 @@ class Result(C.Structure):
 
 class Record(C.Structure):
     _fields_ = [("id", C.c_void_p), ("id_len", C.c_uint64), ("seq", C.c_void_p), ("seq_len", C.c_uint64),
-                ("qual", C.c_void_p), ("qual_len", C.c_uint64), ("format", C.c_uint32), ("reserved", C.c_uint32),
-                ("line", C.c_uint64), ("num_bases", C.c_uint64)]
+                ("qual", C.c_void_p), ("qual_len", C.c_uint64), ("format", C.c_uint32), ("line_ending", C.c_uint32),
+                ("line", C.c_uint64), ("num_bases", C.c_uint64), ("byte", C.c_uint64)]
 
 
 class NtkError(RuntimeError):
@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
     L.ntk_reader_open_memory.argtypes = [C.c_char_p, u64, pp]
     L.ntk_reader_next.argtypes = [vp, C.POINTER(Record)]
     L.ntk_reader_error.argtypes = [vp, C.POINTER(i32), C.POINTER(u64), C.c_char_p, u64, C.c_char_p, u64]
+    L.ntk_reader_position.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
     L.ntk_reader_close.restype = None
     L.ntk_reader_close.argtypes = [vp]
     L.ntk_scan_reader.argtypes = [vp, vp, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]

@@ -170,9 +170,17 @@ int FastxReader::next(FastxRecord *rec)
 {
     if (finished_ || !started_) return err_kind_ ? -1 : 0;
     // release the previous record
-    start_ += prev_len_; line_ += prev_lines_;
+    start_ += prev_len_; line_ += prev_lines_; byte_ += prev_len_;
     prev_len_ = 0; prev_lines_ = 0;
     return format_ == kFasta ? next_fasta(rec) : next_fastq(rec);
+}
+
+// find_line_ending over the first record's bytes (reference src/parser/utils.rs:106-117, fasta.rs:358-360, fastq.rs:438-440)
+void FastxReader::note_line_ending(const uint8_t *all, size_t n)
+{
+    if (line_ending_ || n == 0) return;
+    const uint8_t *p = (const uint8_t *)memchr(all, '\n', n);
+    if (p) line_ending_ = (p > all && p[-1] == '\r') ? 2 : 1;
 }
 
 int FastxReader::next_fasta(FastxRecord *rec)
@@ -238,6 +246,9 @@ int FastxReader::next_fasta(FastxRecord *rec)
     for (uint64_t i = 0; i < rec->seq_len; i++) nb -= (rec->seq[i] == '\n' || rec->seq[i] == '\r');
     rec->num_bases = nb;
     prev_len_ = rec_len; prev_lines_ = n_lines;
+    // the reference looks at the record without its final line end (fasta.rs:40-42 `all`): ">id\nACGT"
+    note_line_ending(base, last_nl < rec_len ? last_nl : rec_len);
+    rec->byte = byte_; rec->line_ending = line_ending_ ? line_ending_ : 1;  // record.rs:39,53 unwrap_or(Unix)
     return 1;
 }
 
@@ -302,6 +313,8 @@ int FastxReader::next_fastq(FastxRecord *rec)
     rec->num_bases = seq_len;
     prev_len_ = end < len_ - start_ ? end + 1 : end;
     prev_lines_ = 4;
+    note_line_ending(base, end);
+    rec->byte = byte_; rec->line_ending = line_ending_ ? line_ending_ : 1;  // record.rs:39,53 unwrap_or(Unix)
     return 1;
 }
 

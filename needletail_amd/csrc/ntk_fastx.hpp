@@ -37,6 +37,8 @@ struct FastxRecord {
     int format = kFasta;
     uint64_t line = 0;        // start_line_number()
     uint64_t num_bases = 0;   // reference src/parser/fasta.rs:102-107 / fastq.rs:52
+    uint64_t byte = 0;        // position().byte(): offset of the record start in the (decompressed) stream
+    int line_ending = 0;      // SequenceRecord::line_ending(): 1 = Unix, 2 = Windows
 };
 
 class FastxReader {
@@ -56,6 +58,11 @@ public:
     uint64_t error_line() const { return err_line_; }
     const std::string &error_id() const { return err_id_; }
     int format() const { return format_; }
+    // FastxReader::position (reference src/parser/utils.rs:125-126): line / byte of the record handed out last
+    uint64_t position_line() const { return line_; }
+    uint64_t position_byte() const { return byte_; }
+    // FastxReader::line_ending (reference src/parser/utils.rs:127-130): 0 before the first record, 1 = Unix, 2 = Windows
+    int line_ending() const { return line_ending_; }
 
 private:
     // raw source
@@ -72,6 +79,8 @@ private:
     int format_ = kFasta; bool started_ = false, finished_ = false;
     uint64_t line_ = 1;        // line number of the record about to be parsed
     size_t prev_len_ = 0; uint64_t prev_lines_ = 0;
+    uint64_t byte_ = 0; int line_ending_ = 0;
+    void note_line_ending(const uint8_t *all, size_t n);
     bool fail(int kind, const std::string &msg, uint64_t line, const std::string &id = std::string());
     int next_fasta(FastxRecord *rec);
     int next_fastq(FastxRecord *rec);

@@ -60,8 +60,8 @@ int ntk_reader_next(ntk_reader *h, ntk_record *rec)
     if (rc < 0) return NTK_ERR_PARSE;
     if (rc == 0) return NTK_EOF;
     rec->id = fr.id; rec->id_len = fr.id_len; rec->seq = fr.seq; rec->seq_len = fr.seq_len;
-    rec->qual = fr.qual; rec->qual_len = fr.qual_len; rec->format = (uint32_t)fr.format; rec->reserved = 0;
-    rec->line = fr.line; rec->num_bases = fr.num_bases;
+    rec->qual = fr.qual; rec->qual_len = fr.qual_len; rec->format = (uint32_t)fr.format; rec->line_ending = (uint32_t)fr.line_ending;
+    rec->line = fr.line; rec->num_bases = fr.num_bases; rec->byte = fr.byte;
     return NTK_OK;
 }
 
@@ -72,6 +72,15 @@ int ntk_reader_error(ntk_reader *h, int *kind, uint64_t *line, char *msg, uint64
     if (line) *line = h->r.error_line();
     copy_str(h->r.error_msg(), msg, msg_cap);
     copy_str(h->r.error_id(), id, id_cap);
+    return NTK_OK;
+}
+
+int ntk_reader_position(ntk_reader *h, uint64_t *line, uint64_t *byte, int *ending)
+{
+    if (!h) return NTK_ERR_BAD_ARG;
+    if (line) *line = h->r.position_line();
+    if (byte) *byte = h->r.position_byte();
+    if (ending) *ending = h->r.line_ending();
     return NTK_OK;
 }
 

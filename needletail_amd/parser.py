@@ -29,13 +29,15 @@ class Record:
     """reference src/python.rs:100-290 / needletail.pyi: id, seq (line breaks stripped), qual, name, description."""
 
     def __init__(self, id: str, seq: str, qual: Optional[str] = None, raw_seq: bytes = None, line: int = 0,
-                 num_bases: int = None):
+                 num_bases: int = None, byte: int = 0, line_ending: str = "\n"):
         self.id = id
         self.seq = seq
         self.qual = qual
         self.raw_seq = raw_seq if raw_seq is not None else seq.encode()
         self.line = line
         self.num_bases = len(seq) if num_bases is None else num_bases
+        self.byte = byte                  # SequenceRecord::position().byte()  (reference src/parser/record.rs:147-149)
+        self.line_ending = line_ending    # SequenceRecord::line_ending()      (reference src/parser/record.rs:152-154)
 
     @property
     def name(self) -> str:
@@ -94,6 +96,7 @@ class FastxReader:
         rid = C.string_at(rec.id, rec.id_len)
         seq = C.string_at(rec.seq, rec.seq_len)
         qual = C.string_at(rec.qual, rec.qual_len) if rec.qual else None
+        self._last = (rec.byte, "\r\n" if rec.line_ending == 2 else "\n")
         return rid, seq, qual, rec.line, rec.num_bases
 
     def __iter__(self) -> Iterator[Record]:
@@ -107,7 +110,19 @@ class FastxReader:
         # SequenceRecord::seq(): raw_seq minus CR/LF (reference src/parser/record.rs:85-92, fasta.rs:65-99)
         seq = raw.replace(b"\n", b"").replace(b"\r", b"") if qual is None else raw
         return Record(rid.decode("utf-8", "replace"), seq.decode("utf-8", "replace"),
-                      qual.decode("utf-8", "replace") if qual is not None else None, raw, line, nb)
+                      qual.decode("utf-8", "replace") if qual is not None else None, raw, line, nb, *self._last)
+
+    def position(self):
+        """FastxReader::position (reference src/parser/utils.rs:125-126): (line, byte) of the record handed out last."""
+        line, byte = C.c_uint64(0), C.c_uint64(0)
+        L.check(L.lib().ntk_reader_position(self._h, C.byref(line), C.byref(byte), None), "ntk_reader_position")
+        return line.value, byte.value
+
+    def line_ending(self):
+        """FastxReader::line_ending (reference src/parser/utils.rs:127-130): None before the first record."""
+        e = C.c_int(0)
+        L.check(L.lib().ntk_reader_position(self._h, None, None, C.byref(e)), "ntk_reader_position")
+        return {0: None, 1: "\n", 2: "\r\n"}[e.value]
 
     def close(self):
         if self._h:

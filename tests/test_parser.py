@@ -193,3 +193,36 @@ def test_parallel_split_points_are_record_starts():
     cuts = (C.c_uint64 * 9)()
     assert L.lib().ntk_fastx_split_points(fa, len(fa), 8, cuts) == 0
     assert all(fa[c:c + 2] == b">c" or c == len(fa) for c in cuts)
+
+
+def test_record_position_and_line_number():
+    """reference src/parser/record.rs:259-285 (test_start_line_number, test_position)."""
+    r = nt.parse_fastx_string("@test\nACGT\n+\nIIII\n@test2\nACGT\n+\nIIII")
+    assert [rec.line for rec in r] == [1, 5]
+    r = nt.parse_fastx_string("@test1\nACGT\n+\nIIII\n@test222\nACGT\n+\nIIII\n@test3\nACGT\n+\nIIII")
+    got = []
+    for rec in r:
+        got.append(rec.byte)
+        assert r.position() == (rec.line, rec.byte)
+    assert got == [0, 19, 40]
+    # FASTA: byte offsets advance by whole records, lines by the record's line count
+    r = nt.parse_fastx_string(">a\nAC\nGT\n>b\nA\n>c\nACGT")
+    assert [(rec.line, rec.byte) for rec in r] == [(1, 0), (4, 9), (6, 14)]
+
+
+def test_reader_line_ending():
+    """reference src/parser/fasta.rs:390-441, fastq.rs tests: None before the first next(), then Unix / Windows."""
+    r = nt.parse_fastx_string(">test\nACGT\n>test2\nTGCA\n")
+    assert r.line_ending() is None
+    rec = next(r)
+    assert r.line_ending() == "\n" and rec.line_ending == "\n"
+    r = nt.parse_fastx_string(">test\r\nACGT\r\nACGT\r\n>test2\r\nTGCA\r\nTG")
+    rec = next(r)
+    assert rec.raw_seq == b"ACGT\r\nACGT" and rec.num_bases == 8 and rec.line == 1
+    assert r.line_ending() == "\r\n" and rec.line_ending == "\r\n"
+    r = nt.parse_fastx_string("@test\r\nAGCT\r\n+test\r\n~~a!\r\n")
+    rec = next(r)
+    assert r.line_ending() == "\r\n" and rec.qual == "~~a!"
+    r = nt.parse_fastx_string("@test\nAGCT\n+test\n~~a!")
+    next(r)
+    assert r.line_ending() == "\n"
