@@ -71,8 +71,12 @@ typedef struct ntk_params {
     uint32_t pre;  /* NTK_PRE_*                                                        */
     uint32_t flags;/* bits 7:0 = minimizer window w (k-mers per window; 0 = plain k-mers):  */
                    /* reduce entry points then fold windowed minimizers instead of k-mers; */
+                   /* bits 15:8 = quality cutoff (0 = none): bases whose quality byte is below it  */
+                   /* are masked as QualitySequence::quality_mask does (src/sequence.rs:285-296)   */
+                   /* on the *_quality entry points and on batches that carry qualities;           */
                    /* other bits reserved, must be 0                                      */
 } ntk_params;
+#define NTK_FLAGS(window_w, quality_cutoff) (((uint32_t)(window_w) & 0xFFu) | (((uint32_t)(quality_cutoff) & 0xFFu) << 8))
 
 /* Reduced result of a scan.  `value` is the emitted k-mer in the reference's
  * 2-bit encoding (A0 C1 G2 T3, first base most significant; src/bitkmer.rs:5-36). */
@@ -123,6 +127,12 @@ int ntk_ctx_scan_time_ms(ntk_ctx *ctx, double *total_ms, uint64_t *launches);
  * (reference src/lib.rs:22-31, benches/benchmark.rs:32-41,55-64). */
 int ntk_accum_reset(ntk_ctx *ctx);
 int ntk_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p); /* async */
+/* Quality masking fused into the scan: `(seq, qual).quality_mask(cutoff)` (reference
+ * src/sequence.rs:285-296: a base whose RAW quality byte is < cutoff becomes N) followed by the chain above, in one pass.
+ * d_qual has the layout and alignment of d_seq (one quality byte per sequence byte; the byte under a record's break byte
+ * is ignored).  cutoff = bits 15:8 of p->flags; d_qual NULL or cutoff 0 = ntk_reduce_device. */
+int ntk_reduce_device_quality(ntk_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_bytes,
+                              const ntk_params *p);                                      /* async */
 int ntk_accum_read(ntk_ctx *ctx, ntk_result *out);            /* synchronises the ctx stream        */
 int ntk_accum_device_ptr(ntk_ctx *ctx, uint64_t **d_words);  /* NTK_ACC_WORDS u64 words on device  */
 /* Accumulate into caller-owned device memory (NTK_ACC_WORDS u64, e.g. a torch tensor that is then
@@ -139,6 +149,8 @@ int ntk_accum_bind_device(ntk_ctx *ctx, uint64_t *d_words);
  * d_rc16 hold ceil(n_bytes/16) u16 each.  d_values may be NULL (flags only). */
 int ntk_materialize_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p,
                            uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16);   /* async */
+int ntk_materialize_device_quality(ntk_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n_bytes,
+                                   const ntk_params *p, uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16);
 
 /* ---- batch face, pinned host batches (CPU parser fills, H2D copy overlaps the kernels) ---------
  * A batch exposes PINNED host memory; the caller (FastxReader loop) appends records between
@@ -150,6 +162,13 @@ int ntk_batch_acquire(ntk_ctx *ctx, uint64_t max_bytes, uint64_t max_records, nt
  * applying the DELETE part of `pre` (NONE: nothing; STRIP_RETURNS: CR/LF; NORMALIZE*: space, tab, CR, LF),
  * then one break byte.  NTK_ERR_CAPACITY when the batch is full (submit it and acquire another). */
 int ntk_batch_append(ntk_batch *b, const uint8_t *seq, uint64_t n, uint32_t pre);
+/* The same with the record's quality line (`SequenceRecord::qual()`, n bytes) for masking at `cutoff` (1..255): the batch
+ * then carries a parallel pinned quality stream, copied and applied by ntk_batch_submit, whose p->flags must hold the
+ * same cutoff (NTK_ERR_BAD_ARG otherwise; one cutoff per fill).  A byte of the deleted class is dropped with its quality
+ * byte unless that quality is below the cutoff - the reference masks before it normalizes, so such a byte is an N by
+ * then.  Records appended without qualities are never masked. */
+int ntk_batch_append_quality(ntk_batch *b, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint32_t pre,
+                             uint32_t cutoff);
 int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t *n_bytes, uint64_t *n_records);
 int ntk_batch_submit(ntk_ctx *ctx, ntk_batch *b, const ntk_params *p);  /* async: H2D + reduce */
 int ntk_batch_wait(ntk_ctx *ctx, ntk_batch *b);

@@ -22,9 +22,9 @@ SYMBOLS = [
     "ntk_strerror", "ntk_last_hip_error", "ntk_abi_version",
     "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
     "ntk_ctx_set_launch", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
-    "ntk_accum_reset", "ntk_reduce_device", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
-    "ntk_materialize_device",
-    "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
+    "ntk_accum_reset", "ntk_reduce_device", "ntk_reduce_device_quality", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
+    "ntk_materialize_device", "ntk_materialize_device_quality",
+    "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_append_quality", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
     "ntk_batch_release",
     "ntk_normalize", "ntk_strip_returns", "ntk_reverse_complement", "ntk_canonical_kmers", "ntk_bit_kmers",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
@@ -36,6 +36,13 @@ SYMBOLS = [
 
 class Params(C.Structure):
     _fields_ = [("k", C.c_uint32), ("path", C.c_uint32), ("pre", C.c_uint32), ("flags", C.c_uint32)]
+
+
+def flags(w: int = 0, quality_cutoff: int = 0) -> int:
+    """ntk_params.flags (NTK_FLAGS): bits 7:0 minimizer window, bits 15:8 quality cutoff."""
+    if not (0 <= w <= 255 and 0 <= quality_cutoff <= 255):
+        raise ValueError("w and quality_cutoff must be 0..255")
+    return w | (quality_cutoff << 8)
 
 
 class Result(C.Structure):
@@ -83,12 +90,15 @@ def lib() -> C.CDLL:
     L.ntk_ctx_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.ntk_accum_reset.argtypes = [vp]
     L.ntk_reduce_device.argtypes = [vp, vp, u64, C.POINTER(Params)]
+    L.ntk_reduce_device_quality.argtypes = [vp, vp, vp, u64, C.POINTER(Params)]
     L.ntk_accum_read.argtypes = [vp, C.POINTER(Result)]
     L.ntk_accum_device_ptr.argtypes = [vp, pp]
     L.ntk_accum_bind_device.argtypes = [vp, vp]
     L.ntk_materialize_device.argtypes = [vp, vp, u64, C.POINTER(Params), vp, vp, vp]
+    L.ntk_materialize_device_quality.argtypes = [vp, vp, vp, u64, C.POINTER(Params), vp, vp, vp]
     L.ntk_batch_acquire.argtypes = [vp, u64, u64, pp]
     L.ntk_batch_append.argtypes = [vp, C.c_char_p, u64, u32]
+    L.ntk_batch_append_quality.argtypes = [vp, C.c_char_p, C.c_char_p, u64, u32, u32]
     L.ntk_batch_buffers.argtypes = [vp, pp, pp, C.POINTER(u64), C.POINTER(u64)]
     L.ntk_batch_submit.argtypes = [vp, vp, C.POINTER(Params)]
     L.ntk_batch_wait.argtypes = [vp, vp]

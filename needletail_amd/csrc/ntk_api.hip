@@ -104,6 +104,10 @@ struct ntk_batch {
     uint8_t *h_seq = nullptr;
     uint64_t *h_off = nullptr;
     uint8_t *d_seq = nullptr;
+    uint8_t *h_qual = nullptr, *d_qual = nullptr;  // allocated by the first ntk_batch_append_quality
+    bool has_qual = false;                         // some record of the current fill carries qualities
+    uint32_t qual_cutoff = 0;                      // ... appended for this cutoff (must be the one submitted)
+    int device = 0;
     uint64_t cap_bytes = 0, cap_records = 0, n_bytes = 0, n_records = 0;
     hipEvent_t ev_copied = nullptr, ev_done = nullptr;
     bool in_flight = false;
@@ -135,12 +139,13 @@ int ensure_partials(ntk_ctx *c, int blocks)
 }
 
 struct Mode { int kw; bool canon, tie_rc, accept_u; };
+inline uint32_t quality_cutoff(const ntk_params *p) { return (p->flags >> 8) & 0xFFu; }
 
 int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 {
     if (!p) return NTK_ERR_BAD_ARG;
     if (p->k < 1 || p->k > 32) return NTK_ERR_BAD_K;
-    if ((p->flags & ~0xFFu) != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
+    if ((p->flags & ~0xFFFFu) != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
     m->kw = p->k > 16 ? 2 : 1;
     m->accept_u = p->pre >= NTK_PRE_NORMALIZE;
     switch (p->path) {
@@ -157,7 +162,7 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
     return NTK_OK;
 }
 
-template <bool REDUCE>
+template <bool REDUCE, bool QM>
 hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, hipStream_t st)
 {
     const size_t lds = REDUCE ? 0 : (size_t)(block.x / 64) * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
@@ -165,7 +170,7 @@ hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, 
     // there: the window-mask algebra indexes lane masks by k), -10..15 % against the generic runtime-k build.
     // Materialise mode: only k = 21 has a specialised (per-lane) build (-5 %; for larger k the generic build is as fast).
 #define NTK_LAUNCH_SV(KF, T, U)                                                                 \
-    if (REDUCE && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {      \
+    if (REDUCE && !QM && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) { \
         hipLaunchKernelGGL((scan_kernel<2, true, T, U, true, KF, true>), grid, block, lds, st, a); \
         return hipGetLastError();                                                               \
     }
@@ -174,8 +179,17 @@ hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, 
     NTK_LAUNCH_SV4(25) NTK_LAUNCH_SV4(26) NTK_LAUNCH_SV4(27) NTK_LAUNCH_SV4(28) NTK_LAUNCH_SV4(29) NTK_LAUNCH_SV4(30) NTK_LAUNCH_SV4(31) NTK_LAUNCH_SV4(32)
 #undef NTK_LAUNCH_SV4
 #undef NTK_LAUNCH_SV
+    // quality-masking builds of the scalar-validity variant: the two k the reference's own programs use (21, 31)
+#define NTK_LAUNCH_SVQ(KF, T, U)                                                                \
+    if (REDUCE && QM && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) { \
+        hipLaunchKernelGGL((scan_kernel<2, true, T, U, true, KF, true, true>), grid, block, lds, st, a); \
+        return hipGetLastError();                                                               \
+    }
+    NTK_LAUNCH_SVQ(21, false, false) NTK_LAUNCH_SVQ(21, false, true) NTK_LAUNCH_SVQ(21, true, false) NTK_LAUNCH_SVQ(21, true, true)
+    NTK_LAUNCH_SVQ(31, false, false) NTK_LAUNCH_SVQ(31, false, true) NTK_LAUNCH_SVQ(31, true, false) NTK_LAUNCH_SVQ(31, true, true)
+#undef NTK_LAUNCH_SVQ
 #define NTK_LAUNCH_FIX(KF, T, U)                                                                \
-    if (!REDUCE && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) {     \
+    if (!REDUCE && !QM && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) { \
         hipLaunchKernelGGL((scan_kernel<2, true, T, U, false, KF, false>), grid, block, lds, st, a); \
         return hipGetLastError();                                                               \
     }
@@ -183,7 +197,7 @@ hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, 
 #undef NTK_LAUNCH_FIX
 #define NTK_LAUNCH(KW, C, T, U)                                                                 \
     if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U) {                       \
-        hipLaunchKernelGGL((scan_kernel<KW, C, T, U, REDUCE>), grid, block, lds, st, a);          \
+        hipLaunchKernelGGL((scan_kernel<KW, C, T, U, REDUCE, 0, false, QM>), grid, block, lds, st, a); \
         return hipGetLastError();                                                               \
     }
     NTK_LAUNCH(1, false, false, false) NTK_LAUNCH(1, false, false, true)
@@ -206,10 +220,11 @@ int get_event(ntk_ctx *c, hipEvent_t *e)
 // One scan over d_seq[0, n): launches cover at most kMaxTilesPerLaunch tiles each so that per-block u32
 // histogram cells and 32-bit buffer offsets cannot overflow.
 int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
-             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16)
+             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16, const uint8_t *d_qual = nullptr)
 {
     if (n == 0) return NTK_OK;
-    if (!d_seq || ((uintptr_t)d_seq & 15)) return NTK_ERR_BAD_ARG;
+    if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
+    const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
     const int threads = reduce ? c->launch_threads : 256;
     const int waves_per_block = threads / 64;
@@ -222,6 +237,7 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     a.n_bytes = n;
     a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
     a.values = d_values; a.valid16 = d_valid16; a.rc16 = d_rc16;
+    if (cutoff) { const QualityCut qc = quality_cut(cutoff); a.qual = d_qual; a.q_add = qc.add; a.q_sel = qc.sel; }
     // per launch: a shard holds <= 2^22 tiles so that the per-block u32 histogram cells (a block can at most drain its
     // whole shard: 2^22 * 992 windows) and the u32 work counters cannot overflow
     const uint64_t kMaxTilesPerLaunch = (uint64_t)8 << 22;
@@ -253,8 +269,10 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
             rc = get_event(c, &e1); if (rc) return rc;
             HIPCHK(hipEventRecord(e0, c->stream));
         }
-        HIPCHK(reduce ? launch_scan<true>(m, a, dim3(blocks), dim3(threads), c->stream)
-                      : launch_scan<false>(m, a, dim3(blocks), dim3(threads), c->stream));
+        HIPCHK(cutoff ? (reduce ? launch_scan<true, true>(m, a, dim3(blocks), dim3(threads), c->stream)
+                                : launch_scan<false, true>(m, a, dim3(blocks), dim3(threads), c->stream))
+                      : (reduce ? launch_scan<true, false>(m, a, dim3(blocks), dim3(threads), c->stream)
+                                : launch_scan<false, false>(m, a, dim3(blocks), dim3(threads), c->stream)));
         if (c->timing) {
             HIPCHK(hipEventRecord(e1, c->stream));
             c->ev_used.emplace_back(e0, e1);
@@ -395,15 +413,22 @@ int ntk_accum_reset(ntk_ctx *c)
     return NTK_OK;
 }
 
-int ntk_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p)
+static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, const ntk_params *p, uint32_t w);
+
+int ntk_reduce_device_quality(ntk_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, const ntk_params *p)
 {
     if (!c) return NTK_ERR_BAD_ARG;
     Mode m;
     int rc = resolve_mode(p, true, &m);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
-    if (p->flags & 0xFFu) return ntk_minimizers_reduce_device(c, d_seq, n, p, p->flags & 0xFFu);
-    return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr);
+    if (p->flags & 0xFFu) return minimizers_reduce_impl(c, d_seq, d_qual, n, p, p->flags & 0xFFu);
+    return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, d_qual);
+}
+
+int ntk_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p)
+{
+    return ntk_reduce_device_quality(c, d_seq, nullptr, n, p);
 }
 
 int ntk_accum_read(ntk_ctx *c, ntk_result *out)
@@ -432,15 +457,21 @@ int ntk_accum_bind_device(ntk_ctx *c, uint64_t *d_words)
     return NTK_OK;
 }
 
-int ntk_materialize_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p,
-                           uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16)
+int ntk_materialize_device_quality(ntk_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, const ntk_params *p,
+                                   uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16)
 {
     if (!c || !d_valid16 || !d_rc16) return NTK_ERR_BAD_ARG;
     Mode m;
     int rc = resolve_mode(p, true, &m);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
-    return run_scan(c, d_seq, n, p, m, false, d_values, d_valid16, d_rc16);
+    return run_scan(c, d_seq, n, p, m, false, d_values, d_valid16, d_rc16, d_qual);
+}
+
+int ntk_materialize_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p,
+                           uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16)
+{
+    return ntk_materialize_device_quality(c, d_seq, nullptr, n, p, d_values, d_valid16, d_rc16);
 }
 
 /* ---- pinned batches ------------------------------------------------------------------------ */
@@ -464,28 +495,64 @@ int ntk_batch_acquire(ntk_ctx *c, uint64_t max_bytes, uint64_t max_records, ntk_
         return NTK_ERR_HIP;
     }
     b->h_off[0] = 0;
+    b->device = c->device;
     *out = b;
+    return NTK_OK;
+}
+
+static int batch_append_impl(ntk_batch *b, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint32_t pre, uint32_t cutoff)
+{
+    if (!b || (!seq && n) || pre > NTK_PRE_NORMALIZE_IUPAC || b->in_flight) return NTK_ERR_BAD_ARG;
+    if (b->n_records >= b->cap_records || b->n_bytes + n + 1 > b->cap_bytes) return NTK_ERR_CAPACITY;
+    if (qual && !b->h_qual) {
+        // quality stream: same capacity and offsets as the sequence stream; records appended without qualities read
+        // as 0xFF (never below a cutoff)
+        HIPCHK(hipSetDevice(b->device));
+        HIPCHK(hipHostMalloc((void **)&b->h_qual, b->cap_bytes, hipHostMallocDefault));
+        if (hipMalloc((void **)&b->d_qual, b->cap_bytes) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError();
+            (void)hipHostFree(b->h_qual); b->h_qual = nullptr;
+            return NTK_ERR_HIP;
+        }
+        memset(b->h_qual, 0xFF, b->n_bytes);
+    }
+    uint8_t *o = b->h_seq + b->n_bytes;
+    uint8_t *oq = b->h_qual ? b->h_qual + b->n_bytes : nullptr;
+    uint64_t w = 0;
+    // the pre-step's deleted class is dropped here together with its quality byte - unless that quality is below the
+    // cutoff: the reference masks (base, quality) pairs BEFORE normalize deletes anything (src/sequence.rs:285-296), so
+    // such a byte has become an N by then and stays, as a break.  It is kept here and masked on the device.
+    if (pre == NTK_PRE_NONE) {
+        memcpy(o, seq, n); w = n;
+        if (oq) { if (qual) memcpy(oq, qual, n); else memset(oq, 0xFF, n); }
+    } else {
+        const bool ws = pre != NTK_PRE_STRIP_RETURNS;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint8_t ch = seq[i];
+            if ((ch == '\r' || ch == '\n' || (ws && (ch == ' ' || ch == '\t'))) && !(qual && qual[i] < cutoff)) continue;
+            if (oq) oq[w] = qual ? qual[i] : (uint8_t)0xFF;
+            o[w++] = ch;
+        }
+    }
+    if (oq) oq[w] = 0xFF;
+    o[w++] = '\n';
+    b->n_bytes += w;
+    b->n_records += 1;
+    b->h_off[b->n_records] = b->n_bytes;
+    if (qual) { b->has_qual = true; b->qual_cutoff = cutoff; }
     return NTK_OK;
 }
 
 int ntk_batch_append(ntk_batch *b, const uint8_t *seq, uint64_t n, uint32_t pre)
 {
-    if (!b || (!seq && n) || pre > NTK_PRE_NORMALIZE_IUPAC || b->in_flight) return NTK_ERR_BAD_ARG;
-    if (b->n_records >= b->cap_records || b->n_bytes + n + 1 > b->cap_bytes) return NTK_ERR_CAPACITY;
-    uint8_t *o = b->h_seq + b->n_bytes;
-    uint64_t w = 0;
-    if (pre == NTK_PRE_NONE) {
-        memcpy(o, seq, n); w = n;
-    } else if (pre == NTK_PRE_STRIP_RETURNS) {
-        for (uint64_t i = 0; i < n; i++) { const uint8_t ch = seq[i]; if (ch != '\r' && ch != '\n') o[w++] = ch; }
-    } else {
-        for (uint64_t i = 0; i < n; i++) { const uint8_t ch = seq[i]; if (ch != '\r' && ch != '\n' && ch != ' ' && ch != '\t') o[w++] = ch; }
-    }
-    o[w++] = '\n';
-    b->n_bytes += w;
-    b->n_records += 1;
-    b->h_off[b->n_records] = b->n_bytes;
-    return NTK_OK;
+    return batch_append_impl(b, seq, nullptr, n, pre, 0);
+}
+
+int ntk_batch_append_quality(ntk_batch *b, const uint8_t *seq, const uint8_t *qual, uint64_t n, uint32_t pre, uint32_t cutoff)
+{
+    if ((!qual && n) || cutoff < 1 || cutoff > 255) return NTK_ERR_BAD_ARG;
+    if (b && b->has_qual && b->qual_cutoff != cutoff) return NTK_ERR_BAD_ARG;  // one cutoff per fill
+    return batch_append_impl(b, seq, qual ? qual : (const uint8_t *)"", n, pre, cutoff);
 }
 
 int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t *n_bytes, uint64_t *n_records)
@@ -509,10 +576,18 @@ int ntk_batch_submit(ntk_ctx *c, ntk_batch *b, const ntk_params *p)
         const uint64_t padded = (b->n_bytes + 15) & ~(uint64_t)15;
         for (uint64_t i = b->n_bytes; i < padded; i++) b->h_seq[i] = '\n';
         HIPCHK(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, c->copy_stream));
+        // the quality stream travels only when a cutoff is set and some record of this fill carries qualities
+        const uint8_t *d_qual = nullptr;
+        if (b->has_qual && quality_cutoff(p) != b->qual_cutoff) return NTK_ERR_BAD_ARG;
+        if (quality_cutoff(p) && b->has_qual) {
+            for (uint64_t i = b->n_bytes; i < padded; i++) b->h_qual[i] = 0xFF;
+            HIPCHK(hipMemcpyAsync(b->d_qual, b->h_qual, padded, hipMemcpyHostToDevice, c->copy_stream));
+            d_qual = b->d_qual;
+        }
         HIPCHK(hipEventRecord(b->ev_copied, c->copy_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, b->ev_copied, 0));
-        rc = (p->flags & 0xFFu) ? ntk_minimizers_reduce_device(c, b->d_seq, b->n_bytes, p, p->flags & 0xFFu)
-                               : run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr);
+        rc = (p->flags & 0xFFu) ? minimizers_reduce_impl(c, b->d_seq, d_qual, b->n_bytes, p, p->flags & 0xFFu)
+                               : run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr, d_qual);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(b->ev_done, c->stream));
@@ -524,7 +599,7 @@ int ntk_batch_wait(ntk_ctx *c, ntk_batch *b)
 {
     if (!c || !b) return NTK_ERR_BAD_ARG;
     if (b->in_flight) { HIPCHK(hipEventSynchronize(b->ev_done)); b->in_flight = false; }
-    b->n_bytes = 0; b->n_records = 0; b->h_off[0] = 0;
+    b->n_bytes = 0; b->n_records = 0; b->h_off[0] = 0; b->has_qual = false;
     return NTK_OK;
 }
 
@@ -536,6 +611,8 @@ void ntk_batch_release(ntk_ctx *c, ntk_batch *b)
     if (b->h_seq) (void)hipHostFree(b->h_seq);
     if (b->h_off) (void)hipHostFree(b->h_off);
     if (b->d_seq) (void)hipFree(b->d_seq);
+    if (b->h_qual) (void)hipHostFree(b->h_qual);
+    if (b->d_qual) (void)hipFree(b->d_qual);
     if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
     if (b->ev_done) (void)hipEventDestroy(b->ev_done);
     delete b;
@@ -694,7 +771,14 @@ int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int ca
 
 /* ---- minimizers, quality mask --------------------------------------------------------------------------------- */
 
+static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, const ntk_params *p, uint32_t w);
+
 int ntk_minimizers_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, uint32_t w)
+{
+    return minimizers_reduce_impl(c, d_seq, nullptr, n, p, w);
+}
+
+static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, const ntk_params *p, uint32_t w)
 {
     if (!c || w < 1 || w > 256) return NTK_ERR_BAD_ARG;
     Mode m;
@@ -709,7 +793,7 @@ int ntk_minimizers_reduce_device(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, c
     if ((rc = ensure_scratch(c, 5, nt / 8 + 16))) return rc;
     uint64_t *d_val = (uint64_t *)c->scratch[3].p;
     uint16_t *d_v16 = (uint16_t *)c->scratch[4].p, *d_r16 = (uint16_t *)c->scratch[5].p;
-    if ((rc = run_scan(c, d_seq, n, p, m, false, d_val, d_v16, d_r16))) return rc;
+    if ((rc = run_scan(c, d_seq, n, p, m, false, d_val, d_v16, d_r16, d_qual))) return rc;
     const int blocks = c->n_cu * 4;
     if ((rc = ensure_partials(c, blocks))) return rc;
     ScanArgs a; memset(&a, 0, sizeof(a)); scan_args_set_k(a, p->k);

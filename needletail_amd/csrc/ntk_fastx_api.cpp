@@ -87,6 +87,15 @@ int ntk_reader_position(ntk_reader *h, uint64_t *line, uint64_t *byte, int *endi
 void ntk_reader_close(ntk_reader *h) { delete h; }
 
 namespace {
+// FASTQ records carry their quality line into the batch when the parameters hold a quality cutoff (bits 15:8 of flags)
+inline int append_record(ntk_batch *b, const ntk_record &rec, const ntk_params *p)
+{
+    const uint32_t cutoff = (p->flags >> 8) & 0xFFu;
+    if (cutoff && rec.qual && rec.qual_len == rec.seq_len)
+        return ntk_batch_append_quality(b, rec.seq, rec.qual, rec.seq_len, p->pre, cutoff);
+    return ntk_batch_append(b, rec.seq, rec.seq_len, p->pre);
+}
+
 // A record longer than a whole batch (a chromosome-sized contig against a small batch_bytes): scanned through a one-off
 // batch sized for it, so that the batch size is a tuning knob and never a limit on the input.  The accumulators are sums, so
 // the order relative to the batches still in flight does not matter.
@@ -95,7 +104,7 @@ int scan_oversized_record(ntk_ctx *ctx, std::mutex *mu, const ntk_record &rec, c
     ntk_batch *big = nullptr;
     int rc = ntk_batch_acquire(ctx, rec.seq_len + 64, 2, &big);
     if (rc != NTK_OK) return rc;
-    rc = ntk_batch_append(big, rec.seq, rec.seq_len, p->pre);
+    rc = append_record(big, rec, p);
     if (rc == NTK_OK) {
         if (mu) { std::lock_guard<std::mutex> g(*mu); rc = ntk_batch_submit(ctx, big, p); }
         else rc = ntk_batch_submit(ctx, big, p);
@@ -122,12 +131,12 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *h, const ntk_params *p, uint64_t b
         const int s = ntk_reader_next(h, &rec);
         if (s == NTK_EOF) break;
         if (s != NTK_OK) { rc = s; break; }
-        int a = ntk_batch_append(batches[cur], rec.seq, rec.seq_len, p->pre);
+        int a = append_record(batches[cur], rec, p);
         if (a == NTK_ERR_CAPACITY) {
             if ((rc = ntk_batch_submit(ctx, batches[cur], p)) != NTK_OK) break;  // async: H2D copy + scan
             cur = (cur + 1) % n_batches;
             if ((rc = ntk_batch_wait(ctx, batches[cur])) != NTK_OK) break;        // the oldest batch in flight
-            a = ntk_batch_append(batches[cur], rec.seq, rec.seq_len, p->pre);
+            a = append_record(batches[cur], rec, p);
             if (a == NTK_ERR_CAPACITY) a = scan_oversized_record(ctx, nullptr, rec, p);  // longer than an empty batch
         }
         if (a != NTK_OK) { rc = a; break; }
@@ -195,7 +204,7 @@ void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
         const int s = ntk_reader_next(rd, &rec);
         if (s == NTK_EOF) break;
         if (s != NTK_OK) { rc = s; break; }
-        int a = ntk_batch_append(b[cur], rec.seq, rec.seq_len, sh->p->pre);
+        int a = append_record(b[cur], rec, sh->p);
         if (a == NTK_ERR_CAPACITY) {
             {
                 std::lock_guard<std::mutex> g(sh->mu);
@@ -204,7 +213,7 @@ void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
             if (rc != NTK_OK) break;
             cur ^= 1;
             if ((rc = ntk_batch_wait(sh->ctx, b[cur])) != NTK_OK) break;  // event wait only: no ctx state touched
-            a = ntk_batch_append(b[cur], rec.seq, rec.seq_len, sh->p->pre);
+            a = append_record(b[cur], rec, sh->p);
             if (a == NTK_ERR_CAPACITY) a = scan_oversized_record(sh->ctx, &sh->mu, rec, sh->p);
         }
         if (a != NTK_OK) { rc = a; break; }

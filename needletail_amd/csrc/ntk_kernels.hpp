@@ -188,7 +188,7 @@ struct DevMasks {
 // bytes each) with the next tile's load in flight while the current one is processed; no byte is fetched from HBM
 // twice (the 32 halo bytes of a tile come back from L2).
 // ---------------------------------------------------------------------------------------------
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0, bool SV = false>
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0, bool SV = false, bool QM = false>
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
     static_assert(!SV || (REDUCE && KW == 2 && KFIX >= 17), "the scalar-validity path is a k-specialised reduce path");
@@ -253,23 +253,39 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+        // QM builds: the quality bytes travel as a second stream with the same geometry (out of range -> quality 0 on
+        // bytes that are breaks already), prefetched one tile ahead like the sequence stream.
+        __amdgpu_buffer_rsrc_t rq = rs;
+        if constexpr (QM) {
+            const uint64_t qbase = (uint64_t)a.qual + run_byte - halo;
+            const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase);  // u32 temporaries: the builtin returns int
+            const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
+            rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qhi << 32) | qlo), 0, nrec, 0x00020000);
+        }
 
         uint32_t voff = lane * 16u - (32u - halo);  // wraps (out of range -> 0) for the halo lanes of tile 0
         uint64_t tile_byte = run_byte;              // wave-uniform: first emitting byte of the current tile
         u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        u32x4 curq = cur;
+        if constexpr (QM) curq = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
         for (uint32_t r = r0; r < r1; r++) {
-            u32x4 nxt = cur;
-            if (r + 1 < r1) nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);  // wave-uniform
+            u32x4 nxt = cur, nxtq = curq;
+            if (r + 1 < r1) {  // wave-uniform
+                nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);
+                if constexpr (QM) nxtq = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + kTileStride, 0, 0);
+            }
             const bool tail = r >= a.tail_tile_rel;  // this tile reaches the end of the input
+            Raw16 raw{cur.x, cur.y, cur.z, cur.w};
+            if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
             if constexpr (SV) {
-                const EncSV en = encode16_sv<ACCEPT_U>(Raw16{cur.x, cur.y, cur.z, cur.w});
+                const EncSV en = encode16_sv<ACCEPT_U>(raw);
                 mp.template compute<KFIX>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
                 lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
             } else {
-                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, Raw16{cur.x, cur.y, cur.z, cur.w},
+                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, raw,
                                                              (int64_t)tile_byte - 32 + lane * 16, halo_lane, tail);
             }
-            cur = nxt; voff += kTileStride; tile_byte += kTileStride;
+            cur = nxt; curq = nxtq; voff += kTileStride; tile_byte += kTileStride;
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }

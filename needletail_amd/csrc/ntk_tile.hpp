@@ -39,6 +39,9 @@ struct ScanArgs {
     uint64_t *values;
     uint16_t *valid16;
     uint16_t *rc16;
+    // quality masking (QM builds): one quality byte per sequence byte, same alignment and padding rules as seq
+    const uint8_t *qual;
+    uint32_t q_add, q_sel;  // quality_cut(cutoff)
 };
 
 // Fills the k-derived fields (host side).  k must be 1..32.
@@ -137,6 +140,35 @@ NTK_HD uint32_t win32(const uint32_t (&W)[N], int off)
 // and the lane's word of the reverse-complement stream.  Pure SWAR, no LUT in memory.
 // ---------------------------------------------------------------------------------------------
 struct Raw16 { uint32_t x, y, z, w; };  // little-endian dwords: byte 0 of x is base 0
+
+// ---------------------------------------------------------------------------------------------
+// Quality masking fused into the load.  Reference QualitySequence::quality_mask, src/sequence.rs:285-296:
+// `if q < score { b'N' } else { s }` per (base, quality) pair, ahead of normalize / the k-mer iterators.  On every path
+// a masked base only has to stop being a base, so instead of writing 'N' the top bit of its byte is set: no good base
+// (acgtuACGTU) and no deleted byte has it, normalize maps such a byte to N and the 2-bit LUT misses it.  Exact for all
+// 256 quality values and cutoffs 1..255: q >= c  <=>  (c <= 128) ? (q >= 128 || q7 >= c) : (q >= 128 && q7 >= c - 128)
+// with q7 = q & 127; `q7 + add` puts "q7 >= c mod 128" into the byte's top bit and cannot carry into the next byte
+// (add <= 127).  4 full-rate VALU ops per dword (4 bases).
+// ---------------------------------------------------------------------------------------------
+struct QualityCut { uint32_t add, sel; };
+inline QualityCut quality_cut(uint32_t cutoff)  // 1..255
+{
+    QualityCut c;
+    c.add = ((cutoff <= 128 ? 128u - cutoff : 256u - cutoff) & 0x7Fu) * 0x01010101u;
+    c.sel = cutoff <= 128 ? 0xFFFFFFFFu : 0u;
+    return c;
+}
+NTK_HD uint32_t quality_break(uint32_t s, uint32_t q, uint32_t add, uint32_t sel)
+{
+    const uint32_t u = (q & 0x7F7F7F7Fu) + add;
+    const uint32_t ge = bitop3<0xE8>(u, q, sel);      // majority: sel ? u | q : u & q  -> top bit of a byte = (q >= cutoff)
+    return bitop3<0xF2>(s, ge, 0x80808080u);          // s | (~ge & 0x80808080)
+}
+NTK_HD Raw16 quality_break16(Raw16 s, Raw16 q, uint32_t add, uint32_t sel)
+{
+    return Raw16{quality_break(s.x, q.x, add, sel), quality_break(s.y, q.y, add, sel),
+                 quality_break(s.z, q.z, add, sel), quality_break(s.w, q.w, add, sel)};
+}
 struct Enc {
     uint32_t code;   // 2-bit codes, MSB-first
     uint32_t rcode;  // group g (bits 2g+1:2g) = complement of base g: the reverse-complement stream word

@@ -70,10 +70,16 @@ class Context:
     def accum_reset(self):
         L.check(L.lib().ntk_accum_reset(self._h), "ntk_accum_reset")
 
-    def reduce_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int, w: int = 0):
-        """w > 0: fold windowed minimizers (w k-mers per window) instead of every k-mer."""
-        p = L.Params(k, path, pre, w)
-        L.check(L.lib().ntk_reduce_device(self._h, C.c_void_p(_ptr(d_seq)), n_bytes, C.byref(p)), "ntk_reduce_device")
+    def reduce_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int, w: int = 0, d_qual=None,
+                      quality_cutoff: int = 0):
+        """w > 0: fold windowed minimizers (w k-mers per window) instead of every k-mer.  d_qual + quality_cutoff: mask
+        bases whose quality byte is below the cutoff first (QualitySequence::quality_mask, reference src/sequence.rs:285-296)."""
+        p = L.Params(k, path, pre, L.flags(w, quality_cutoff))
+        if d_qual is None:
+            L.check(L.lib().ntk_reduce_device(self._h, C.c_void_p(_ptr(d_seq)), n_bytes, C.byref(p)), "ntk_reduce_device")
+        else:
+            L.check(L.lib().ntk_reduce_device_quality(self._h, C.c_void_p(_ptr(d_seq)), C.c_void_p(_ptr(d_qual)), n_bytes,
+                                                      C.byref(p)), "ntk_reduce_device_quality")
 
     def accum_read(self) -> dict:
         r = L.Result()
@@ -91,11 +97,13 @@ class Context:
                 "ntk_accum_bind_device")
 
     # -- materialise mode --------------------------------------------------------------------------
-    def materialize_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int, d_values, d_valid16, d_rc16):
-        p = L.Params(k, path, pre, 0)
+    def materialize_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int, d_values, d_valid16, d_rc16,
+                           d_qual=None, quality_cutoff: int = 0):
+        p = L.Params(k, path, pre, L.flags(0, quality_cutoff))
         dv = C.c_void_p(_ptr(d_values)) if d_values is not None else None
-        L.check(L.lib().ntk_materialize_device(self._h, C.c_void_p(_ptr(d_seq)), n_bytes, C.byref(p), dv,
-                                               C.c_void_p(_ptr(d_valid16)), C.c_void_p(_ptr(d_rc16))),
+        dq = C.c_void_p(_ptr(d_qual)) if d_qual is not None else None
+        L.check(L.lib().ntk_materialize_device_quality(self._h, C.c_void_p(_ptr(d_seq)), dq, n_bytes, C.byref(p), dv,
+                                                       C.c_void_p(_ptr(d_valid16)), C.c_void_p(_ptr(d_rc16))),
                 "ntk_materialize_device")
 
     def minimizers_reduce_device(self, d_seq, n_bytes: int, k: int, w: int, path: int, pre: int):
@@ -127,9 +135,15 @@ class Batch:
         self._h = C.c_void_p()
         L.check(L.lib().ntk_batch_acquire(ctx._h, max_bytes, max_records, C.byref(self._h)), "ntk_batch_acquire")
 
-    def append(self, seq: bytes, pre: int) -> bool:
-        """False when the batch is full (submit it and use another)."""
-        rc = L.lib().ntk_batch_append(self._h, seq, len(seq), pre)
+    def append(self, seq: bytes, pre: int, qual: bytes = None, quality_cutoff: int = 0) -> bool:
+        """False when the batch is full (submit it and use another).  qual + quality_cutoff: carry the record's quality
+        line for masking at that cutoff (submit with the same cutoff)."""
+        if qual is not None and quality_cutoff:
+            if len(qual) != len(seq):
+                raise ValueError("sequence and quality lengths differ")
+            rc = L.lib().ntk_batch_append_quality(self._h, seq, qual, len(seq), pre, quality_cutoff)
+        else:
+            rc = L.lib().ntk_batch_append(self._h, seq, len(seq), pre)
         if rc == 5:  # NTK_ERR_CAPACITY
             return False
         L.check(rc, "ntk_batch_append")
@@ -143,8 +157,8 @@ class Batch:
         o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(int(nr.value) + 1,))
         return s, o
 
-    def submit(self, k: int, path: int, pre: int, w: int = 0):
-        p = L.Params(k, path, pre, w)
+    def submit(self, k: int, path: int, pre: int, w: int = 0, quality_cutoff: int = 0):
+        p = L.Params(k, path, pre, L.flags(w, quality_cutoff))
         L.check(L.lib().ntk_batch_submit(self.ctx._h, self._h, C.byref(p)), "ntk_batch_submit")
 
     def wait(self):

@@ -147,14 +147,14 @@ def parse_fastx_string(content) -> FastxReader:
 
 
 def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int = 0, batch_bytes: int = 16 << 20, w: int = 0,
-                       data: bytes = None) -> dict:
+                       data: bytes = None, quality_cutoff: int = 0) -> dict:
     """scan_file with one parser thread per file range (plain FASTA/FASTQ only; gzip streams are sequential -> scan_file).
     `data` scans an in-memory buffer instead of a path."""
     import os
     from .engine import result_to_dict  # noqa: F401
     threads = threads or min(os.cpu_count() or 1, 16)  # measured best 8-16 on a 256-thread host (tools/pipeline_bench.py)
     ctx.accum_reset()
-    p = L.Params(k, path_kind, pre, w)
+    p = L.Params(k, path_kind, pre, L.flags(w, quality_cutoff))
     nrec, nb = C.c_uint64(0), C.c_uint64(0)
     if data is not None:
         rc = L.lib().ntk_scan_buffer_parallel(ctx._h, data, len(data), C.byref(p), batch_bytes, threads, C.byref(nrec), C.byref(nb))
@@ -166,14 +166,16 @@ def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int
     return out
 
 
-def scan_file(ctx, path, k: int, path_kind: int, pre: int, batch_bytes: int = 64 << 20, n_batches: int = 3, w: int = 0) -> dict:
+def scan_file(ctx, path, k: int, path_kind: int, pre: int, batch_bytes: int = 64 << 20, n_batches: int = 3, w: int = 0,
+              quality_cutoff: int = 0) -> dict:
     """The README program on the GPU: parse -> pinned batches -> overlapped H2D + scan; returns the reduced result plus
-    n_records / n_bases (reference src/lib.rs:15-35)."""
+    n_records / n_bases (reference src/lib.rs:15-35).  quality_cutoff > 0 masks FASTQ bases below that raw quality byte
+    first (QualitySequence::quality_mask, reference src/sequence.rs:285-296)."""
     from .engine import result_to_dict
     rd = FastxReader(path=path)
     try:
         ctx.accum_reset()
-        p = L.Params(k, path_kind, pre, w)
+        p = L.Params(k, path_kind, pre, L.flags(w, quality_cutoff))
         nrec, nb = C.c_uint64(0), C.c_uint64(0)
         rc = L.lib().ntk_scan_reader(ctx._h, rd._h, C.byref(p), batch_bytes, n_batches, C.byref(nrec), C.byref(nb))
         if rc == 8:

@@ -64,6 +64,17 @@ Raw16 load16(const uint8_t *buf, uint64_t n_padded, int64_t off)
     return r;
 }
 
+// QM builds of the kernel: the quality tile is loaded with the same geometry and folded into the sequence bytes
+// (ntk_tile.hpp quality_break16) before anything else looks at them.
+const uint8_t *g_qual = nullptr;
+QualityCut g_qc = {0, 0};
+Raw16 load16q(const uint8_t *buf, uint64_t n_padded, int64_t off)
+{
+    Raw16 r = load16(buf, n_padded, off);
+    if (g_qual) r = quality_break16(r, load16(g_qual, n_padded, off), g_qc.add, g_qc.sel);
+    return r;
+}
+
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX = 0>
 void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st, uint64_t *values,
          uint16_t *valid16, uint16_t *rc16)
@@ -79,7 +90,7 @@ void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStat
             for (int l = 0; l < 64; l++) {
                 xl.next_lane(l == 0);
                 const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
-                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sinks[l], xl, load16(buf, n_padded, lane_base), lane_base,
+                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sinks[l], xl, load16q(buf, n_padded, lane_base), lane_base,
                                                        l < kHaloLanes, tail);
             }
         }
@@ -107,7 +118,7 @@ void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostS
         uint64_t G[16] = {0};
         for (int l = 0; l < 64; l++) {
             const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
-            en[l] = encode16_sv<ACCEPT_U>(load16(buf, n_padded, lane_base));
+            en[l] = encode16_sv<ACCEPT_U>(load16q(buf, n_padded, lane_base));
             for (int i = 0; i < 16; i++) {
                 bool good = !sv_base_is_break(en[l], i);
                 if (tail && lane_base + i >= (int64_t)n) good = false;
@@ -169,6 +180,18 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     memcpy(out + 4, st->hist, sizeof(st->hist));
     delete st;
     return 0;
+}
+
+// The same with the quality stream of the QM builds: bases whose quality byte is below `cutoff` (1..255) are masked.
+int emu_scan_quality(const uint8_t *buf, const uint8_t *qual, uint32_t cutoff, uint64_t n, uint64_t n_padded, uint32_t k, int canon,
+                     int tie_rc, int accept_u, uint32_t tiles_per_wave, uint64_t *out, uint64_t *values, uint16_t *valid16,
+                     uint16_t *rc16)
+{
+    if (cutoff < 1 || cutoff > 255 || !qual) return -1;
+    g_qual = qual; g_qc = quality_cut(cutoff);
+    const int rc = emu_scan(buf, n, n_padded, k, canon, tie_rc, accept_u, tiles_per_wave, out, values, valid16, rc16);
+    g_qual = nullptr;
+    return rc;
 }
 
 void emu_encode16(const uint8_t *raw16, int accept_u, uint32_t *out3)

@@ -557,3 +557,134 @@ def test_specimen_corpus_through_the_pipeline(ctx):
             assert_stats_equal(st, O.reduce_records(recs, k, p, pre), f"{os.path.basename(path)} k={k}")
             n_kmers += st["n_total"]
     assert n_kmers > 10_000
+
+
+# ---- quality masking fused into the scan (reference src/sequence.rs:285-296) -----------------------
+
+def _qual_dev(qual: bytes):
+    n = len(qual)
+    t = torch.zeros(((n + 1023) // 1024 * 1024 + 1024,), dtype=torch.uint8, device="cuda")  # quality 0 in the padding
+    if n:
+        t[:n] = torch.frombuffer(bytearray(qual), dtype=torch.uint8).cuda()
+    return t
+
+
+@pytest.mark.parametrize("k", [1, 4, 11, 16, 17, 21, 27, 31, 32])
+def test_quality_masked_reduce_device(ctx, k):
+    """`(seq, qual).quality_mask(cutoff)` then the chain, in one pass: against the oracle's quality_mask followed by its
+    reduce, for every mode, realistic Phred+33 qualities and arbitrary bytes/cutoffs."""
+    rng = np.random.default_rng(1000 + k)
+    n = 200_000
+    base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)]
+    other = np.frombuffer(b"NnacgtUu-\n", dtype=np.uint8)[rng.integers(0, 10, size=n)]
+    buf = np.where(rng.random(n) < 0.01, other, base).astype(np.uint8).tobytes()
+    for trial, (path, pre, canon, tie_rc, accept_u) in enumerate(MODES):
+        if trial % 2 == 0:
+            qual = rng.integers(33, 75, size=n, dtype=np.uint8).tobytes()
+            cutoff = [36, 53, 74, 34][trial % 4]
+        else:
+            qual = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+            cutoff = [3, 128, 129, 250][(trial + k) % 4]
+        masked = O.quality_mask(buf, qual, cutoff)
+        want = O.reduce_fused(masked, k, canon, tie_rc, accept_u)
+        ctx.accum_reset()
+        ctx.reduce_device(to_dev(buf), n, k, path, pre, d_qual=_qual_dev(qual), quality_cutoff=cutoff)
+        assert_stats_equal(ctx.accum_read(), want, f"quality k={k} mode={trial} cutoff={cutoff}")
+    # cutoff 0 and "no quality stream" are the plain scan
+    want = O.reduce_fused(buf, k, True, True, True)
+    ctx.accum_reset()
+    ctx.reduce_device(to_dev(buf), n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, d_qual=_qual_dev(qual), quality_cutoff=0)
+    assert_stats_equal(ctx.accum_read(), want, "cutoff 0")
+
+
+def test_quality_masked_materialize_and_minimizers(ctx):
+    rng = np.random.default_rng(4242)
+    n, k, w, cutoff = 50_000, 21, 11, 40
+    buf = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes()
+    qual = rng.integers(33, 75, size=n, dtype=np.uint8).tobytes()
+    masked = O.quality_mask(buf, qual, cutoff)
+    # minimizers over the masked reads
+    want = O.minimizers_reduce(masked, k, w, True, True)
+    ctx.accum_reset()
+    ctx.reduce_device(to_dev(buf), n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w, d_qual=_qual_dev(qual), quality_cutoff=cutoff)
+    assert_stats_equal(ctx.accum_read(), want, "minimizers + quality")
+    # materialise: identical planes to materialising the masked buffer without a quality stream
+    nt16 = (n + 15) // 16 * 16
+    outs = []
+    for b, q, c in ((buf, _qual_dev(qual), cutoff), (masked, None, 0)):
+        vals = torch.zeros(nt16 + 1024, dtype=torch.int64, device="cuda")
+        v16 = torch.zeros(nt16 // 16 + 64, dtype=torch.int16, device="cuda")
+        r16 = torch.zeros(nt16 // 16 + 64, dtype=torch.int16, device="cuda")
+        ctx.materialize_device(to_dev(b), n, k, nt.PATH_BITS_CANONICAL, nt.PRE_NONE, vals, v16, r16, d_qual=q, quality_cutoff=c)
+        torch.cuda.synchronize()
+        valid = v16[: nt16 // 16].cpu().numpy().view(np.uint16)
+        bits = np.unpackbits(valid.byteswap().view(np.uint8))[:n].astype(bool)
+        outs.append((valid.copy(), r16[: nt16 // 16].cpu().numpy().copy(), vals[:n].cpu().numpy()[bits]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert outs[0][2].size > 1000
+
+
+def test_quality_masked_pipeline(ctx, golden_dir, tmp_path):
+    """FASTQ file -> parser -> pinned batches carrying the quality lines -> masked scan, against the literal per-record chain
+    quality_mask -> normalize -> canonical_kmers on the reference's own FASTQ sample; sequential and parallel producers."""
+    fq = os.path.join(golden_dir, "PRJNA271013_head.fq")
+    recs = [(r.raw_seq, r.qual.encode()) for r in nt.parse_fastx_file(fq)]
+    assert len(recs) > 100
+    for cutoff in (35, 53, 64):
+        masked = [O.quality_mask(s, q, cutoff) for s, q in recs]
+        want = O.reduce_records(masked, 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE)
+        plain = O.reduce_records([s for s, _ in recs], 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE)
+        st = nt.scan_file(ctx, fq, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 16, quality_cutoff=cutoff)
+        assert_stats_equal(st, want, f"pipeline cutoff {cutoff}")
+        assert st["n_total"] < plain["n_total"] or cutoff == 35
+        stp = nt.scan_file_parallel(ctx, fq, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=4, batch_bytes=1 << 16,
+                                    quality_cutoff=cutoff)
+        assert_stats_equal(stp, want, f"parallel pipeline cutoff {cutoff}")
+    # a FASTA file has no qualities: a cutoff changes nothing
+    fa = os.path.join(golden_dir, "28S.fasta")
+    a = nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    b = nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, quality_cutoff=60)
+    assert_stats_equal(a, b, "fasta + cutoff")
+    # whitespace inside a sequence line with a low quality is an N by the time normalize runs (it is not deleted)
+    odd = tmp_path / "odd.fq"
+    odd.write_bytes(b"@r\nACGTAC GTACGTACGTACGTAC\tGTACGT\n+\nIIIIII!IIIIIIIIIIIIIIIIIIIIIII\n")
+    seq, qual = b"ACGTAC GTACGTACGTACGTAC\tGTACGT", b"IIIIII!IIIIIIIIIIIIIIIIIIIIIII"
+    for cutoff in (34, 80):
+        want = O.reduce_records([O.quality_mask(seq, qual, cutoff)], 5, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE)
+        st = nt.scan_file(ctx, str(odd), 5, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, quality_cutoff=cutoff)
+        assert_stats_equal(st, want, f"whitespace + quality, cutoff {cutoff}")
+    # a batch filled for one cutoff cannot be submitted with another
+    b = ctx.batch(1 << 16, 16)
+    assert b.append(b"ACGTACGTACGT", nt.PRE_NORMALIZE, qual=b"IIIIIIIIIIII", quality_cutoff=40)
+    with pytest.raises(nt.NtkError):
+        b.submit(4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, quality_cutoff=41)
+    b.release()
+
+
+def test_quality_stream_at_any_address(ctx):
+    """Both streams at device addresses whose low 32 bits have the top bit set / clear (a sign-extended buffer descriptor
+    base would fault or read elsewhere), several chunks of tiles long."""
+    rng = np.random.default_rng(99)
+    n, k, cutoff = 3_000_000, 21, 36
+    buf = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes()
+    qual = rng.integers(33, 75, size=n, dtype=np.uint8).tobytes()
+    want = O.reduce_fused(O.quality_mask(buf, qual, cutoff), k, True, True, True)
+    big = torch.zeros(5 << 30, dtype=torch.uint8, device="cuda")   # spans at least one 4 GiB boundary
+    base = big.data_ptr()
+    hb, hq = torch.frombuffer(bytearray(buf), dtype=torch.uint8), torch.frombuffer(bytearray(qual), dtype=torch.uint8)
+    seen = set()
+    for want_bit in (1, 0):
+        off = 0
+        while ((base + off) >> 31) & 1 != want_bit:
+            off += 1 << 30
+        s_off, q_off = off + 4096, off + 4096 + ((n + 4096 + 15) // 16 * 16)
+        assert q_off + n + 2048 < big.numel() and (base + s_off) % 16 == 0 and (base + q_off) % 16 == 0
+        seen.add(((base + q_off) >> 31) & 1)
+        big[s_off: s_off + n] = hb.cuda()
+        big[q_off: q_off + n] = hq.cuda()
+        ctx.accum_reset()
+        ctx.reduce_device(big[s_off:], n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, d_qual=big[q_off:], quality_cutoff=cutoff)
+        assert_stats_equal(ctx.accum_read(), want, f"address bit31={want_bit}")
+    assert seen == {0, 1}
+    del big
+    torch.cuda.empty_cache()

@@ -151,3 +151,52 @@ def test_emu_matches_oracle_property(data, k, mode, variant):
     want = O.reduce_fused(data, k, bool(canon), bool(tie_rc), bool(accept_u))
     got = emu_scan(L, data, k, canon, tie_rc, accept_u, variant)
     assert_stats_equal(got, want, (k, mode, variant, len(data)))
+
+
+# ---- quality masking fused into the load (reference src/sequence.rs:285-296) --------------------
+
+def emu_scan_quality(L, buf: bytes, qual: bytes, cutoff, k, canon, tie_rc, accept_u, tpw=3):
+    n = len(buf)
+    assert len(qual) == n
+    npad = (n + 15) // 16 * 16
+    arr = np.frombuffer(buf + b"\xAA" * (npad - n), dtype=np.uint8).copy()
+    qarr = np.frombuffer(qual + b"\x00" * (npad - n), dtype=np.uint8).copy()
+    out = np.zeros(4 + 4096, dtype=np.uint64)
+    L.emu_scan_quality.restype = C.c_int
+    L.emu_scan_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.emu_scan_quality(arr.ctypes.data, qarr.ctypes.data, cutoff, n, npad, k, int(canon), int(tie_rc), int(accept_u),
+                            tpw, out.ctypes.data, None, None, None)
+    assert rc == 0
+    return {"n_total": int(out[0]), "n_fwd": int(out[1]), "n_rc": int(out[0] - out[1]), "sum": int(out[2]),
+            "xor": int(out[3]), "hist": out[4:].copy()}
+
+
+def test_quality_compare_is_exact_for_every_byte_and_cutoff(emu):
+    """The SWAR `q < cutoff` of ntk_tile.hpp quality_break against the plain comparison, all 256 quality bytes x all 255
+    cutoffs, observed through the scan: one valid 1-mer per unmasked base."""
+    seq = b"ACGT" * 64                       # 256 bases, one per quality value
+    qual = bytes(range(256))
+    for cutoff in range(1, 256):
+        got = emu_scan_quality(emu, seq, qual, cutoff, 1, 0, 0, 0)
+        assert got["n_total"] == 256 - cutoff, cutoff
+        masked = O.quality_mask(seq, qual, cutoff)
+        assert masked == b"".join(b"N" if q < cutoff else bytes([s]) for s, q in zip(seq, qual))
+        assert_stats_equal(got, O.reduce_fused(masked, 1, False, False, False), cutoff)
+
+
+def test_emu_quality_scan_matches_masked_oracle(emu):
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        n = int(rng.integers(0, 3000))
+        buf = bytes(rng.choice(list(_ALPHABET), size=n).astype(np.uint8))
+        qual = bytes(rng.integers(33, 75, size=n, dtype=np.uint8)) if trial % 3 else bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+        cutoff = int(rng.integers(1, 256)) if trial % 3 == 0 else int(rng.integers(34, 75))
+        k = int(rng.integers(1, 33))
+        canon, tie_rc, accept_u = [(1, 1, 1), (1, 0, 0), (0, 0, 0), (1, 0, 1)][trial % 4]
+        # the reference masks (base, quality) pairs first, then runs the chain (src/sequence.rs:285-296)
+        masked = O.quality_mask(buf, qual, cutoff)
+        want = O.reduce_fused(masked, k, bool(canon), bool(tie_rc), bool(accept_u))
+        for tpw in (0, 3):
+            got = emu_scan_quality(emu, buf, qual, cutoff, k, canon, tie_rc, accept_u, tpw)
+            assert_stats_equal(got, want, (trial, k, cutoff, tpw))
