@@ -6,7 +6,9 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "ntk_kernels.hpp"
@@ -98,6 +100,7 @@ struct ntk_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
+    std::map<std::pair<const void *, int>, int> occupancy;  // resident blocks per CU of a scan build at a block size
 };
 
 struct ntk_batch {
@@ -162,52 +165,44 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
     return NTK_OK;
 }
 
+// The scan kernel build for a mode: k-specialised builds where they exist, the runtime-k build otherwise.
+// Reduce mode: every 17 <= k <= 32 runs the scalar-validity variant (k is a template constant there: the window-mask
+// algebra indexes lane masks by k), -10..15 % against the generic runtime-k build; with a quality stream only k = 21 and
+// 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
+// build (-5 %; for larger k the generic build is as fast).
 template <bool REDUCE, bool QM>
-hipError_t launch_scan(const Mode &m, const ScanArgs &a, dim3 grid, dim3 block, hipStream_t st)
+const void *pick_scan(const Mode &m, uint32_t k)
 {
-    const size_t lds = REDUCE ? 0 : (size_t)(block.x / 64) * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
-    // k-specialised builds.  Reduce mode: every 17 <= k <= 32 runs the scalar-validity variant (k is a template constant
-    // there: the window-mask algebra indexes lane masks by k), -10..15 % against the generic runtime-k build.
-    // Materialise mode: only k = 21 has a specialised (per-lane) build (-5 %; for larger k the generic build is as fast).
-#define NTK_LAUNCH_SV(KF, T, U)                                                                 \
-    if (REDUCE && !QM && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) { \
-        hipLaunchKernelGGL((scan_kernel<2, true, T, U, true, KF, true>), grid, block, lds, st, a); \
-        return hipGetLastError();                                                               \
-    }
-#define NTK_LAUNCH_SV4(KF) NTK_LAUNCH_SV(KF, false, false) NTK_LAUNCH_SV(KF, false, true) NTK_LAUNCH_SV(KF, true, false) NTK_LAUNCH_SV(KF, true, true)
-    NTK_LAUNCH_SV4(17) NTK_LAUNCH_SV4(18) NTK_LAUNCH_SV4(19) NTK_LAUNCH_SV4(20) NTK_LAUNCH_SV4(21) NTK_LAUNCH_SV4(22) NTK_LAUNCH_SV4(23) NTK_LAUNCH_SV4(24)
-    NTK_LAUNCH_SV4(25) NTK_LAUNCH_SV4(26) NTK_LAUNCH_SV4(27) NTK_LAUNCH_SV4(28) NTK_LAUNCH_SV4(29) NTK_LAUNCH_SV4(30) NTK_LAUNCH_SV4(31) NTK_LAUNCH_SV4(32)
-#undef NTK_LAUNCH_SV4
-#undef NTK_LAUNCH_SV
-    // quality-masking builds of the scalar-validity variant: the two k the reference's own programs use (21, 31)
-#define NTK_LAUNCH_SVQ(KF, T, U)                                                                \
-    if (REDUCE && QM && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) { \
-        hipLaunchKernelGGL((scan_kernel<2, true, T, U, true, KF, true, true>), grid, block, lds, st, a); \
-        return hipGetLastError();                                                               \
-    }
-    NTK_LAUNCH_SVQ(21, false, false) NTK_LAUNCH_SVQ(21, false, true) NTK_LAUNCH_SVQ(21, true, false) NTK_LAUNCH_SVQ(21, true, true)
-    NTK_LAUNCH_SVQ(31, false, false) NTK_LAUNCH_SVQ(31, false, true) NTK_LAUNCH_SVQ(31, true, false) NTK_LAUNCH_SVQ(31, true, true)
-#undef NTK_LAUNCH_SVQ
-#define NTK_LAUNCH_FIX(KF, T, U)                                                                \
-    if (!REDUCE && !QM && m.kw == 2 && m.canon && a.k == KF && m.tie_rc == T && m.accept_u == U) { \
-        hipLaunchKernelGGL((scan_kernel<2, true, T, U, false, KF, false>), grid, block, lds, st, a); \
-        return hipGetLastError();                                                               \
-    }
-    NTK_LAUNCH_FIX(21, false, false) NTK_LAUNCH_FIX(21, false, true) NTK_LAUNCH_FIX(21, true, false) NTK_LAUNCH_FIX(21, true, true)
-#undef NTK_LAUNCH_FIX
-#define NTK_LAUNCH(KW, C, T, U)                                                                 \
-    if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U) {                       \
-        hipLaunchKernelGGL((scan_kernel<KW, C, T, U, REDUCE, 0, false, QM>), grid, block, lds, st, a); \
-        return hipGetLastError();                                                               \
-    }
-    NTK_LAUNCH(1, false, false, false) NTK_LAUNCH(1, false, false, true)
-    NTK_LAUNCH(1, true, false, false) NTK_LAUNCH(1, true, false, true)
-    NTK_LAUNCH(1, true, true, false) NTK_LAUNCH(1, true, true, true)
-    NTK_LAUNCH(2, false, false, false) NTK_LAUNCH(2, false, false, true)
-    NTK_LAUNCH(2, true, false, false) NTK_LAUNCH(2, true, false, true)
-    NTK_LAUNCH(2, true, true, false) NTK_LAUNCH(2, true, true, true)
-#undef NTK_LAUNCH
-    return hipErrorInvalidValue;
+#define NTK_PICK_SV(KF, T, U)                                                                       \
+    if (REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \
+        return (const void *)&scan_kernel<2, true, T, U, true, KF, true>;
+#define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
+    NTK_PICK_SV4(17) NTK_PICK_SV4(18) NTK_PICK_SV4(19) NTK_PICK_SV4(20) NTK_PICK_SV4(21) NTK_PICK_SV4(22) NTK_PICK_SV4(23) NTK_PICK_SV4(24)
+    NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
+#undef NTK_PICK_SV4
+#undef NTK_PICK_SV
+#define NTK_PICK_SVQ(KF, T, U)                                                                      \
+    if (REDUCE && QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)        \
+        return (const void *)&scan_kernel<2, true, T, U, true, KF, true, true>;
+    NTK_PICK_SVQ(21, false, false) NTK_PICK_SVQ(21, false, true) NTK_PICK_SVQ(21, true, false) NTK_PICK_SVQ(21, true, true)
+    NTK_PICK_SVQ(31, false, false) NTK_PICK_SVQ(31, false, true) NTK_PICK_SVQ(31, true, false) NTK_PICK_SVQ(31, true, true)
+#undef NTK_PICK_SVQ
+#define NTK_PICK_FIX(KF, T, U)                                                                      \
+    if (!REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)      \
+        return (const void *)&scan_kernel<2, true, T, U, false, KF, false>;
+    NTK_PICK_FIX(21, false, false) NTK_PICK_FIX(21, false, true) NTK_PICK_FIX(21, true, false) NTK_PICK_FIX(21, true, true)
+#undef NTK_PICK_FIX
+#define NTK_PICK(KW, C, T, U)                                                                       \
+    if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U)                             \
+        return (const void *)&scan_kernel<KW, C, T, U, REDUCE, 0, false, QM>;
+    NTK_PICK(1, false, false, false) NTK_PICK(1, false, false, true)
+    NTK_PICK(1, true, false, false) NTK_PICK(1, true, false, true)
+    NTK_PICK(1, true, true, false) NTK_PICK(1, true, true, true)
+    NTK_PICK(2, false, false, false) NTK_PICK(2, false, false, true)
+    NTK_PICK(2, true, false, false) NTK_PICK(2, true, false, true)
+    NTK_PICK(2, true, true, false) NTK_PICK(2, true, true, true)
+#undef NTK_PICK
+    return nullptr;
 }
 
 int get_event(ntk_ctx *c, hipEvent_t *e)
@@ -228,8 +223,24 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
     const int threads = reduce ? c->launch_threads : 256;
     const int waves_per_block = threads / 64;
-    // auto: 32 waves per CU (the kernel needs <= 64 VGPRs), e.g. 2 x 1024-thread blocks - measured best (profiles/r01_launch_sweep_first.jsonl)
-    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : (reduce ? c->n_cu * 2 * (1024 / threads) : c->n_cu * 4);
+    const void *fn = cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
+                            : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));
+    if (!fn) return NTK_ERR_BAD_ARG;
+    const size_t lds = reduce ? 0 : (size_t)waves_per_block * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
+    // auto grid: exactly the blocks that are resident at once (work is pulled, so a second round of blocks would only
+    // zero and write out empty histograms: measured +1.5 % at config 2).  Reduce builds: 2 x 1024 threads per CU at
+    // <= 64 VGPRs, 1 x 1024 for the 66-VGPR scalar-validity builds; materialise: 4 x 256 (LDS staging).
+    int per_cu = 0;
+    auto it = c->occupancy.find(std::make_pair(fn, threads));
+    if (it != c->occupancy.end()) per_cu = it->second;
+    else {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds));
+        if (per_cu < 1) per_cu = 1;
+        const int cap = reduce ? 2 * (1024 / threads) : 4;
+        if (per_cu > cap) per_cu = cap;
+        c->occupancy[std::make_pair(fn, threads)] = per_cu;
+    }
+    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : c->n_cu * per_cu;
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     scan_args_set_k(a, p->k);
@@ -269,10 +280,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
             rc = get_event(c, &e1); if (rc) return rc;
             HIPCHK(hipEventRecord(e0, c->stream));
         }
-        HIPCHK(cutoff ? (reduce ? launch_scan<true, true>(m, a, dim3(blocks), dim3(threads), c->stream)
-                                : launch_scan<false, true>(m, a, dim3(blocks), dim3(threads), c->stream))
-                      : (reduce ? launch_scan<true, false>(m, a, dim3(blocks), dim3(threads), c->stream)
-                                : launch_scan<false, false>(m, a, dim3(blocks), dim3(threads), c->stream)));
+        void *kargs[] = {(void *)&a};
+        HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), kargs, lds, c->stream));
         if (c->timing) {
             HIPCHK(hipEventRecord(e1, c->stream));
             c->ev_used.emplace_back(e0, e1);
