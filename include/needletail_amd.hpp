@@ -1,7 +1,8 @@
 // needletail_amd.hpp — header-only C++ mirror of needletail's public surface for the accelerated path, on top of the
 // C ABI (needletail_amd.h).  Names, argument meaning and results follow the reference so that code written against
 //   needletail::{parse_fastx_file, FastxReader::next, SequenceRecord, Sequence::{normalize, strip_returns,
-//   reverse_complement, canonical_kmers, kmers, bit_kmers}}           (reference src/lib.rs:56-57, src/sequence.rs:156-253)
+//   reverse_complement, canonical_kmers, kmers, bit_kmers}, QualitySequence::quality_mask, minimizer,
+//   bitkmer::{reverse_complement, canonical, minimizer}}              (reference src/lib.rs:56-57, src/sequence.rs:156-303)
 // ports line by line (see examples/stdin_pipe.cpp, the reference's examples/stdin_pipe.rs).  Where the reference
 // panics (k = 0 ...) or returns Err(ParseError), this throws needletail::Error.
 #pragma once
@@ -90,6 +91,46 @@ public:
 private:
     Slice s_; Context *c_;
 };
+
+// QualitySequence (reference src/sequence.rs:273-303) for a (sequence, quality) pair.
+class QualitySequence : public Sequence {
+public:
+    QualitySequence(Slice seq, Slice qual, Context &c = Context::global()) : Sequence(seq, c), q_(qual), cq_(&c) {}
+    Slice quality() const { return q_; }
+    // bases whose quality byte is below `score` become N; zip semantics: the shorter of the two lengths (src/sequence.rs:285-296)
+    Bytes quality_mask(uint8_t score) const {
+        const uint64_t n = sequence().size() < q_.size() ? sequence().size() : q_.size();
+        Bytes out(n, 0);
+        check(ntk_quality_mask(cq_->get(), sequence().data(), q_.data(), n, score, out.data()), "ntk_quality_mask");
+        return out;
+    }
+private:
+    Slice q_; Context *cq_;
+};
+
+// sequence::minimizer (reference src/sequence.rs:139-152) and the bitkmer free functions (reference src/bitkmer.rs:112-162)
+inline Bytes minimizer(Slice seq, size_t length, Context &c = Context::global()) {
+    Bytes out(length, 0);
+    check(ntk_minimizer(c.get(), seq.data(), seq.size(), (uint32_t)length, out.data()), "ntk_minimizer");
+    return out;
+}
+namespace bitkmer {
+inline BitKmer reverse_complement(BitKmer kmer, Context &c = Context::global()) {
+    uint64_t out = 0;
+    check(ntk_bit_canonical(c.get(), &kmer.first, 1, kmer.second, 0, &out, nullptr), "ntk_bit_canonical");
+    return BitKmer{out, kmer.second};
+}
+inline std::pair<BitKmer, bool> canonical(BitKmer kmer, Context &c = Context::global()) {
+    uint64_t out = 0; uint8_t rc = 0;
+    check(ntk_bit_canonical(c.get(), &kmer.first, 1, kmer.second, 1, &out, &rc), "ntk_bit_canonical");
+    return {BitKmer{out, kmer.second}, rc != 0};
+}
+inline BitKmer minimizer(BitKmer kmer, uint8_t minmer_size, Context &c = Context::global()) {
+    uint64_t out = 0;
+    check(ntk_bit_minimizers(c.get(), &kmer.first, 1, kmer.second, minmer_size, &out), "ntk_bit_minimizers");
+    return BitKmer{out, minmer_size};
+}
+}  // namespace bitkmer
 
 // Position / LineEnding (reference src/parser/utils.rs:50-104)
 struct Position { uint64_t line_ = 0, byte_ = 0; uint64_t line() const { return line_; } uint64_t byte() const { return byte_; } };

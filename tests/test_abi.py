@@ -70,13 +70,14 @@ def test_product_never_references_the_oracle():
     assert "ntko_" not in out
 
 
-def _build_example():
-    exe = os.path.join(ROOT, "examples", "stdin_pipe")
-    src = os.path.join(ROOT, "examples", "stdin_pipe.cpp")
+def _build_example(name="stdin_pipe"):
+    exe = os.path.join(ROOT, "examples", name)
+    src = os.path.join(ROOT, "examples", name + ".cpp")
     hdr = os.path.join(ROOT, "include", "needletail_amd.hpp")
     _ensure_built()
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, src, "-L" + os.path.join(ROOT, "needletail_amd"),
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, src,
+                               "-L" + os.path.join(ROOT, "needletail_amd"),
                                "-lneedletail_amd", "-Wl,-rpath,$ORIGIN/../needletail_amd"])
     return exe
 
@@ -85,6 +86,7 @@ def test_cpp_mirror_compiles_and_fails_loudly_without_gpu():
     """include/needletail_amd.hpp (C++ mirror of the reference surface) + examples/stdin_pipe.cpp build with plain g++."""
     import torch
     exe = _build_example()
+    _build_example("mirror_check")
     if torch.cuda.is_available():
         pytest.skip("GPU present: the example is run by the gpu tests")
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "test.fa")], capture_output=True, text=True)
@@ -105,3 +107,18 @@ def test_cpp_example_program_on_gpu():
         f.write(b">id1\nAGTCGTCA\n"); f.flush()
         r = subprocess.run([exe, f.name], capture_output=True, text=True)
     assert "There are 8 bases in your file." in r.stdout and "There are 0 AAAAs in your file." in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_quality_and_minimizers_on_gpu():
+    """QualitySequence::quality_mask, minimizer and the bitkmer free functions of the C++ mirror against the reference's
+    unit-test literals (src/sequence.rs:363-374) and the oracle."""
+    import oracle as O
+    exe = _build_example("mirror_check")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split()
+    assert lines[0] == "AGCN" and lines[1] == "AAA"
+    cv, crc = O.bit_canonical(0xE4, 4)
+    assert (int(lines[2]), int(lines[3])) == (cv, int(crc))
+    assert int(lines[4]) == O.bit_minimizer(0x1B, 4, 2)
