@@ -803,7 +803,7 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     uint64_t *d_val = (uint64_t *)c->scratch[3].p;
     uint16_t *d_v16 = (uint16_t *)c->scratch[4].p, *d_r16 = (uint16_t *)c->scratch[5].p;
     if ((rc = run_scan(c, d_seq, n, p, m, false, d_val, d_v16, d_r16, d_qual))) return rc;
-    const int blocks = c->n_cu * 4;
+    const int blocks = c->n_cu * 4;  // ~35 KiB of LDS per block
     if ((rc = ensure_partials(c, blocks))) return rc;
     ScanArgs a; memset(&a, 0, sizeof(a)); scan_args_set_k(a, p->k);
     hipLaunchKernelGGL(window_min_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)d_val,

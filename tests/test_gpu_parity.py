@@ -334,6 +334,30 @@ def test_windowed_minimizers_reduce(ctx, k, w):
     assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, k, w, False, False), (k, w, "bits"))
 
 
+@pytest.mark.parametrize("w", [1, 2, 15, 16, 17, 31, 32, 33, 64, 100, 255, 256])
+def test_windowed_minimizers_any_window_and_tile_boundaries(ctx, w):
+    """Window sizes around the 16- and 32-bit word edges of the LDS flag words and up to the API's maximum, over long
+    unbroken contigs (windows crossing the 2048-position tiles of the window-min kernel), low-complexity stretches (ties:
+    the leftmost minimum decides the flag) and lengths around the tile size."""
+    rng = np.random.default_rng(500 + w)
+    parts = []
+    for L in (2047, 2048, 2049, 5000, w + 20, 12_345):
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)].copy()
+        seq[L // 3: L // 3 + min(L // 4, 400)] = ord("A") if L % 2 else ord("T")     # homopolymer run: ties everywhere
+        per = np.frombuffer(b"ACGTTGCA", dtype=np.uint8)
+        m = min(L // 5, 300)
+        seq[L // 2: L // 2 + m] = np.resize(per, m)                                   # short period: repeated k-mers
+        parts.append(seq.tobytes())
+    buf = b"\n".join(parts) + b"\n"
+    t = to_dev(buf)
+    for k, (path, accept_u, tie_rc) in ((21, (nt.PATH_BYTES_CANONICAL, True, True)), (8, (nt.PATH_BITS_CANONICAL, False, False))):
+        ctx.accum_reset()
+        ctx.minimizers_reduce_device(t, len(buf), k, w, path, nt.PRE_NORMALIZE if accept_u else nt.PRE_NONE)
+        got = ctx.accum_read()
+        assert_stats_equal(got, O.minimizers_reduce(buf, k, w, accept_u, tie_rc), (k, w))
+        assert got["n_total"] > 0
+
+
 # ---- materialise mode ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("k,path", [(5, nt.PATH_BITS), (16, nt.PATH_BITS_CANONICAL), (21, nt.PATH_BITS_CANONICAL), (32, nt.PATH_BITS_CANONICAL)])
