@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -101,6 +102,12 @@ struct ntk_ctx {
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
     std::map<std::pair<const void *, int>, int> occupancy;  // resident blocks per CU of a scan build at a block size
+    // released batches are kept for re-use: pinned + device allocations cost milliseconds each, a parser thread's two
+    // batches more than its share of a multi-GB input (tools/pipeline_bench.py).  Guarded: producer threads acquire and
+    // release concurrently.
+    std::mutex pool_mu;
+    std::vector<ntk_batch *> pool;
+    uint64_t pool_bytes = 0;
 };
 
 struct ntk_batch {
@@ -295,6 +302,18 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     return NTK_OK;
 }
 
+void destroy_batch(ntk_batch *b)
+{
+    if (b->h_seq) (void)hipHostFree(b->h_seq);
+    if (b->h_off) (void)hipHostFree(b->h_off);
+    if (b->d_seq) (void)hipFree(b->d_seq);
+    if (b->h_qual) (void)hipHostFree(b->h_qual);
+    if (b->d_qual) (void)hipFree(b->d_qual);
+    if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
+    if (b->ev_done) (void)hipEventDestroy(b->ev_done);
+    delete b;
+}
+
 int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
 {
     if (!out) return NTK_ERR_BAD_ARG;
@@ -364,6 +383,8 @@ void ntk_ctx_destroy(ntk_ctx *c)
     (void)hipStreamSynchronize(c->copy_stream);
     for (auto &p : c->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    for (auto b : c->pool) destroy_batch(b);
+    c->pool.clear();
     for (auto &s : c->scratch) if (s.p) (void)hipFree(s.p);
     if (c->d_part_hist) (void)hipFree(c->d_part_hist);
     if (c->d_part_scalars) (void)hipFree(c->d_part_scalars);
@@ -490,17 +511,30 @@ int ntk_batch_acquire(ntk_ctx *c, uint64_t max_bytes, uint64_t max_records, ntk_
     if (!c || !out || max_bytes == 0) return NTK_ERR_BAD_ARG;
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
+    const uint64_t want_bytes = (max_bytes + 1023) & ~(uint64_t)1023, want_records = max_records ? max_records : 1;
+    {   // a pooled batch that is large enough, and not more than twice as large as asked for
+        std::lock_guard<std::mutex> g(c->pool_mu);
+        for (size_t i = 0; i < c->pool.size(); i++) {
+            ntk_batch *p = c->pool[i];
+            if (p->cap_bytes >= want_bytes && p->cap_bytes <= 2 * want_bytes && p->cap_records >= want_records) {
+                c->pool[i] = c->pool.back(); c->pool.pop_back();
+                c->pool_bytes -= p->cap_bytes;
+                *out = p;
+                return NTK_OK;
+            }
+        }
+    }
     ntk_batch *b = new (std::nothrow) ntk_batch();
     if (!b) return NTK_ERR_NOMEM;
-    b->cap_bytes = (max_bytes + 1023) & ~(uint64_t)1023;
-    b->cap_records = max_records ? max_records : 1;
+    b->cap_bytes = want_bytes;
+    b->cap_records = want_records;
     if (hipHostMalloc((void **)&b->h_seq, b->cap_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&b->h_off, (b->cap_records + 1) * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&b->d_seq, b->cap_bytes) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
         g_last_hip = (int)hipGetLastError();
-        ntk_batch_release(c, b);
+        destroy_batch(b);
         return NTK_ERR_HIP;
     }
     b->h_off[0] = 0;
@@ -617,14 +651,17 @@ void ntk_batch_release(ntk_ctx *c, ntk_batch *b)
     if (!b) return;
     if (c) (void)hipSetDevice(c->device);
     if (b->in_flight && b->ev_done) (void)hipEventSynchronize(b->ev_done);
-    if (b->h_seq) (void)hipHostFree(b->h_seq);
-    if (b->h_off) (void)hipHostFree(b->h_off);
-    if (b->d_seq) (void)hipFree(b->d_seq);
-    if (b->h_qual) (void)hipHostFree(b->h_qual);
-    if (b->d_qual) (void)hipFree(b->d_qual);
-    if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
-    if (b->ev_done) (void)hipEventDestroy(b->ev_done);
-    delete b;
+    b->in_flight = false;
+    if (c && b->h_seq && b->h_off && b->d_seq) {  // keep it for the next acquire (bounded: 256 batches / 8 GiB pinned)
+        std::lock_guard<std::mutex> g(c->pool_mu);
+        if (c->pool.size() < 256 && c->pool_bytes + b->cap_bytes <= ((uint64_t)8 << 30)) {
+            b->n_bytes = 0; b->n_records = 0; b->h_off[0] = 0; b->has_qual = false; b->qual_cutoff = 0;
+            c->pool.push_back(b);
+            c->pool_bytes += b->cap_bytes;
+            return;
+        }
+    }
+    destroy_batch(b);
 }
 
 /* ---- compat face ------------------------------------------------------------------------------ */

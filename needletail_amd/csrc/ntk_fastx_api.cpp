@@ -195,7 +195,7 @@ void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
     int rc = ntk_reader_open_memory(d, n, &rd);
     ntk_batch *b[2] = {nullptr, nullptr};
     const uint64_t max_records = sh->batch_bytes / 32 + 16;
-    // acquire / release touch no ctx state (pinned + device allocations only): not serialised
+    // acquire / release take the ctx's own pool lock; they are not serialised with submit
     for (int i = 0; i < 2 && rc == NTK_OK; i++) rc = ntk_batch_acquire(sh->ctx, sh->batch_bytes, max_records, &b[i]);
     uint64_t nrec = 0, nbases = 0;
     int cur = 0;

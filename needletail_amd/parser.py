@@ -152,7 +152,7 @@ def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int
     `data` scans an in-memory buffer instead of a path."""
     import os
     from .engine import result_to_dict  # noqa: F401
-    threads = threads or min(os.cpu_count() or 1, 16)  # measured best 8-16 on a 256-thread host (tools/pipeline_bench.py)
+    threads = threads or min(os.cpu_count() or 1, 32)  # measured best 16-32 on a 256-thread host (tools/pipeline_bench.py)
     ctx.accum_reset()
     p = L.Params(k, path_kind, pre, L.flags(w, quality_cutoff))
     nrec, nb = C.c_uint64(0), C.c_uint64(0)

@@ -60,7 +60,7 @@ for bb, nbat in ((8 << 20, 3), (64 << 20, 3)):
         best = dt if best is None else min(best, dt)
     out[f"pipeline_batch{bb >> 20}MiB"] = {"seconds": round(best, 4), "Gbases_s": round(reads * RL / best / 1e9, 3),
                                            "fastq_GB_s": round(len(text) / best / 1e9, 3)}
-for th in (8, 32, 128):
+for th in (8, 16, 32, 48, 64, 128):
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
