@@ -565,16 +565,39 @@ static int batch_append_impl(ntk_batch *b, const uint8_t *seq, const uint8_t *qu
     // the pre-step's deleted class is dropped here together with its quality byte - unless that quality is below the
     // cutoff: the reference masks (base, quality) pairs BEFORE normalize deletes anything (src/sequence.rs:285-296), so
     // such a byte has become an N by then and stays, as a break.  It is kept here and masked on the device.
+    // Line by line (memchr for LF): a line without any other byte of the deleted class - the usual case, checked by a
+    // branch-free reduction the compiler vectorises - is one memcpy; wrapped FASTA contigs cost a memchr + memcpy per line.
+    const bool ws = pre != NTK_PRE_STRIP_RETURNS;
     if (pre == NTK_PRE_NONE) {
         memcpy(o, seq, n); w = n;
         if (oq) { if (qual) memcpy(oq, qual, n); else memset(oq, 0xFF, n); }
     } else {
-        const bool ws = pre != NTK_PRE_STRIP_RETURNS;
-        for (uint64_t i = 0; i < n; i++) {
-            const uint8_t ch = seq[i];
-            if ((ch == '\r' || ch == '\n' || (ws && (ch == ' ' || ch == '\t'))) && !(qual && qual[i] < cutoff)) continue;
-            if (oq) oq[w] = qual ? qual[i] : (uint8_t)0xFF;
-            o[w++] = ch;
+        uint64_t i = 0;
+        while (i < n) {
+            const uint8_t *nl = (const uint8_t *)memchr(seq + i, '\n', n - i);
+            const uint64_t end = nl ? (uint64_t)(nl - seq) : n;   // line = [i, end), then the LF (if any)
+            unsigned any = 0;
+            for (uint64_t j = i; j < end; j++) {
+                const uint8_t ch = seq[j];
+                any |= (unsigned)(ch == '\r') | ((unsigned)ws & ((unsigned)(ch == ' ') | (unsigned)(ch == '\t')));
+            }
+            if (!any) {
+                memcpy(o + w, seq + i, end - i);
+                if (oq) { if (qual) memcpy(oq + w, qual + i, end - i); else memset(oq + w, 0xFF, end - i); }
+                w += end - i;
+            } else {
+                for (uint64_t j = i; j < end; j++) {
+                    const uint8_t ch = seq[j];
+                    if ((ch == '\r' || (ws && (ch == ' ' || ch == '\t'))) && !(qual && qual[j] < cutoff)) continue;
+                    if (oq) oq[w] = qual ? qual[j] : (uint8_t)0xFF;
+                    o[w++] = ch;
+                }
+            }
+            if (nl && qual && qual[end] < cutoff) {   // a low-quality LF has become an N: it stays (see above)
+                if (oq) oq[w] = qual[end];
+                o[w++] = '\n';
+            }
+            i = end + 1;
         }
     }
     if (oq) oq[w] = 0xFF;

@@ -712,3 +712,31 @@ def test_quality_stream_at_any_address(ctx):
     assert seen == {0, 1}
     del big
     torch.cuda.empty_cache()
+
+
+def test_batch_packer_against_a_model(ctx):
+    """ntk_batch_append / ntk_batch_append_quality (the line-wise fast paths and the per-byte path) against a Python model of
+    the packer: every pre-step, records with and without bytes of the deleted class, with and without qualities."""
+    rng = np.random.default_rng(31337)
+    alphabet = np.frombuffer(b"ACGTacgtNn-. \t\r\n*U", dtype=np.uint8)
+    for pre in (nt.PRE_NONE, nt.PRE_STRIP_RETURNS, nt.PRE_NORMALIZE, nt.PRE_NORMALIZE_IUPAC):
+        deleted = {nt.PRE_NONE: b"", nt.PRE_STRIP_RETURNS: b"\r\n"}.get(pre, b" \t\r\n")
+        for cutoff in (0, 40):
+            b = ctx.batch(1 << 20, 4096)
+            want_seq, want_off = bytearray(), [0]
+            for r in range(300):
+                L = int(rng.integers(0, 400))
+                p_ws = [0.0, 0.02, 0.3][r % 3]
+                seq = np.where(rng.random(L) < p_ws, alphabet[rng.integers(12, 16, size=L)], alphabet[rng.integers(0, 12, size=L)]).astype(np.uint8).tobytes()
+                qual = rng.integers(33, 75, size=L, dtype=np.uint8).tobytes() if (cutoff and r % 4) else None
+                assert b.append(seq, pre, qual=qual, quality_cutoff=cutoff)
+                for i, ch in enumerate(seq):
+                    if ch in deleted and not (qual is not None and qual[i] < cutoff):
+                        continue
+                    want_seq.append(ch)
+                want_seq.append(ord("\n"))
+                want_off.append(len(want_seq))
+            got_seq, got_off = b.buffers()
+            assert bytes(got_seq) == bytes(want_seq), (pre, cutoff)
+            assert list(got_off) == want_off
+            b.release()
