@@ -88,7 +88,7 @@ struct ntk_ctx {
     hipStream_t copy_stream = nullptr;  // H2D copies of pinned batches
     bool owns_stream = false;
     int n_cu = 256;
-    int launch_blocks = 0, launch_threads = 1024;
+    int launch_blocks = 0, launch_threads = 512;
     uint64_t *d_acc = nullptr;      // accumulators in use (own or caller-bound)
     uint64_t *d_acc_own = nullptr;
     uint32_t *d_part_hist = nullptr;

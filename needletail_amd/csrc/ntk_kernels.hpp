@@ -127,11 +127,19 @@ struct MaterializeSink {
 // ---------------------------------------------------------------------------------------------
 // "sv" reduce path (k-specialised, 17 <= k <= 32): break flags and window validity in scalar registers (ntk_tile.hpp)
 // ---------------------------------------------------------------------------------------------
+template <int K>
 struct ReduceSinkSV {
     uint64_t sum = 0, xr = 0;
     uint32_t *hist;
     uint32_t bin_shift;
-    __device__ __forceinline__ void add(uint32_t hi, uint32_t lo)
+    // byte offset of the bin, (v >> (2K - 12)) * 4, as one funnel shift (or one plain shift) + one AND: the generic
+    // `v >> bin_shift` is a 64-bit shift and the * 4 a left shift, both half-rate on gfx950 (tools/ubench.hip)
+    __device__ __forceinline__ static uint32_t bin_offset(uint32_t hi, uint32_t lo)
+    {
+        constexpr int n = 2 * K - 14;   // hi < 2^(2K-32), so the shifted value has 14 significant bits
+        return (n >= 32 ? hi >> (n & 31) : alignbit(hi, lo, n & 31)) & 0x3FFCu;
+    }
+    __device__ __forceinline__ void add(uint32_t hi, uint32_t lo, uint32_t off)
     {
         const uint64_t v = ((uint64_t)hi << 32) | lo;
 #ifndef NTK_ABL_NODIGEST
@@ -139,9 +147,10 @@ struct ReduceSinkSV {
         xr ^= v;
 #endif
 #ifndef NTK_ABL_NOHIST
-        atomicAdd(&hist[(uint32_t)(v >> bin_shift)], 1u);
+        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hist) + off), 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-        sum += (uint32_t)(v >> bin_shift);
+        sum += off;
 #endif
     }
 };
@@ -152,7 +161,7 @@ struct ReduceSinkSV {
 
 struct DevMasks {
     uint64_t V[16];  // lane masks: window ending at byte j is emitted
-    uint32_t n_fwd_lane = 0;
+    uint32_t *fwd_cell = nullptr;  // this thread's own LDS cell: forward-strand count
 
     template <int K>
     __device__ __forceinline__ void compute(const EncSV &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
@@ -174,11 +183,22 @@ struct DevMasks {
         window_masks<K>(B, V);
     }
 
-    __device__ __forceinline__ void emit(ReduceSinkSV &sink, int j, bool take_fwd, uint32_t hi, uint32_t lo)
+    template <class S>
+    __device__ __forceinline__ void emit(S &sink, int j, bool take_fwd, uint32_t hi, uint32_t lo)
     {
-        // the forward-strand count stays a per-lane v_addc: a scalar popcount would cost three more SALU instructions
-        // per position and the scalar unit (one per CU) is the co-bottleneck of this variant (tools/kbench.hip A/B)
-        if (__builtin_amdgcn_inverse_ballot_w64(V[j])) { sink.add(hi, lo); n_fwd_lane += take_fwd ? 1u : 0u; }
+        // Everything that does not depend on the window being valid - strand select, histogram offset - is computed under
+        // the full exec mask and pinned there (a VALU instruction costs the same with one active lane as with 64; left to
+        // itself the compiler sinks it into the masked region, which then exceeds the length below which it drops the
+        // s_cbranch_execz: one branch and one basic-block boundary per position).  Only the side effects are masked.
+        uint32_t off = S::bin_offset(hi, lo);
+        asm volatile("" : "+v"(hi), "+v"(lo), "+v"(off));
+        // The forward-strand count costs NO vector ALU work: exec is narrowed once more by the compare mask and a
+        // non-returning ds_add_u32 bumps the thread's own LDS cell (conflict-free, the LDS pipe has headroom).
+        // (two sibling regions, not nested ones: a region without inner control flow and this short loses its execz branch)
+        const uint64_t fwd = __builtin_amdgcn_ballot_w64(take_fwd);  // the compare's own SGPR pair, no VALU work
+        if (__builtin_amdgcn_inverse_ballot_w64(V[j])) sink.add(hi, lo, off);
+        if (__builtin_amdgcn_inverse_ballot_w64(V[j] & fwd))
+            __hip_atomic_fetch_add(fwd_cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -192,9 +212,10 @@ template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX 
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
     static_assert(!SV || (REDUCE && KW == 2 && KFIX >= 17), "the scalar-validity path is a k-specialised reduce path");
-    using Sink = typename std::conditional<SV, ReduceSinkSV, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
+    using Sink = typename std::conditional<SV, ReduceSinkSV<(KFIX >= 17 ? KFIX : 17)>, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
     __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
     __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
+    __shared__ uint32_t s_nfwd[SV ? 1024 : 1];  // sv builds: per-thread forward-strand counters
     extern __shared__ __attribute__((aligned(16))) uint64_t s_stage[];  // materialise mode: kStageWaveU64 u64 per wave (dynamic)
 
 #ifdef NTK_V_CLOCKS
@@ -230,6 +251,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
     DevXL xl;
     DevMasks mp;
+    if constexpr (SV) { s_nfwd[threadIdx.x] = 0; mp.fwd_cell = &s_nfwd[threadIdx.x]; }  // own cell: no barrier needed
     const bool halo_lane = lane < (uint32_t)kHaloLanes;
 
     uint32_t next = 0;
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         if constexpr (SV) {
             // the sv path does not count emitted windows one by one: every emit increments exactly one bin, so the
             // block's n_total is the sum of its histogram, taken while the histogram is copied out
-            nf = mp.n_fwd_lane; nv = 0;
+            nf = s_nfwd[threadIdx.x]; nv = 0;
             __syncthreads();
             for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) { const uint32_t h = s_hist[i]; ph[i] = h; nv += h; }
         } else {

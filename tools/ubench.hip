@@ -126,6 +126,67 @@ BENCH_KERNEL(k_and_or, {
                  "v_and_or_b32 %1, %1, %0, %3\n v_and_or_b32 %3, %3, %2, %5\n v_and_or_b32 %5, %5, %4, %7\n v_and_or_b32 %7, %7, %6, %1\n"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
 
+BENCH_KERNEL(k_xor32, {
+    asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %2, %2, %3\n v_xor_b32 %4, %4, %5\n v_xor_b32 %6, %6, %7\n"
+                 "v_xor_b32 %1, %1, %0\n v_xor_b32 %3, %3, %2\n v_xor_b32 %5, %5, %4\n v_xor_b32 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_min_u32, {
+    asm volatile("v_min_u32 %0, %0, %1\n v_min_u32 %2, %2, %3\n v_min_u32 %4, %4, %5\n v_min_u32 %6, %6, %7\n"
+                 "v_min_u32 %1, %1, %0\n v_min_u32 %3, %3, %2\n v_min_u32 %5, %5, %4\n v_min_u32 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_mul_u24, {
+    asm volatile("v_mul_u32_u24 %0, %0, %1\n v_mul_u32_u24 %2, %2, %3\n v_mul_u32_u24 %4, %4, %5\n v_mul_u32_u24 %6, %6, %7\n"
+                 "v_mul_u32_u24 %1, %1, %0\n v_mul_u32_u24 %3, %3, %2\n v_mul_u32_u24 %5, %5, %4\n v_mul_u32_u24 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_lshlrev, {
+    asm volatile("v_lshlrev_b32 %0, %0, %1\n v_lshlrev_b32 %2, %2, %3\n v_lshlrev_b32 %4, %4, %5\n v_lshlrev_b32 %6, %6, %7\n"
+                 "v_lshlrev_b32 %1, %1, %0\n v_lshlrev_b32 %3, %3, %2\n v_lshlrev_b32 %5, %5, %4\n v_lshlrev_b32 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_sub, {
+    asm volatile("v_sub_u32 %0, %0, %1\n v_sub_u32 %2, %2, %3\n v_sub_u32 %4, %4, %5\n v_sub_u32 %6, %6, %7\n"
+                 "v_sub_u32 %1, %1, %0\n v_sub_u32 %3, %3, %2\n v_sub_u32 %5, %5, %4\n v_sub_u32 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_dot4, {
+    asm volatile("v_dot4_u32_u8 %0, %0, %1, %2\n v_dot4_u32_u8 %2, %2, %3, %4\n v_dot4_u32_u8 %4, %4, %5, %6\n v_dot4_u32_u8 %6, %6, %7, %0\n"
+                 "v_dot4_u32_u8 %1, %1, %0, %3\n v_dot4_u32_u8 %3, %3, %2, %5\n v_dot4_u32_u8 %5, %5, %4, %7\n v_dot4_u32_u8 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_mad_u24, {
+    asm volatile("v_mad_u32_u24 %0, %0, %1, %2\n v_mad_u32_u24 %2, %2, %3, %4\n v_mad_u32_u24 %4, %4, %5, %6\n v_mad_u32_u24 %6, %6, %7, %0\n"
+                 "v_mad_u32_u24 %1, %1, %0, %3\n v_mad_u32_u24 %3, %3, %2, %5\n v_mad_u32_u24 %5, %5, %4, %7\n v_mad_u32_u24 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_add3, {
+    asm volatile("v_add3_u32 %0, %0, %1, %2\n v_add3_u32 %2, %2, %3, %4\n v_add3_u32 %4, %4, %5, %6\n v_add3_u32 %6, %6, %7, %0\n"
+                 "v_add3_u32 %1, %1, %0, %3\n v_add3_u32 %3, %3, %2, %5\n v_add3_u32 %5, %5, %4, %7\n v_add3_u32 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_or3, {
+    asm volatile("v_or3_b32 %0, %0, %1, %2\n v_or3_b32 %2, %2, %3, %4\n v_or3_b32 %4, %4, %5, %6\n v_or3_b32 %6, %6, %7, %0\n"
+                 "v_or3_b32 %1, %1, %0, %3\n v_or3_b32 %3, %3, %2, %5\n v_or3_b32 %5, %5, %4, %7\n v_or3_b32 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_xad, {
+    asm volatile("v_xad_u32 %0, %0, %1, %2\n v_xad_u32 %2, %2, %3, %4\n v_xad_u32 %4, %4, %5, %6\n v_xad_u32 %6, %6, %7, %0\n"
+                 "v_xad_u32 %1, %1, %0, %3\n v_xad_u32 %3, %3, %2, %5\n v_xad_u32 %5, %5, %4, %7\n v_xad_u32 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_pk_add_u16, {
+    asm volatile("v_pk_add_u16 %0, %0, %1\n v_pk_add_u16 %2, %2, %3\n v_pk_add_u16 %4, %4, %5\n v_pk_add_u16 %6, %6, %7\n"
+                 "v_pk_add_u16 %1, %1, %0\n v_pk_add_u16 %3, %3, %2\n v_pk_add_u16 %5, %5, %4\n v_pk_add_u16 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_pk_min_u16, {
+    asm volatile("v_pk_min_u16 %0, %0, %1\n v_pk_min_u16 %2, %2, %3\n v_pk_min_u16 %4, %4, %5\n v_pk_min_u16 %6, %6, %7\n"
+                 "v_pk_min_u16 %1, %1, %0\n v_pk_min_u16 %3, %3, %2\n v_pk_min_u16 %5, %5, %4\n v_pk_min_u16 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_sad_u8, {
+    asm volatile("v_sad_u8 %0, %0, %1, %2\n v_sad_u8 %2, %2, %3, %4\n v_sad_u8 %4, %4, %5, %6\n v_sad_u8 %6, %6, %7, %0\n"
+                 "v_sad_u8 %1, %1, %0, %3\n v_sad_u8 %3, %3, %2, %5\n v_sad_u8 %5, %5, %4, %7\n v_sad_u8 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_msad, {
+    asm volatile("v_msad_u8 %0, %0, %1, %2\n v_msad_u8 %2, %2, %3, %4\n v_msad_u8 %4, %4, %5, %6\n v_msad_u8 %6, %6, %7, %0\n"
+                 "v_msad_u8 %1, %1, %0, %3\n v_msad_u8 %3, %3, %2, %5\n v_msad_u8 %5, %5, %4, %7\n v_msad_u8 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_cvt_pk_u8, {
+    asm volatile("v_lerp_u8 %0, %0, %1, %2\n v_lerp_u8 %2, %2, %3, %4\n v_lerp_u8 %4, %4, %5, %6\n v_lerp_u8 %6, %6, %7, %0\n"
+                 "v_lerp_u8 %1, %1, %0, %3\n v_lerp_u8 %3, %3, %2, %5\n v_lerp_u8 %5, %5, %4, %7\n v_lerp_u8 %7, %7, %6, %1\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+
 __global__ __launch_bounds__(256) void k_ldsadd(uint32_t *out, uint32_t seed)
 {
     __shared__ uint32_t h[4096];
@@ -167,7 +228,7 @@ int main()
                 {"cmp32+cndmask pair", k_cmp_cndmask}, {"v_add_co_u32", k_addco}, {"addco+saveexec+add+restore (per 4)", k_saveexec},
                 {"v_mad_u64_u32", k_mulu64u32}, {"v_cmp_ne_u32_sdwa (byte sel)", k_cmp_sdwa}, {"SALU only (or/lshl/bcnt/add b64)", k_salu_or64},
                 {"VALU add + SALU 1:1", k_mixed_valu_salu}, {"VALU add + SALU 1:3", k_mixed_valu_2salu}, {"v_lshl_or_b32", k_lshl_or}, {"v_bfe_u32", k_bfe},
-                {"v_cndmask_b32", k_cndmask}, {"v_lshrrev_b32", k_lshr32}, {"v_and_or_b32", k_and_or}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
+                {"v_cndmask_b32", k_cndmask}, {"v_lshrrev_b32", k_lshr32}, {"v_and_or_b32", k_and_or}, {"v_xor_b32", k_xor32}, {"v_min_u32", k_min_u32}, {"v_mul_u32_u24", k_mul_u24}, {"v_lshlrev_b32", k_lshlrev}, {"v_sub_u32", k_sub}, {"v_dot4_u32_u8", k_dot4}, {"v_mad_u32_u24", k_mad_u24}, {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_xad_u32", k_xad}, {"v_pk_add_u16", k_pk_add_u16}, {"v_pk_min_u16", k_pk_min_u16}, {"v_sad_u8", k_sad_u8}, {"v_msad_u8", k_msad}, {"v_lerp_u8", k_cvt_pk_u8}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     for (auto &b : list) {
