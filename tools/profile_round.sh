@@ -14,8 +14,8 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- $BENCH --steps 5 --warmup 1 --no-verify > /dev/null 2> $O/pmc_sq2.err
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
-if [ -x tools/kb_cur ]; then   # tools/build_kbench.sh; grid = resident blocks (1 x 1024 threads per CU)
-  ( cd tools; for v in cur nohist nodigest; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 256 1024 10 $v 16; done ) > $O/ablation.txt 2>&1
+if [ -x tools/kb_cur ]; then   # tools/build_kbench.sh; grid = resident blocks (3 x 512 threads per CU)
+  ( cd tools; for v in cur nohist nodigest; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 768 512 10 $v 16; done ) > $O/ablation.txt 2>&1
   ( cd tools; ./ubench ) > $O/ubench.txt 2>&1
 fi
 python tools/quality_bench.py --cutoff 34 > $O/quality_bench.json 2> $O/quality.err
