@@ -235,8 +235,9 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     if (!fn) return NTK_ERR_BAD_ARG;
     const size_t lds = reduce ? 0 : (size_t)waves_per_block * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
     // auto grid: exactly the blocks that are resident at once (work is pulled, so a second round of blocks would only
-    // zero and write out empty histograms: measured +1.5 % at config 2).  Reduce builds: 2 x 1024 threads per CU at
-    // <= 64 VGPRs, 1 x 1024 for the 66-VGPR scalar-validity builds; materialise: 4 x 256 (LDS staging).
+    // zero and write out empty histograms: measured +1.5 % at config 2).  Reduce builds, 512-thread blocks (default): 4 per
+    // CU at <= 64 VGPRs, 3 for the 66-VGPR scalar-validity builds (6 waves per SIMD: -5 % against one 1024-thread block);
+    // materialise: 4 x 256 (LDS staging).
     int per_cu = 0;
     auto it = c->occupancy.find(std::make_pair(fn, threads));
     if (it != c->occupancy.end()) per_cu = it->second;
