@@ -93,6 +93,7 @@ struct ntk_ctx {
     uint64_t *d_acc_own = nullptr;
     uint32_t *d_part_hist = nullptr;
     uint32_t *d_work = nullptr;     // 8 work counters, one per 64-B line
+    bool work_dirty = true;         // not known to be zero
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
@@ -276,7 +277,10 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         a.tiles_per_shard = (uint32_t)((tiles + a.n_shards - 1) / a.n_shards);
         a.chunk_tiles = (uint32_t)chunk;
         a.work_counters = c->d_work;
-        HIPCHK(hipMemsetAsync(c->d_work, 0, 8 * 64, c->stream));
+        // the work counters are zero on entry: the fold kernel of the previous reduce scan re-armed them; anything else
+        // (first use, a materialise scan, an error on the way) leaves work_dirty set and costs a memset here
+        if (c->work_dirty) HIPCHK(hipMemsetAsync(c->d_work, 0, 8 * 64, c->stream));
+        c->work_dirty = true;
         if (reduce) {
             int rc = ensure_partials(c, blocks);
             if (rc) return rc;
@@ -296,8 +300,9 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         }
         if (reduce) {
             hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
-                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
+                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, c->d_work);
             HIPCHK(hipGetLastError());
+            c->work_dirty = false;
         }
     }
     return NTK_OK;

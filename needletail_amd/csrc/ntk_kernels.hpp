@@ -363,7 +363,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 constexpr int kFoldThreads = 256, kFoldBinGroups = kHistBins / kFoldThreads, kFoldRowGroups = 32;
 constexpr int kFoldBlocks = kFoldBinGroups * kFoldRowGroups + 1;
 __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part_hist, const uint64_t *part_scalars, int nblocks,
-                                                            uint64_t *acc)
+                                                            uint64_t *acc, uint32_t *work_counters = nullptr)
 {
     if (blockIdx.x < kFoldBinGroups * kFoldRowGroups) {
         const int bin = (blockIdx.x % kFoldBinGroups) * kFoldThreads + threadIdx.x;
@@ -374,6 +374,8 @@ __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part
         return;
     }
     __shared__ uint64_t s_red[kFoldThreads / 64][4];
+    // the scan that filled these partials is complete: re-arm its 8 work counters for the next scan (saves a memset launch)
+    if (work_counters && threadIdx.x < 8) work_counters[threadIdx.x * 16] = 0;
     uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
     for (int b = threadIdx.x; b < nblocks; b += kFoldThreads) {
         tv += part_scalars[b * 4 + 0]; tf += part_scalars[b * 4 + 1];
