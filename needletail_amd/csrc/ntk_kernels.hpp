@@ -132,13 +132,9 @@ struct ReduceSinkSV {
     uint64_t sum = 0, xr = 0;
     uint32_t *hist;
     uint32_t bin_shift;
-    // byte offset of the bin, (v >> (2K - 12)) * 4, as one funnel shift (or one plain shift) + one AND: the generic
-    // `v >> bin_shift` is a 64-bit shift and the * 4 a left shift, both half-rate on gfx950 (tools/ubench.hip)
-    __device__ __forceinline__ static uint32_t bin_offset(uint32_t hi, uint32_t lo)
-    {
-        constexpr int n = 2 * K - 14;   // hi < 2^(2K-32), so the shifted value has 14 significant bits
-        return (n >= 32 ? hi >> (n & 31) : alignbit(hi, lo, n & 31)) & 0x3FFCu;
-    }
+    // byte offset of the bin from T, the value's top 32 bits: (T >> 20) * 4 as one shift + one AND, both full-rate (the
+    // generic `v >> bin_shift` is a 64-bit shift and the * 4 a left shift, both half-rate on gfx950: tools/ubench.hip)
+    __device__ __forceinline__ static uint32_t bin_offset(uint32_t t) { return (t >> 18) & 0x3FFCu; }
     __device__ __forceinline__ void add(uint32_t hi, uint32_t lo, uint32_t off)
     {
         const uint64_t v = ((uint64_t)hi << 32) | lo;
@@ -183,14 +179,16 @@ struct DevMasks {
         window_masks<K>(B, V);
     }
 
-    template <class S>
-    __device__ __forceinline__ void emit(S &sink, int j, bool take_fwd, uint32_t hi, uint32_t lo)
+    // (t, lo): top and low 32 bits of the chosen value (ntk_tile.hpp lane_tile_sv)
+    template <int K, class S>
+    __device__ __forceinline__ void emit(S &sink, int j, bool take_fwd, uint32_t t, uint32_t lo)
     {
+        uint32_t hi = K == 32 ? t : t >> ((64 - 2 * K) & 31);
         // Everything that does not depend on the window being valid - strand select, histogram offset - is computed under
         // the full exec mask and pinned there (a VALU instruction costs the same with one active lane as with 64; left to
         // itself the compiler sinks it into the masked region, which then exceeds the length below which it drops the
         // s_cbranch_execz: one branch and one basic-block boundary per position).  Only the side effects are masked.
-        uint32_t off = S::bin_offset(hi, lo);
+        uint32_t off = S::bin_offset(t);
         asm volatile("" : "+v"(hi), "+v"(lo), "+v"(off));
         // The forward-strand count costs NO vector ALU work: exec is narrowed once more by the compare mask and a
         // non-returning ds_add_u32 bumps the thread's own LDS cell (conflict-free, the LDS pipe has headroom).

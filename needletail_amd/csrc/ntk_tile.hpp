@@ -403,7 +403,6 @@ template <bool CANON, bool TIE_RC, int KFIX, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv(Sink &sink, XL &xl, MP &mp, const EncSV &en)
 {
     constexpr int D = KFIX - 16, S = 64 - 2 * KFIX;
-    constexpr uint32_t mask_hi = KFIX == 32 ? 0xFFFFFFFFu : ((1u << ((2 * KFIX - 32) & 31)) - 1u);
     const uint32_t c1 = xl.prev(kSlotCode, en.code);
     const uint32_t r1 = xl.prev(kSlotRcode, en.rcode);
     uint32_t Q[3];
@@ -419,15 +418,20 @@ NTK_HD void lane_tile_sv(Sink &sink, XL &xl, MP &mp, const EncSV &en)
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
+        // A value is handled as (T, lo): lo = its low 32 bits, T = its TOP 32 bits (the first 16 bases) - they overlap in
+        // 64-2K bits.  (T:lo) pairs order exactly like the values (T decides unless equal, and then the overlap is equal too),
+        // so the strand compare needs no hi words; T is the lo word of the window ending K-16 bases earlier (already in a
+        // register for most j), the hi word of the CHOSEN value is one shift of the chosen T, and the histogram offset is a
+        // shift + AND of T whatever K is.
         const uint32_t fl = fls[j], rl = rls[j];
-        const uint32_t fh = j >= D ? (S ? fls[j >= D ? j - D : 0] >> S : fls[j >= D ? j - D : 0]) : (win32(W2, 2 + 2 * j) & mask_hi);
-        const uint32_t rh = j + D <= 15 ? (S ? rls[j + D <= 15 ? j + D : 0] >> S : rls[j + D <= 15 ? j + D : 0]) : (win32(Q, 2 * (15 - j)) & mask_hi);
+        const uint32_t ft = j >= D ? fls[j >= D ? j - D : 0] : win32(W2, 34 + 2 * (j - D));
+        const uint32_t rt = j + D <= 15 ? rls[j + D <= 15 ? j + D : 0] : win32(Q, 2 * (15 - j) + S);
         bool take_fwd = true;
         if (CANON) {
-            const uint64_t f = ((uint64_t)fh << 32) | fl, r = ((uint64_t)rh << 32) | rl;
+            const uint64_t f = ((uint64_t)ft << 32) | fl, r = ((uint64_t)rt << 32) | rl;
             take_fwd = TIE_RC ? (f < r) : (f <= r);
         }
-        mp.emit(sink, j, take_fwd, take_fwd ? fh : rh, take_fwd ? fl : rl);
+        mp.template emit<KFIX>(sink, j, take_fwd, take_fwd ? ft : rt, take_fwd ? fl : rl);
     }
 }
 

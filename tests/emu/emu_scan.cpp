@@ -102,8 +102,11 @@ void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStat
 struct EmuMP {
     uint64_t V[16];
     int lane = 0;
-    template <class S>
-    void emit(S &sink, int j, bool take_fwd, uint32_t hi, uint32_t lo) { sink.emit(j, (V[j] >> lane) & 1, take_fwd, hi, lo); }
+    template <int K, class S>
+    void emit(S &sink, int j, bool take_fwd, uint32_t t, uint32_t lo)  // (t, lo): top and low 32 bits of the value
+    {
+        sink.emit(j, (V[j] >> lane) & 1, take_fwd, K == 32 ? t : t >> (64 - 2 * K), lo);
+    }
 };
 
 template <bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX>
