@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--sync-allreduce", action="store_true",
                     help="keep the per-step all-reduce on the scan's critical path instead of overlapping it")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend; gloo + --single-device exercise the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true",
+                    help="test affordance: every rank uses cuda:0 (NOT a measurement: ranks share one GPU)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     args = ap.parse_args()
@@ -103,20 +107,24 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at N = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
 
     stride = args.read_len + 1
     n_bytes = args.reads * stride
     seq = torch.empty(n_bytes + 2048, dtype=torch.uint8, device="cuda")
     acc = torch.zeros(ntl.ACC_WORDS, dtype=torch.int64, device="cuda")
-    ctx = nt.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = nt.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
     ctx.set_launch(args.blocks, args.threads)
     ctx.accum_bind_device(acc)
     first_read, _ = nd.shard_range(args.reads * world, rank, world)
@@ -253,6 +261,8 @@ def main():
                 "parallelism": f"records sharded over {world} GPU(s), one RCCL all-reduce per step" if world > 1
                                else "single GPU",
                 "launch": {"blocks": args.blocks or "auto", "threads": args.threads},
+                **({"test_mode": f"{args.backend} backend, all ranks on cuda:0 - NOT a measurement"}
+                   if (args.single_device or args.backend != "nccl") else {}),
             },
             "result": {"n_total": res["n_total"], "n_fwd": res["n_fwd"], "sum": hex(res["sum"]), "xor": hex(res["xor"])},
             "roofline": {

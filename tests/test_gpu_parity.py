@@ -740,3 +740,15 @@ def test_batch_packer_against_a_model(ctx):
             assert bytes(got_seq) == bytes(want_seq), (pre, cutoff)
             assert list(got_off) == want_off
             b.release()
+
+
+def test_bench_two_ranks_on_one_gpu_match_single_rank():
+    """bench.py's N > 1 path end to end (records sharded by rank, the overlapped all-reduce of the accumulator words, the
+    xor digest rebuilt from its summable form) with two ranks sharing cuda:0 over gloo, against one rank scanning the same
+    2 x reads: identical reduced results.  (RCCL itself needs two GPUs; the driver's scaling run covers that.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, READS="100000")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "n2_on_one_gpu.sh")], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "n2_on_one_gpu ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
