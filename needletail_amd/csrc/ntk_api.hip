@@ -94,6 +94,7 @@ struct ntk_ctx {
     uint32_t *d_part_hist = nullptr;
     uint32_t *d_work = nullptr;     // 8 work counters, one per 64-B line
     bool work_dirty = true;         // not known to be zero
+    uint64_t minimizer_chunk = (uint64_t)256 << 20;  // bytes of input per minimizer pass (NTK_MINIMIZER_CHUNK_BYTES: test hook)
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
@@ -350,6 +351,10 @@ int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
     build_strip_lut(h + 512);
     build_complement_lut(h + 768);
     HIPCHK(hipMemcpyAsync(c->d_lut, h, 4 * 256 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    if (const char *e = getenv("NTK_MINIMIZER_CHUNK_BYTES")) {
+        const uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 4096) c->minimizer_chunk = v & ~(uint64_t)4095;
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = c;
     return NTK_OK;
@@ -862,21 +867,31 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     if (!m.canon) return NTK_ERR_BAD_ARG;
     if (n == 0) return NTK_OK;
     HIPCHK(hipSetDevice(c->device));
-    const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 3, nt * 8))) return rc;
-    if ((rc = ensure_scratch(c, 4, nt / 8 + 16))) return rc;
-    if ((rc = ensure_scratch(c, 5, nt / 8 + 16))) return rc;
-    uint64_t *d_val = (uint64_t *)c->scratch[3].p;
-    uint16_t *d_v16 = (uint16_t *)c->scratch[4].p, *d_r16 = (uint16_t *)c->scratch[5].p;
-    if ((rc = run_scan(c, d_seq, n, p, m, false, d_val, d_v16, d_r16, d_qual))) return rc;
+    // Long inputs are scanned in chunks so that the scratch planes stay bounded (8 B per position: 2 GiB for the default
+    // 256 MiB chunk instead of 80 GB for a 10 GB batch).  A chunk is scanned together with the w+k-2 bytes of left context
+    // before it (start rounded down to the 16-byte alignment of the scan); only windows ENDING inside the chunk are counted.
+    const uint64_t chunk = c->minimizer_chunk;
+    const uint64_t back = (uint64_t)w + p->k - 2;
     const int blocks = c->n_cu * 4;  // ~35 KiB of LDS per block
     if ((rc = ensure_partials(c, blocks))) return rc;
     ScanArgs a; memset(&a, 0, sizeof(a)); scan_args_set_k(a, p->k);
-    hipLaunchKernelGGL(window_min_reduce_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint64_t *)d_val,
-                       (const uint16_t *)d_v16, (const uint16_t *)d_r16, n, w, a.bin_shift, c->d_part_hist, c->d_part_scalars);
-    hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
-                       (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
-    HIPCHK(hipGetLastError());
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk) {
+        const uint64_t c1 = c0 + chunk < n ? c0 + chunk : n;
+        const uint64_t start = c0 > back ? (c0 - back) & ~(uint64_t)15 : 0;
+        const uint64_t n_sub = c1 - start, nt = (n_sub + 15) / 16 * 16;
+        if ((rc = ensure_scratch(c, 3, nt * 8))) return rc;
+        if ((rc = ensure_scratch(c, 4, nt / 8 + 16))) return rc;
+        if ((rc = ensure_scratch(c, 5, nt / 8 + 16))) return rc;
+        uint64_t *d_val = (uint64_t *)c->scratch[3].p;
+        uint16_t *d_v16 = (uint16_t *)c->scratch[4].p, *d_r16 = (uint16_t *)c->scratch[5].p;
+        if ((rc = run_scan(c, d_seq + start, n_sub, p, m, false, d_val, d_v16, d_r16, d_qual ? d_qual + start : nullptr))) return rc;
+        hipLaunchKernelGGL(window_min_reduce_kernel, dim3(blocks), dim3(kWmThreads), 0, c->stream, (const uint64_t *)d_val,
+                           (const uint16_t *)d_v16, (const uint16_t *)d_r16, n_sub, w, a.bin_shift, c->d_part_hist,
+                           c->d_part_scalars, c0 - start);
+        hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
+                           (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
+        HIPCHK(hipGetLastError());
+    }
     return NTK_OK;
 }
 

@@ -545,8 +545,11 @@ __device__ __forceinline__ bool wm_all_set(const uint32_t *bits, uint32_t start,
 
 __global__ __launch_bounds__(kWmThreads) void window_min_reduce_kernel(const uint64_t *values, const uint16_t *valid16, const uint16_t *rc16,
                                                                        uint64_t n, uint32_t w, uint32_t bin_shift,
-                                                                       uint32_t *part_hist, uint64_t *part_scalars)
+                                                                       uint32_t *part_hist, uint64_t *part_scalars,
+                                                                       uint64_t first_end = 0)
 {
+    // first_end: only windows ENDING at or after this position are counted (the host scans long inputs in chunks that
+    // overlap by the w+k-2 bytes of left context)
     __shared__ uint32_t s_hist[kHistBins];
     __shared__ uint64_t s_red[kWmThreads / 64][4];
     __shared__ uint64_t s_val[kWmTile + kWmMaxHalo];
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(kWmThreads) void window_min_reduce_kernel(const uin
     const uint64_t n_tiles = (n + kWmTile - 1) / kWmTile;
     const uint32_t span = kWmTile + halo;
     uint64_t sum = 0, xr = 0, nv = 0, nf = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = blockIdx.x + first_end / kWmTile; tile < n_tiles; tile += gridDim.x) {
         const int64_t region = (int64_t)(tile * kWmTile) - halo;   // first position held in LDS (may be negative)
         __syncthreads();   // the previous tile's readers are done (and the histogram is zeroed)
         for (uint32_t q = threadIdx.x; q < span; q += kWmThreads) {
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(kWmThreads) void window_min_reduce_kernel(const uin
 #pragma unroll 1
         for (uint32_t pos = threadIdx.x; pos < (uint32_t)kWmTile; pos += kWmThreads) {
             if (tile * kWmTile + pos >= n) break;
+            if (tile * kWmTile + pos < first_end) continue;
             const uint32_t first = halo + pos - (w - 1);          // leftmost k-mer of the window, LDS index
             if (!wm_all_set(s_vbits, first, w)) continue;
             uint64_t best = s_val[first];

@@ -752,3 +752,21 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank():
     r = subprocess.run(["bash", os.path.join(root, "tools", "n2_on_one_gpu.sh")], cwd=root, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "n2_on_one_gpu ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_minimizers_in_chunks(monkeypatch):
+    """Long inputs are scanned in chunks with w+k-2 bytes of left context (bounded scratch); with a 4 KiB chunk every
+    boundary case shows up in a small buffer: records and windows straddling chunk edges, all window sizes."""
+    monkeypatch.setenv("NTK_MINIMIZER_CHUNK_BYTES", "4096")
+    rng = np.random.default_rng(2718)
+    parts = []
+    for L in rng.integers(1, 3000, size=60):
+        parts.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(L))].tobytes())
+    buf = b"\n".join(parts) + b"\n"
+    with nt.Context(0, stream=torch.cuda.current_stream().cuda_stream) as c:
+        t = to_dev(buf)
+        for k, w in ((21, 11), (31, 2), (17, 16), (5, 64), (12, 256), (32, 1)):
+            for path, accept_u, tie_rc in ((nt.PATH_BYTES_CANONICAL, True, True), (nt.PATH_BITS_CANONICAL, False, False)):
+                c.accum_reset()
+                c.minimizers_reduce_device(t, len(buf), k, w, path, nt.PRE_NORMALIZE if accept_u else nt.PRE_NONE)
+                assert_stats_equal(c.accum_read(), O.minimizers_reduce(buf, k, w, accept_u, tie_rc), (k, w, "chunked"))
