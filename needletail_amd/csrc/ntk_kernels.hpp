@@ -19,30 +19,13 @@ namespace ntk {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Cross-lane "value the previous lane holds": DPP wave_shr:1 (lane 0 reads 0), a single VALU move that the
-// compiler folds into the consuming VOP2 where it can (v_and_b32_dpp).  gfx9-family DPP, available on gfx950.
+// Cross-lane "value the previous lane holds": DPP wave_shr:1 (lane 0 reads 0), a single VALU move.
 constexpr int kDppWaveShr1 = 0x138;
 struct DevXL {
-#ifdef NTK_V_ANDDPP
-    // (previous lane's x) & mask as ONE v_and_b32_dpp; the s_nop covers the VALU-write -> DPP-read hazard that hipcc
-    // cannot see inside an asm statement (x was usually produced by the immediately preceding v_alignbit).
-    __device__ __forceinline__ uint32_t prev_and(int, uint32_t x, uint32_t mask_vgpr) const
-    {
-        uint32_t r;
-        asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(mask_vgpr));
-        return r;
-    }
-#else
     __device__ __forceinline__ uint32_t prev_and(int s, uint32_t x, uint32_t mask) const { return prev(s, x) & mask; }
-#endif
     __device__ __forceinline__ uint32_t prev(int, uint32_t x) const
     {
-#ifndef NTK_NO_DPP
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kDppWaveShr1, 0xf, 0xf, true);
-#else
-        const uint32_t up = __shfl_up(x, 1, 64);
-        return (threadIdx.x & 63) ? up : 0u;
-#endif
     }
 };
 
