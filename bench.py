@@ -95,6 +95,10 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if not os.path.exists(os.path.join(ROOT, "needletail_amd", "libneedletail_amd.so")) and \
+            int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        import subprocess  # a snapshot without the built library: compile it (hipcc is in the image); no other path exists
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "needletail_amd", "csrc")], stdout=sys.stderr)
     import needletail_amd as nt
     from needletail_amd import _lib as ntl
     from needletail_amd import distributed as nd

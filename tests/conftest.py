@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    # the HIP library is built in-tree (python -c "import __graft_entry__ as g; g.build()"); a checkout without it gets it
+    # compiled here once (hipcc cross-compiles gfx950 without a GPU) - there is nothing else to fall back to
+    so = os.path.join(ROOT, "needletail_amd", "libneedletail_amd.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "needletail_amd", "csrc")])
 
 
 @pytest.fixture(scope="session")
