@@ -7,11 +7,13 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: %s <file.fa|fq[.gz]>\n", argv[0]); return 2; }
+    // like the reference's example, records come from standard input when no file is named (the batched variant reads its
+    // input a second time and so needs a file)
+    const bool from_stdin = argc < 2;
     using namespace needletail;
     try {
         size_t n_bases = 0, n_valid_kmers = 0;
-        auto reader = parse_fastx_file(argv[1]);
+        auto reader = from_stdin ? parse_fastx_stdin() : parse_fastx_file(argv[1]);
         while (auto record = reader.next()) {
             const SequenceRecord &seqrec = *record;
             n_bases += seqrec.num_bases();
@@ -25,6 +27,7 @@ int main(int argc, char **argv)
         printf("There are %zu bases in your file.\n", n_bases);
         printf("There are %zu AAAAs in your file.\n", n_valid_kmers);
 
+        if (from_stdin) return 0;
         // batched fast path: hist[0] at k = 4 is the AAAA count
         auto rd2 = parse_fastx_file(argv[1]);
         ntk_params p = {4, NTK_PATH_BYTES_CANONICAL, NTK_PRE_NORMALIZE, 0};

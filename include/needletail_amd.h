@@ -197,7 +197,7 @@ enum { /* ParseErrorKind, reference src/errors.rs:26-44 */
     NTK_PARSE_UNEQUAL_LENGTHS = 5, NTK_PARSE_UNEXPECTED_END = 6, NTK_PARSE_EMPTY_FILE = 7
 };
 /* On NTK_ERR_PARSE *out is still a valid handle (query ntk_reader_error, then close it). */
-int ntk_reader_open_file(const char *path, ntk_reader **out);
+int ntk_reader_open_file(const char *path, ntk_reader **out);   /* "-" reads standard input (parse_fastx_stdin) */
 int ntk_reader_open_memory(const uint8_t *data, uint64_t n, ntk_reader **out); /* data must outlive the reader */
 int ntk_reader_next(ntk_reader *r, ntk_record *rec);  /* NTK_OK, NTK_EOF or NTK_ERR_PARSE */
 int ntk_reader_error(ntk_reader *r, int *kind, uint64_t *line, char *msg, uint64_t msg_cap, char *id, uint64_t id_cap);

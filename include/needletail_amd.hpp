@@ -193,6 +193,7 @@ inline FastxReader parse_fastx_file(const std::string &path) {  // reference src
     if (st != NTK_OK) { if (h) rd.throw_parse(st); throw Error(st, ntk_strerror(st)); }
     return rd;
 }
+inline FastxReader parse_fastx_stdin() { return parse_fastx_file("-"); }  // reference src/parser/mod.rs:154-159
 inline FastxReader parse_fastx_reader(const uint8_t *data, uint64_t n) {  // reference src/parser/mod.rs:85 over a byte slice
     ntk_reader *h = nullptr;
     const int st = ntk_reader_open_memory(data, n, &h);

@@ -44,7 +44,7 @@ std::string first_word(const uint8_t *p, size_t n)
 FastxReader::~FastxReader()
 {
     if (zs_) { inflateEnd(zs_); delete zs_; }
-    if (fp_) fclose(fp_);
+    if (fp_ && !is_stdin_) fclose(fp_);
 }
 
 bool FastxReader::fail(int kind, const std::string &msg, uint64_t line, const std::string &id)
@@ -155,6 +155,8 @@ bool FastxReader::sniff()
 
 bool FastxReader::open_file(const char *path)
 {
+    // "-" is standard input: parse_fastx_stdin (reference src/parser/mod.rs:154-159)
+    if (path[0] == '-' && path[1] == 0) { fp_ = stdin; is_stdin_ = true; return sniff(); }
     fp_ = fopen(path, "rb");
     if (!fp_) return fail(kErrIo, std::string("cannot open ") + path, 0);
     return sniff();

@@ -12,7 +12,7 @@
 //   * FASTQ: strict 4-line records, '@' / '+' checks, equal sequence/quality lengths, last record may lack its newline,
 //     trailing blank lines allowed, otherwise UnexpectedEnd   (reference src/parser/fastq.rs:155-187,240-285,335-355)
 //   * buffer policy: 64 KiB, doubling to 8 MiB, then +8 MiB steps (reference src/parser/utils.rs:8,24-30)
-// Not mirrored (out of scope): bz2/xz/zstd, stdin, record writers, header masking.
+// Not mirrored (out of scope): bz2/xz/zstd, record writers, header masking.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -48,7 +48,7 @@ public:
     FastxReader(const FastxReader &) = delete;
     FastxReader &operator=(const FastxReader &) = delete;
 
-    bool open_file(const char *path);                    // parse_fastx_file
+    bool open_file(const char *path);                    // parse_fastx_file; "-" = parse_fastx_stdin
     bool open_memory(const uint8_t *data, uint64_t n);   // parse_fastx_reader over a byte slice (data must outlive the reader)
     // 1 = record, 0 = end of input, -1 = error (see error_*)
     int next(FastxRecord *rec);
@@ -66,7 +66,7 @@ public:
 
 private:
     // raw source
-    FILE *fp_ = nullptr;
+    FILE *fp_ = nullptr; bool is_stdin_ = false;
     const uint8_t *mem_ = nullptr; uint64_t mem_n_ = 0, mem_pos_ = 0;
     size_t read_raw(uint8_t *dst, size_t cap);
     // gzip layer

@@ -141,6 +141,11 @@ def parse_fastx_file(path) -> FastxReader:
     return FastxReader(path=path)
 
 
+def parse_fastx_stdin() -> FastxReader:
+    """needletail's parse_fastx_stdin (reference src/parser/mod.rs:154-159)."""
+    return FastxReader(path="-")
+
+
 def parse_fastx_string(content) -> FastxReader:
     """needletail.parse_fastx_string (reference src/python.rs:326)."""
     return FastxReader(data=content.encode() if isinstance(content, str) else bytes(content))

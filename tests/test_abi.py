@@ -107,6 +107,10 @@ def test_cpp_example_program_on_gpu():
         f.write(b">id1\nAGTCGTCA\n"); f.flush()
         r = subprocess.run([exe, f.name], capture_output=True, text=True)
     assert "There are 8 bases in your file." in r.stdout and "There are 0 AAAAs in your file." in r.stdout
+    # the reference's own invocation: records piped into standard input (tests/test_stdin.rs:8-32)
+    r = subprocess.run([exe], input=">id1\nAGTCGTCA", capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "There are 8 bases in your file." in r.stdout and "There are 0 AAAAs in your file." in r.stdout
 
 
 @pytest.mark.gpu
