@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <memory>
 #include <optional>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -136,6 +137,21 @@ inline BitKmer minimizer(BitKmer kmer, uint8_t minmer_size, Context &c = Context
 struct Position { uint64_t line_ = 0, byte_ = 0; uint64_t line() const { return line_; } uint64_t byte() const { return byte_; } };
 enum class LineEnding { Windows, Unix };
 
+// write_fasta / write_fastq (reference src/parser/record.rs:207-247)
+inline void write_fasta(Slice id, Slice seq, std::ostream &w, LineEnding le = LineEnding::Unix) {
+    const char *e = le == LineEnding::Windows ? "\r\n" : "\n";
+    w << '>'; w.write(reinterpret_cast<const char *>(id.data()), (std::streamsize)id.size()); w << e;
+    w.write(reinterpret_cast<const char *>(seq.data()), (std::streamsize)seq.size()); w << e;
+}
+inline void write_fastq(Slice id, Slice seq, std::optional<Slice> qual, std::ostream &w, LineEnding le = LineEnding::Unix) {
+    const char *e = le == LineEnding::Windows ? "\r\n" : "\n";
+    w << '@'; w.write(reinterpret_cast<const char *>(id.data()), (std::streamsize)id.size()); w << e;
+    w.write(reinterpret_cast<const char *>(seq.data()), (std::streamsize)seq.size()); w << e << '+' << e;
+    if (qual) w.write(reinterpret_cast<const char *>(qual->data()), (std::streamsize)qual->size());
+    else w << std::string(seq.size(), 'I');   // no qualities: written as "good" (record.rs:237-244)
+    w << e;
+}
+
 // SequenceRecord (reference src/parser/record.rs:21-179): a view valid until the next FastxReader::next().
 struct SequenceRecord {
     Slice id_, raw_seq_, qual_; bool has_qual = false; uint64_t line = 0, bases = 0, byte = 0; int fmt = 0, ending = 1;
@@ -148,6 +164,10 @@ struct SequenceRecord {
     Position position() const { return Position{line, byte}; }           // src/parser/record.rs:147-149
     LineEnding line_ending() const { return ending == 2 ? LineEnding::Windows : LineEnding::Unix; }  // :152-154
     Bytes normalize(bool iupac) const { return Sequence(raw_seq_).normalize(iupac); }
+    void write(std::ostream &w, std::optional<LineEnding> forced = std::nullopt) const {  // src/parser/record.rs:156-179
+        const LineEnding le = forced ? *forced : line_ending();
+        if (has_qual) write_fastq(id_, raw_seq_, qual_, w, le); else write_fasta(id_, raw_seq_, w, le);
+    }
 };
 
 // FastxReader (reference src/parser/utils.rs:119-130)

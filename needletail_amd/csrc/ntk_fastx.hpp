@@ -12,7 +12,7 @@
 //   * FASTQ: strict 4-line records, '@' / '+' checks, equal sequence/quality lengths, last record may lack its newline,
 //     trailing blank lines allowed, otherwise UnexpectedEnd   (reference src/parser/fastq.rs:155-187,240-285,335-355)
 //   * buffer policy: 64 KiB, doubling to 8 MiB, then +8 MiB steps (reference src/parser/utils.rs:8,24-30)
-// Not mirrored (out of scope): bz2/xz/zstd, record writers, header masking.
+// Not mirrored (out of scope): bz2/xz/zstd, header masking (record writers live in the host mirrors).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>

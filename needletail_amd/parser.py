@@ -57,8 +57,29 @@ class Record:
     def normalize(self, iupac: bool = False) -> None:
         self.seq = S.normalize_seq(self.seq, iupac)
 
+    def write(self, writer, forced_line_ending: Optional[str] = None) -> None:
+        """SequenceRecord::write (reference src/parser/record.rs:156-179): the record back to a binary writer, with its own
+        line ending unless one is forced ("\n" or "\r\n")."""
+        ending = forced_line_ending or self.line_ending
+        if self.qual is None:
+            write_fasta(self.id.encode(), self.raw_seq, writer, ending)
+        else:
+            write_fastq(self.id.encode(), self.raw_seq, self.qual.encode(), writer, ending)
+
     def __repr__(self):
         return f"Record(id={self.id!r}, seq={self.seq[:30]!r}{'...' if len(self.seq) > 30 else ''}, qual={'yes' if self.qual else None})"
+
+
+def write_fasta(id: bytes, seq: bytes, writer, line_ending: str = "\n") -> None:
+    """reference src/parser/record.rs:207-220"""
+    e = line_ending.encode()
+    writer.write(b">" + id + e + seq + e)
+
+
+def write_fastq(id: bytes, seq: bytes, qual: Optional[bytes], writer, line_ending: str = "\n") -> None:
+    """reference src/parser/record.rs:222-247: a missing quality line is written as 'I' per base."""
+    e = line_ending.encode()
+    writer.write(b"@" + id + e + seq + e + b"+" + e + (qual if qual is not None else b"I" * len(seq)) + e)
 
 
 class FastxReader:

@@ -244,3 +244,22 @@ def test_stdin_reader(golden_dir):
     data = open(os.path.join(golden_dir, "28S.fasta"), "rb").read()
     r = subprocess.run([sys.executable, "-c", code], input=data, capture_output=True, timeout=120)
     assert r.stdout.decode().split()[:2] == ["570", "738580"]
+
+
+def test_record_write_round_trip(golden_dir):
+    """SequenceRecord::write / write_fasta / write_fastq (reference src/parser/record.rs:156-247): parse -> write gives the
+    input back (own line ending kept, or forced), a record without qualities is written with 'I' per base."""
+    import io
+    for text in (b">a desc\nACGT\nAC\n>b\nTTTT\n", b">a\r\nACGT\r\nAC\r\n>b\r\nT\r\n", b"@r1\nACGT\n+\nIIII\n@r2 x\nAC\n+\n!!\n",
+                 open(os.path.join(golden_dir, "test.fa"), "rb").read()):
+        out = io.BytesIO()
+        for rec in nt.parse_fastx_string(text):
+            rec.write(out)
+        assert out.getvalue() == text
+    out = io.BytesIO()
+    for rec in nt.parse_fastx_string(b">a\nAC\nGT\n"):
+        rec.write(out, "\r\n")
+    assert out.getvalue() == b">a\r\nAC\nGT\r\n"
+    out = io.BytesIO()
+    nt.write_fastq(b"id", b"ACGT", None, out)
+    assert out.getvalue() == b"@id\nACGT\n+\nIIII\n"
