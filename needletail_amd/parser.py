@@ -30,6 +30,8 @@ class Record:
 
     def __init__(self, id: str, seq: str, qual: Optional[str] = None, raw_seq: bytes = None, line: int = 0,
                  num_bases: int = None, byte: int = 0, line_ending: str = "\n"):
+        if qual is not None and len(qual) != len(seq):   # reference src/python.rs:205-216
+            raise ValueError("Sequence and quality strings must have the same length")
         self.id = id
         self.seq = seq
         self.qual = qual
@@ -38,6 +40,19 @@ class Record:
         self.num_bases = len(seq) if num_bases is None else num_bases
         self.byte = byte                  # SequenceRecord::position().byte()  (reference src/parser/record.rs:147-149)
         self.line_ending = line_ending    # SequenceRecord::line_ending()      (reference src/parser/record.rs:152-154)
+
+    # reference src/python.rs:218-268
+    def __eq__(self, other):
+        return isinstance(other, Record) and (self.id, self.seq, self.qual) == (other.id, other.seq, other.qual)
+
+    def __hash__(self):
+        return hash((self.id, self.seq)) if self.qual is None else hash((self.id, self.seq, self.qual))
+
+    def __len__(self):
+        return len(self.seq)
+
+    def __str__(self):
+        return f">{self.id}\n{self.seq}\n" if self.qual is None else f"@{self.id}\n{self.seq}\n+\n{self.qual}\n"
 
     @property
     def name(self) -> str:
@@ -67,7 +82,11 @@ class Record:
             write_fastq(self.id.encode(), self.raw_seq, self.qual.encode(), writer, ending)
 
     def __repr__(self):
-        return f"Record(id={self.id!r}, seq={self.seq[:30]!r}{'...' if len(self.seq) > 30 else ''}, qual={'yes' if self.qual else None})"
+        def snippet(x, max_len=20):   # reference src/python.rs:37-45
+            return x[: max_len - 4] + "\u2026" + x[-3:] if len(x) > max_len else x
+        name = self.name
+        id_snippet = name if name == self.id else name + "\u2026"
+        return f"Record(id={id_snippet}, seq={snippet(self.seq)}, qual={snippet(self.qual) if self.qual is not None else 'None'})"
 
 
 def write_fasta(id: bytes, seq: bytes, writer, line_ending: str = "\n") -> None:
@@ -160,6 +179,18 @@ class FastxReader:
 def parse_fastx_file(path) -> FastxReader:
     """needletail.parse_fastx_file (reference src/parser/mod.rs:161, src/python.rs:293)."""
     return FastxReader(path=path)
+
+
+def decode_phred(qual: str, base_64: bool = False) -> tuple:
+    """needletail.decode_phred (reference src/python.rs:416-427, src/quality.rs:10-28): quality characters minus the
+    offset (33, or 64 with base_64); a character below the offset is a ValueError."""
+    offset = 64 if base_64 else 33
+    out = []
+    for ch in qual.encode("latin-1", "replace"):
+        if ch < offset:
+            raise ValueError(f"Invalid Phred quality: character {ch} is below the offset {offset}")
+        out.append(ch - offset)
+    return tuple(out)
 
 
 def parse_fastx_stdin() -> FastxReader:

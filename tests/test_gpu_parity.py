@@ -85,6 +85,12 @@ def test_python_facade_literals(ctx):
     assert rc("a") == "t" and rc("c") == "g" and rc("g") == "c" and rc("n") == "n"
     assert rc("atcg") == "cgat" and rc("ATCG") == "CGAT"
     assert nt.reverse_complement(b"AACC", ctx) == b"GGTT"  # reference src/sequence.rs:200
+    # Record.normalize (reference test_python.py:42-47)
+    rec = nt.Record("test", "AGCTGYrtcga")
+    rec.normalize(iupac=True)
+    assert rec.seq == "AGCTGYRTCGA"
+    rec.normalize()
+    assert rec.seq == "AGCTGNNTCGA"
 
 
 def test_normalize_strip_revcomp_random(ctx):
