@@ -16,5 +16,8 @@ int main() {
     printf("%llu %d\n", (unsigned long long)c.first.first, (int)c.second);
     auto mi = bitkmer::minimizer(BitKmer{0x1B, 4}, 2);
     printf("%llu\n", (unsigned long long)mi.first);
+    const uint8_t ph[] = "#</</BBFFFBF<";                 // reference src/quality.rs:35-40: 2 27 14 27 14 33 33 37 37 37 33 37 27
+    for (uint8_t v : decode_phred(Slice(ph, 13), PhredEncoding::Phred33)) printf("%d ", (int)v);
+    printf("\n");
     return 0;
 }

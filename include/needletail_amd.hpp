@@ -109,6 +109,18 @@ private:
     Slice q_; Context *cq_;
 };
 
+// quality::decode_phred (reference src/quality.rs:3-28): characters minus the offset; a character below it throws
+enum class PhredEncoding { Phred33, Phred64 };
+inline std::vector<uint8_t> decode_phred(Slice qual, PhredEncoding enc) {
+    const uint8_t offset = enc == PhredEncoding::Phred33 ? '!' : '@';
+    std::vector<uint8_t> scores; scores.reserve(qual.size());
+    for (uint8_t q : qual) {
+        if (q < offset) throw Error(NTK_ERR_BAD_ARG, "PhredOffsetError: quality " + std::to_string(q) + " is below the offset " + std::to_string(offset));
+        scores.push_back((uint8_t)(q - offset));
+    }
+    return scores;
+}
+
 // sequence::minimizer (reference src/sequence.rs:139-152) and the bitkmer free functions (reference src/bitkmer.rs:112-162)
 inline Bytes minimizer(Slice seq, size_t length, Context &c = Context::global()) {
     Bytes out(length, 0);

@@ -126,3 +126,4 @@ def test_cpp_mirror_quality_and_minimizers_on_gpu():
     cv, crc = O.bit_canonical(0xE4, 4)
     assert (int(lines[2]), int(lines[3])) == (cv, int(crc))
     assert int(lines[4]) == O.bit_minimizer(0x1B, 4, 2)
+    assert [int(x) for x in lines[5:18]] == [2, 27, 14, 27, 14, 33, 33, 37, 37, 37, 33, 37, 27]
