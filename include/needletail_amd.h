@@ -249,6 +249,9 @@ int ntk_bit_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k, int 
 int ntk_minimizers_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p, uint32_t w);
 /* sequence::minimizer (reference src/sequence.rs:139-152) for one sequence; out holds m bytes; n >= m >= 1. */
 int ntk_minimizer(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t m, uint8_t *out);
+/* sequence::canonical (reference src/sequence.rs:110-134): the lexicographically lower of seq and its reverse complement
+ * (raw-byte order, complement as ntk_reverse_complement); out holds n bytes; *was_rc = 1 when the reverse complement won. */
+int ntk_canonical(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint8_t *out, int *was_rc);
 /* bitkmer::minimizer (reference src/bitkmer.rs:146-162), element-wise over n packed k-mers (host arrays). */
 int ntk_bit_minimizers(ntk_ctx *ctx, const uint64_t *values, uint64_t n, uint32_t k, uint32_t m, uint64_t *out);
 /* bitkmer::reverse_complement (reference src/bitkmer.rs:112-132) / bitkmer::canonical (:136-143), element-wise over n

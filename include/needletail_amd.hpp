@@ -127,6 +127,18 @@ inline Bytes minimizer(Slice seq, size_t length, Context &c = Context::global())
     check(ntk_minimizer(c.get(), seq.data(), seq.size(), (uint32_t)length, out.data()), "ntk_minimizer");
     return out;
 }
+// sequence::canonical (reference src/sequence.rs:110-134)
+inline Bytes canonical(Slice seq, Context &c = Context::global()) {
+    Bytes out(seq.size(), 0);
+    check(ntk_canonical(c.get(), seq.data(), seq.size(), out.data(), nullptr), "ntk_canonical");
+    return out;
+}
+// mask_header_tabs (reference src/parser/record.rs:188-194): tabs -> '|', nullopt when there is none
+inline std::optional<Bytes> mask_header_tabs(Slice id) {
+    if (id.find((uint8_t)'\t') == Slice::npos) return std::nullopt;
+    Bytes out(id); for (auto &ch : out) if (ch == '\t') ch = '|';
+    return out;
+}
 namespace bitkmer {
 inline BitKmer reverse_complement(BitKmer kmer, Context &c = Context::global()) {
     uint64_t out = 0;

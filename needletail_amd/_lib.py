@@ -30,7 +30,7 @@ SYMBOLS = [
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
     "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_position", "ntk_reader_close",
     "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points",
-    "ntk_minimizers_reduce_device", "ntk_minimizer", "ntk_bit_minimizers", "ntk_quality_mask", "ntk_bit_canonical",
+    "ntk_minimizers_reduce_device", "ntk_minimizer", "ntk_canonical", "ntk_bit_minimizers", "ntk_quality_mask", "ntk_bit_canonical",
 ]
 
 
@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
     L.ntk_scan_file_parallel.argtypes = [vp, C.c_char_p, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]
     L.ntk_minimizers_reduce_device.argtypes = [vp, vp, u64, C.POINTER(Params), u32]
     L.ntk_minimizer.argtypes = [vp, C.c_char_p, u64, u32, C.c_char_p]
+    L.ntk_canonical.argtypes = [vp, C.c_char_p, u64, C.c_char_p, C.POINTER(i32)]
     L.ntk_bit_minimizers.argtypes = [vp, vp, u64, u32, u32, vp]
     L.ntk_bit_canonical.argtypes = [vp, vp, u64, u32, i32, vp, vp]
     L.ntk_quality_mask.argtypes = [vp, C.c_char_p, C.c_char_p, u64, C.c_uint8, C.c_char_p]

@@ -915,6 +915,18 @@ int ntk_minimizer(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t m, uint8_
     return NTK_OK;
 }
 
+int ntk_canonical(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *out, int *was_rc)
+{
+    if (!c || (!seq && n) || (!out && n)) return NTK_ERR_BAD_ARG;
+    if (was_rc) *was_rc = 0;
+    if (n == 0) return NTK_OK;
+    if (n > 0xFFFFFFFFull) return NTK_ERR_UNSUPPORTED;
+    // the smallest length-n substring over both strands IS the canonical form (one candidate per strand)
+    const int rc = ntk_minimizer(c, seq, n, (uint32_t)n, out);
+    if (rc == NTK_OK && was_rc) *was_rc = memcmp(out, seq, n) != 0;
+    return rc;
+}
+
 int ntk_bit_minimizers(ntk_ctx *c, const uint64_t *values, uint64_t n, uint32_t k, uint32_t m, uint64_t *out)
 {
     if (!c || (!values && n) || (!out && n)) return NTK_ERR_BAD_ARG;

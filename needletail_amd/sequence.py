@@ -118,6 +118,28 @@ def minimizer(seq: bytes, length: int, ctx: Context = None) -> bytes:
     return out.raw[:length]
 
 
+def canonical(seq: bytes, ctx: Context = None) -> bytes:
+    """sequence::canonical (reference src/sequence.rs:110-134): the lower of seq and its reverse complement."""
+    c = _ctx(ctx)
+    out = C.create_string_buffer(max(len(seq), 1))
+    L.check(L.lib().ntk_canonical(c._h, seq, len(seq), out, None), "ntk_canonical")
+    return out.raw[:len(seq)]
+
+
+def mask_header_tabs(id: bytes):
+    """reference src/parser/record.rs:188-194: tabs -> '|'; None when there is nothing to mask."""
+    return id.replace(b"\t", b"|") if b"\t" in id else None
+
+
+def mask_header_utf8(id: bytes):
+    """reference src/parser/record.rs:197-204: invalid UTF-8 -> U+FFFD; None when the header is valid UTF-8."""
+    try:
+        id.decode("utf-8")
+        return None
+    except UnicodeDecodeError:
+        return id.decode("utf-8", "replace").encode("utf-8")
+
+
 def bit_minimizers(values, k: int, m: int, ctx: Context = None) -> np.ndarray:
     """bitkmer::minimizer (reference src/bitkmer.rs:146-162) over an array of packed k-mers."""
     c = _ctx(ctx)

@@ -312,6 +312,18 @@ def test_minimizer_and_quality_mask_kats(ctx):
         assert np.array_equal(nt.bit_minimizers(v, k, m, ctx)[:300], want), (k, m)
 
 
+def test_sequence_canonical_kats(ctx):
+    # reference src/sequence.rs:354-361
+    for seq, want in ((b"A", b"A"), (b"T", b"A"), (b"AAGT", b"AAGT"), (b"ACTT", b"AAGT"), (b"GC", b"GC"), (b"", b"")):
+        assert nt.canonical(seq, ctx) == want == O.canonical(seq)
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        s_ = bytes(rng.choice(list(b"ACGTacgtNRY"), size=int(rng.integers(1, 300))).astype(np.uint8))
+        assert nt.canonical(s_, ctx) == O.canonical(s_)
+    assert nt.mask_header_tabs(b"a\tb\tc") == b"a|b|c" and nt.mask_header_tabs(b"abc") is None
+    assert nt.mask_header_utf8(b"ok") is None and nt.mask_header_utf8(b"bad\xff") == "bad\ufffd".encode()
+
+
 def test_bit_reverse_complement_and_canonical_kats(ctx):
     # reference src/bitkmer.rs:253-259, 270-286
     assert list(nt.bit_reverse_complement([0b000000, 0b111111], 3, ctx)) == [0b111111, 0]
