@@ -50,7 +50,7 @@ struct ReduceSink {
 #endif
             n_fwd += take_fwd ? 1u : 0u;  // v_addc_co_u32 off the compare's carry mask
 #ifndef NTK_ABL_NOHIST
-            atomicAdd(&hist[(uint32_t)(v >> bin_shift)], 1u);
+            atomicAdd(&hist[KW == 2 ? (uint32_t)(v >> bin_shift) : (lo >> bin_shift)], 1u);  // no 64-bit shift for 32-bit values
 #else
             n_valid += (uint32_t)(v >> bin_shift);
 #endif
