@@ -1,6 +1,8 @@
 // ntk_fastx.cpp — see ntk_fastx.hpp.  Host-only C++ (zlib for gzip); part of libneedletail_amd.so.
 #include "ntk_fastx.hpp"
 
+#include <immintrin.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -185,6 +187,48 @@ void FastxReader::note_line_ending(const uint8_t *all, size_t n)
     if (p) line_ending_ = (p > all && p[-1] == '\r') ? 2 : 1;
 }
 
+// '\n' and '\r' counts of [p, p+n): 32-byte compares where the CPU has AVX2, a plain loop otherwise
+__attribute__((target("avx2"))) static void count_nl_cr_avx2(const uint8_t *p, size_t n, uint64_t *nl, uint64_t *cr)
+{
+    uint64_t a = 0, b = 0;
+    size_t i = 0;
+    const __m256i vn = _mm256_set1_epi8('\n'), vr = _mm256_set1_epi8('\r');
+    for (; i + 32 <= n; i += 32) {
+        const __m256i x = _mm256_loadu_si256((const __m256i *)(p + i));
+        a += (uint64_t)__builtin_popcount((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vn)));
+        b += (uint64_t)__builtin_popcount((uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vr)));
+    }
+    for (; i < n; i++) { a += p[i] == '\n'; b += p[i] == '\r'; }
+    *nl = a; *cr = b;
+}
+static void count_nl_cr_plain(const uint8_t *p, size_t n, uint64_t *nl, uint64_t *cr)
+{
+    uint64_t a = 0, b = 0;
+    size_t i = 0;
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+    const __m128i vn = _mm_set1_epi8('\n'), vr = _mm_set1_epi8('\r');
+    for (; i + 16 <= n; i += 16) {
+        const __m128i x = _mm_loadu_si128((const __m128i *)(p + i));
+        a += (uint64_t)__builtin_popcount((uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vn)));
+        b += (uint64_t)__builtin_popcount((uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vr)));
+    }
+#endif
+    for (; i < n; i++) { a += p[i] == '\n'; b += p[i] == '\r'; }
+    *nl = a; *cr = b;
+}
+static inline void count_nl_cr(const uint8_t *p, size_t n, uint64_t *nl, uint64_t *cr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // hipcc also runs a device pass over this host-only file
+    count_nl_cr_plain(p, n, nl, cr);
+#else
+    static void (*const fn)(const uint8_t *, size_t, uint64_t *, uint64_t *) = [] {
+        __builtin_cpu_init();
+        return (__builtin_cpu_supports("avx2") && !getenv("NTK_NO_AVX2")) ? count_nl_cr_avx2 : count_nl_cr_plain;
+    }();
+    fn(p, n, nl, cr);
+#endif
+}
+
 int FastxReader::next_fasta(FastxRecord *rec)
 {
     if (start_ == len_) {
@@ -192,28 +236,25 @@ int FastxReader::next_fasta(FastxRecord *rec)
         if (err_kind_) return -1;
         if (start_ == len_) { finished_ = true; return 0; }
     }
-    // A record runs from '>' to the last '\n' before the next line that starts with '>' (or to EOF).  Offsets are
-    // relative to start_ so that they survive make_room() / grow() inside fill().
+    // A record runs from '>' to the last '\n' before the next line that starts with '>' (or to EOF): the header's line
+    // feed is one memchr, the next record one memchr for '>' per candidate (a '>' counts only right after a line feed), and
+    // the line count (reference fasta.rs:235 pushes every line end) one vectorised pass - not a memchr per 60..80-byte
+    // line.  Offsets are relative to start_ so that they survive make_room() / grow() inside fill().
     size_t scan = 1, first_nl = (size_t)-1, last_nl = (size_t)-1, rec_len = 0;
-    uint64_t n_lines = 0;
     for (;;) {
         const uint8_t *base = buf_.data() + start_;
         const size_t avail = len_ - start_;
         bool complete = false;
-        while (scan < avail) {
+        if (first_nl == (size_t)-1 && scan < avail) {
             const uint8_t *p = (const uint8_t *)memchr(base + scan, '\n', avail - scan);
+            if (p) { first_nl = (size_t)(p - base); scan = first_nl + 1; } else scan = avail;
+        }
+        while (first_nl != (size_t)-1 && scan < avail) {
+            const uint8_t *p = (const uint8_t *)memchr(base + scan, '>', avail - scan);
             if (!p) { scan = avail; break; }
             const size_t pos = (size_t)(p - base);
-            if (pos + 1 == avail) {  // cannot look at the next byte (fasta.rs:229-233)
-                if (!eof_) { scan = pos; break; }
-                // at EOF the reference counts this final line end only if an earlier one was pushed (fasta.rs:204-212):
-                // a header line followed by nothing but its newline is a truncated record
-                if (first_nl == (size_t)-1) { fail(kErrUnexpectedEnd, "Unexpected end of input", line_); return -1; }
-            }
-            if (first_nl == (size_t)-1) first_nl = pos;
-            last_nl = pos; n_lines++;   // fasta.rs:235 seq_pos.push(pos)
+            if (base[pos - 1] == '\n') { rec_len = pos; last_nl = pos - 1; complete = true; break; }
             scan = pos + 1;
-            if (scan < avail && base[scan] == '>') { rec_len = scan; complete = true; break; }
         }
         if (complete) break;
         if (!eof_) {
@@ -221,14 +262,13 @@ int FastxReader::next_fasta(FastxRecord *rec)
             if (err_kind_) return -1;
             continue;
         }
-        // EOF: the record ends with the input (fasta.rs:204-212)
-        if (base[avail - 1] != '\n') {
-            if (first_nl == (size_t)-1) {  // a header line and nothing else: seq_pos stays empty -> fasta.rs:342-350
-                fail(kErrUnexpectedEnd, "Unexpected end of input", line_);
-                return -1;
-            }
-            last_nl = avail; n_lines++;  // the last line has no line ending; fasta.rs:208 pushes the buffer end
+        // EOF: the record ends with the input (fasta.rs:204-212).  A header line with nothing after it - with or without its
+        // own line feed - is a truncated record (seq_pos stays empty -> fasta.rs:342-350).
+        if (first_nl == (size_t)-1 || first_nl + 1 == avail) {
+            fail(kErrUnexpectedEnd, "Unexpected end of input", line_);
+            return -1;
         }
+        last_nl = base[avail - 1] == '\n' ? avail - 1 : avail;  // no final line feed: fasta.rs:208 pushes the buffer end
         rec_len = avail;
         break;
     }
@@ -237,21 +277,62 @@ int FastxReader::next_fasta(FastxRecord *rec)
     rec->line = line_;
     rec->id = base + 1;
     rec->id_len = trim_cr_len(base + 1, first_nl - 1);
+    uint64_t n_lines = 1, nl = 0, cr = 0;  // the header's line end
     if (last_nl > first_nl) {  // fasta.rs:55-63 raw_seq
         rec->seq = base + first_nl + 1;
         rec->seq_len = trim_cr_len(rec->seq, last_nl - first_nl - 1);
+        count_nl_cr(rec->seq, rec->seq_len, &nl, &cr);
+        n_lines += nl + 1;     // interior line ends + the record's last one (real or the buffer end)
     } else {
         rec->seq = base + first_nl; rec->seq_len = 0;
     }
     rec->qual = nullptr; rec->qual_len = 0;
-    uint64_t nb = rec->seq_len;  // fasta.rs:102-107
-    for (uint64_t i = 0; i < rec->seq_len; i++) nb -= (rec->seq[i] == '\n' || rec->seq[i] == '\r');
-    rec->num_bases = nb;
+    rec->num_bases = rec->seq_len - nl - cr;  // fasta.rs:102-107
     prev_len_ = rec_len; prev_lines_ = n_lines;
     // the reference looks at the record without its final line end (fasta.rs:40-42 `all`): ">id\nACGT"
     note_line_ending(base, last_nl < rec_len ? last_nl : rec_len);
     rec->byte = byte_; rec->line_ending = line_ending_ ? line_ending_ : 1;  // record.rs:39,53 unwrap_or(Unix)
     return 1;
+}
+
+// The first `want` line feeds of [p, p+n): one pass with 32-byte compares where the CPU has AVX2 (a FASTQ record is four
+// short lines: four memchr calls cost more in call overhead than in scanning), plain memchr otherwise.
+__attribute__((target("avx2"))) static int find_newlines_avx2(const uint8_t *p, size_t n, size_t *out, int want)
+{
+    int found = 0;
+    size_t i = 0;
+    const __m256i nlv = _mm256_set1_epi8('\n');
+    for (; i + 32 <= n && found < want; i += 32) {
+        uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nlv));
+        while (m && found < want) { out[found++] = i + (size_t)__builtin_ctz(m); m &= m - 1; }
+    }
+    for (; i < n && found < want; i++)
+        if (p[i] == '\n') out[found++] = i;
+    return found;
+}
+static int find_newlines_memchr(const uint8_t *p, size_t n, size_t *out, int want)
+{
+    int found = 0;
+    size_t from = 0;
+    while (found < want && from < n) {
+        const uint8_t *q = (const uint8_t *)memchr(p + from, '\n', n - from);
+        if (!q) break;
+        out[found++] = (size_t)(q - p);
+        from = out[found - 1] + 1;
+    }
+    return found;
+}
+static inline int find_newlines(const uint8_t *p, size_t n, size_t *out, int want)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // hipcc also runs a device pass over this host-only file
+    return find_newlines_memchr(p, n, out, want);
+#else
+    static int (*const fn)(const uint8_t *, size_t, size_t *, int) = [] {
+        __builtin_cpu_init();
+        return (__builtin_cpu_supports("avx2") && !getenv("NTK_NO_AVX2")) ? find_newlines_avx2 : find_newlines_memchr;
+    }();
+    return fn(p, n, out, want);
+#endif
 }
 
 int FastxReader::next_fastq(FastxRecord *rec)
@@ -261,14 +342,7 @@ int FastxReader::next_fastq(FastxRecord *rec)
     for (;;) {
         const uint8_t *base = buf_.data() + start_;
         const size_t avail = len_ - start_;
-        found = 0;
-        size_t from = 0;
-        while (found < 4 && from < avail) {
-            const uint8_t *p = (const uint8_t *)memchr(base + from, '\n', avail - from);
-            if (!p) break;
-            nl[found++] = (size_t)(p - base);
-            from = nl[found - 1] + 1;
-        }
+        found = find_newlines(base, avail, nl, 4);
         if (found == 4) break;
         if (!eof_) {
             fill();
@@ -295,16 +369,16 @@ int FastxReader::next_fastq(FastxRecord *rec)
         fail(kErrInvalidStart, "Expected '@' but found '" + escape_byte(base[0]), line_);
         return -1;
     }
-    std::string id;
-    if (seq0 > 1) id = first_word(base + 1, trim_cr_len(base + 1, nl[0] - 1));
+    // the record id is only needed for error messages: built on the error paths, not per record
+    auto rec_id = [&]() { return seq0 > 1 ? first_word(base + 1, trim_cr_len(base + 1, nl[0] - 1)) : std::string(); };
     if (base[sep0] != '+') {
-        fail(kErrInvalidSeparator, "Expected '+' separator but found '" + escape_byte(base[sep0]), line_ + 2, id);
+        fail(kErrInvalidSeparator, "Expected '+' separator but found '" + escape_byte(base[sep0]), line_ + 2, rec_id());
         return -1;
     }
     const size_t seq_len = trim_cr_len(base + seq0, nl[1] - seq0);
     const size_t qual_len = trim_cr_len(base + qual0, end - qual0);
     if (seq_len != qual_len) {
-        fail(kErrUnequalLengths, "Sequence length is " + std::to_string(seq_len) + " but quality length is " + std::to_string(qual_len), line_, id);
+        fail(kErrUnequalLengths, "Sequence length is " + std::to_string(seq_len) + " but quality length is " + std::to_string(qual_len), line_, rec_id());
         return -1;
     }
     rec->format = kFastq;
