@@ -213,8 +213,10 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t b
 
 /* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into n_threads pieces,
  * each parsed by its own thread into its own pinned batches (record order across pieces is not preserved; the reduced
- * result does not depend on it).  gzip input is NTK_ERR_UNSUPPORTED here - a gzip stream is sequential, use
- * ntk_scan_reader.  Parse errors return NTK_ERR_PARSE without position detail. */
+ * result does not depend on it).  A gzip stream is sequential: ntk_scan_buffer_parallel refuses it (NTK_ERR_UNSUPPORTED, use
+ * ntk_scan_reader); ntk_scan_file_parallel inflates the whole file into memory first (all members) when libdeflate.so.0 can
+ * be loaded and the output stays under 16 GiB (NTK_GZ_INMEM_LIMIT_BYTES), and is NTK_ERR_UNSUPPORTED otherwise.
+ * Parse errors return NTK_ERR_PARSE without position detail. */
 /* The cut points the parallel producer uses: cuts[0] = 0 <= cuts[1] <= ... <= cuts[n_pieces] = n, every cut a record start. */
 int ntk_fastx_split_points(const uint8_t *data, uint64_t n, uint32_t n_pieces, uint64_t *cuts);
 int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, const ntk_params *p, uint64_t batch_bytes,

@@ -2,7 +2,9 @@
 // batch face only (include/needletail_amd.h).
 #include "../../include/needletail_amd.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -274,6 +276,129 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
     return sh.rc.load();
 }
 
+namespace {
+// Whole-file gzip for the parallel producer.  A gzip stream is sequential, so the parser threads cannot share it; but
+// when libdeflate (a whole-buffer decoder, ~2x zlib's inflate rate) is installed the file is inflated into memory member by
+// member and the plain-text buffer is then parsed in parallel.  The library is loaded at run time (its runtime .so ships
+// with the image, its headers do not; the three entry points below are its stable v1 ABI); without it, or for outputs
+// beyond the in-memory limit, gzip input stays NTK_ERR_UNSUPPORTED here and the streaming ntk_scan_reader (zlib) is the way.
+struct Deflate {
+    void *(*alloc)() = nullptr;
+    int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+    void (*free_)(void *) = nullptr;
+    bool ok = false;
+    Deflate()
+    {
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        gzip_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
+        free_ = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        ok = alloc && gzip_ex && free_;
+    }
+};
+
+// BGZF (block gzip: bgzip / htslib): every member is <= 64 KiB and carries its own compressed size in a 'BC' extra
+// subfield and its plain size in the trailer, so the members can be located without inflating anything and inflated
+// independently.  Fills `blocks`; false when the stream is not pure BGZF.
+struct BgzfBlock { uint64_t in_off, in_len, out_off, out_len; };
+bool bgzf_index(const uint8_t *in, uint64_t n, std::vector<BgzfBlock> *blocks, uint64_t *total_out)
+{
+    uint64_t ip = 0, op = 0;
+    while (ip < n) {
+        if (n - ip < 28 || in[ip] != 0x1F || in[ip + 1] != 0x8B || in[ip + 2] != 8 || !(in[ip + 3] & 4)) return false;
+        const uint32_t xlen = in[ip + 10] | (in[ip + 11] << 8);
+        if (n - ip < 12 + (uint64_t)xlen + 8) return false;
+        uint64_t bsize = 0;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *sf = in + ip + 12 + x;
+            const uint32_t slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint64_t)(sf[4] | (sf[5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + (uint64_t)xlen + 8 || bsize > n - ip) return false;
+        const uint8_t *tr = in + ip + bsize - 4;
+        const uint64_t isize = (uint64_t)tr[0] | ((uint64_t)tr[1] << 8) | ((uint64_t)tr[2] << 16) | ((uint64_t)tr[3] << 24);
+        blocks->push_back(BgzfBlock{ip, bsize, op, isize});
+        ip += bsize; op += isize;
+    }
+    *total_out = op;
+    return !blocks->empty();
+}
+
+// NTK_OK with *out (malloc'ed) / *out_n, NTK_ERR_UNSUPPORTED (no library, or larger than the limit), NTK_ERR_PARSE (bad data)
+int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n)
+{
+    static const Deflate lib;
+    if (!lib.ok) return NTK_ERR_UNSUPPORTED;
+    uint64_t limit = (uint64_t)16 << 30;
+    if (const char *e = getenv("NTK_GZ_INMEM_LIMIT_BYTES")) limit = strtoull(e, nullptr, 10);
+    {   // BGZF: members inflate in parallel straight to their final offsets
+        std::vector<BgzfBlock> blocks;
+        uint64_t total = 0;
+        if (bgzf_index(in, n, &blocks, &total)) {
+            if (total > limit) return NTK_ERR_UNSUPPORTED;
+            uint8_t *buf = (uint8_t *)malloc(total ? total : 1);
+            if (!buf) return NTK_ERR_NOMEM;
+            const uint32_t nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+            std::atomic<int> bad{0};
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                void *d = lib.alloc();
+                if (!d) { bad = 1; return; }
+                for (size_t i; !bad && (i = next.fetch_add(16)) < blocks.size();)   // 16 blocks (<= 1 MiB) per grab
+                    for (size_t j = i; j < i + 16 && j < blocks.size(); j++) {
+                        const BgzfBlock &b = blocks[j];
+                        size_t used = 0, made = 0;
+                        if (lib.gzip_ex(d, in + b.in_off, b.in_len, buf + b.out_off, b.out_len, &used, &made) != 0 ||
+                            made != b.out_len) { bad = 1; break; }
+                    }
+                lib.free_(d);
+            };
+            std::vector<std::thread> th;
+            for (uint32_t t = 1; t < nt; t++) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+            if (bad) { free(buf); return NTK_ERR_PARSE; }
+            *out = buf; *out_n = total;
+            return NTK_OK;
+        }
+    }
+    uint64_t cap = n * 5 + (1 << 20);
+    if (cap > limit) cap = limit;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    if (!buf) return NTK_ERR_NOMEM;
+    void *d = lib.alloc();
+    if (!d) { free(buf); return NTK_ERR_NOMEM; }
+    uint64_t ip = 0, op = 0;
+    int rc = NTK_OK;
+    while (ip < n) {   // concatenated members (MultiGzDecoder, reference src/parser/mod.rs:95-108)
+        if (n - ip < 18 || in[ip] != 0x1F || in[ip + 1] != 0x8B) {
+            bool pad = true;   // trailing zero padding after the last member is tolerated like zlib-based readers do
+            for (uint64_t i = ip; i < n && pad; i++) pad = in[i] == 0;
+            if (!pad) rc = NTK_ERR_PARSE;
+            break;
+        }
+        size_t used = 0, made = 0;
+        const int r = lib.gzip_ex(d, in + ip, n - ip, buf + op, cap - op, &used, &made);
+        if (r == 3) {   // LIBDEFLATE_INSUFFICIENT_SPACE: grow and retry this member
+            if (cap >= limit) { rc = NTK_ERR_UNSUPPORTED; break; }
+            uint64_t ncap = cap * 2 > limit ? limit : cap * 2;
+            uint8_t *nb = (uint8_t *)realloc(buf, ncap);
+            if (!nb) { rc = NTK_ERR_NOMEM; break; }
+            buf = nb; cap = ncap;
+            continue;
+        }
+        if (r != 0) { rc = NTK_ERR_PARSE; break; }
+        ip += used; op += made;
+    }
+    lib.free_(d);
+    if (rc != NTK_OK) { free(buf); return rc; }
+    *out = buf; *out_n = op;
+    return NTK_OK;
+}
+}  // namespace
+
 int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads,
                            uint64_t *n_records, uint64_t *n_bases)
 {
@@ -285,7 +410,18 @@ int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, 
     void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return NTK_ERR_NOMEM;
-    const int rc = ntk_scan_buffer_parallel(ctx, (const uint8_t *)m, (uint64_t)st.st_size, p, batch_bytes, n_threads, n_records, n_bases);
+    const uint8_t *data = (const uint8_t *)m;
+    int rc;
+    if (data[0] == 0x1F && data[1] == 0x8B) {
+        uint8_t *plain = nullptr; uint64_t plain_n = 0;
+        rc = inflate_whole(data, (uint64_t)st.st_size, n_threads, &plain, &plain_n);
+        if (rc == NTK_OK) {
+            rc = ntk_scan_buffer_parallel(ctx, plain, plain_n, p, batch_bytes, n_threads, n_records, n_bases);
+            free(plain);
+        }
+    } else {
+        rc = ntk_scan_buffer_parallel(ctx, data, (uint64_t)st.st_size, p, batch_bytes, n_threads, n_records, n_bases);
+    }
     munmap(m, (size_t)st.st_size);
     return rc;
 }

@@ -30,3 +30,18 @@ def fastq_raw_seqs(data: bytes):
         lines.pop()
     assert len(lines) % 4 == 0
     return [_trim_cr(lines[i + 1]) for i in range(0, len(lines), 4)]
+
+
+def bgzf_compress(data: bytes, block: int = 60000) -> bytes:
+    """Block gzip (BGZF, bgzip/htslib): independent members of <= 64 KiB with their compressed size in a 'BC' extra subfield,
+    closed by the empty EOF block.  Test helper (no bgzip binary in the image)."""
+    import struct
+    import zlib
+    out = bytearray()
+    for ch in [data[i:i + block] for i in range(0, len(data), block)] + [b""]:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(ch) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch))
+    return bytes(out)

@@ -11,7 +11,7 @@ torch = pytest.importorskip("torch")
 
 import needletail_amd as nt  # noqa: E402
 import oracle as O  # noqa: E402  (the checker)
-from _fastx import fasta_raw_seqs, fastq_raw_seqs  # noqa: E402
+from _fastx import bgzf_compress, fasta_raw_seqs, fastq_raw_seqs  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -278,8 +278,39 @@ def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
         assert_stats_equal(stp, O.reduce_records(recs_fq, 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), ("parallel", threads))
     stp = nt.scan_file_parallel(ctx, fa, 31, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS, threads=8, batch_bytes=1 << 18)
     assert (stp["n_records"], stp["n_total"], stp["n_fwd"]) == (570, 718_007, 350_983)
-    with pytest.raises(nt.NtkError) as e:   # gzip streams are sequential: the parallel entry point refuses them
-        nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    # gzip through the parallel producer: the whole file (every member) is inflated into memory by libdeflate when that
+    # library can be loaded, then parsed in parallel; an in-memory gzip BUFFER is refused (a gzip stream is sequential)
+    seq_st = nt.scan_file(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 16)
+    multi = tmp_path / "multi.fq.gz"
+    fq_lines = open(fq, "rb").read().split(b"\n")
+    cut = (len(fq_lines) // 8) * 4
+    multi.write_bytes(gzip.compress(b"\n".join(fq_lines[:cut]) + b"\n") + gzip.compress(b"\n".join(fq_lines[cut:])))
+    try:
+        import ctypes
+        ctypes.CDLL("libdeflate.so.0")
+        have_libdeflate = True
+    except OSError:
+        have_libdeflate = False
+    if have_libdeflate:
+        bgzf = tmp_path / "blocks.fq.gz"   # block gzip: members located by their 'BC' size field and inflated in parallel
+        bgzf.write_bytes(bgzf_compress(open(fq, "rb").read(), block=20000))
+        assert gzip.decompress(bgzf.read_bytes()) == open(fq, "rb").read()
+        for path_ in (gz, multi, bgzf):
+            par = nt.scan_file_parallel(ctx, str(path_), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=4, batch_bytes=1 << 16)
+            assert_stats_equal(par, seq_st, f"gzip via the parallel producer: {path_.name}")
+            assert par["n_records"] == seq_st["n_records"]
+        bad = tmp_path / "bad.fq.gz"
+        blob = bytearray(gz.read_bytes()); blob[len(blob) // 2] ^= 0x55
+        bad.write_bytes(bytes(blob))
+        with pytest.raises(nt.NtkError) as e:   # corrupted stream (libdeflate verifies the CRC-32 of every member)
+            nt.scan_file_parallel(ctx, str(bad), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+        assert e.value.status == 8
+    else:
+        with pytest.raises(nt.NtkError) as e:
+            nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+        assert e.value.status == 6
+    with pytest.raises(nt.NtkError) as e:
+        nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, data=gz.read_bytes())
     assert e.value.status == 6
     # records longer than a whole batch go through a one-off batch of their own: batch_bytes is a knob, not a limit
     st = nt.scan_file(ctx, fa, 4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1024)

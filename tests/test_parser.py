@@ -263,3 +263,13 @@ def test_record_write_round_trip(golden_dir):
     out = io.BytesIO()
     nt.write_fastq(b"id", b"ACGT", None, out)
     assert out.getvalue() == b"@id\nACGT\n+\nIIII\n"
+
+
+def test_bgzf_through_the_streaming_reader(golden_dir, tmp_path):
+    """Block gzip is just concatenated members to the streaming reader (MultiGzDecoder, reference src/parser/mod.rs:95-108)."""
+    from _fastx import bgzf_compress
+    data = open(os.path.join(golden_dir, "28S.fasta"), "rb").read()
+    p = tmp_path / "28S.fasta.gz"
+    p.write_bytes(bgzf_compress(data, block=30000))
+    recs = list(nt.parse_fastx_file(str(p)))
+    assert len(recs) == 570 and sum(r.num_bases for r in recs) == 738_580
