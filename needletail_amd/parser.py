@@ -204,9 +204,10 @@ def parse_fastx_string(content) -> FastxReader:
 
 
 def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int = 0, batch_bytes: int = 16 << 20, w: int = 0,
-                       data: bytes = None, quality_cutoff: int = 0) -> dict:
-    """scan_file with one parser thread per file range (plain FASTA/FASTQ only; gzip streams are sequential -> scan_file).
-    `data` scans an in-memory buffer instead of a path."""
+                       data: bytes = None, quality_cutoff: int = 0, streaming_fallback: bool = True) -> dict:
+    """scan_file with one parser thread per file range.  Plain FASTA/FASTQ directly; a gzip file is inflated into memory first
+    (libdeflate; block gzip by all threads) and falls back to the streaming scan_file when that is not possible.
+    `data` scans an in-memory plain-text buffer instead of a path."""
     import os
     from .engine import result_to_dict  # noqa: F401
     threads = threads or min(os.cpu_count() or 1, 32)  # measured best 16-32 on a 256-thread host (tools/pipeline_bench.py)
@@ -217,6 +218,9 @@ def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int
         rc = L.lib().ntk_scan_buffer_parallel(ctx._h, data, len(data), C.byref(p), batch_bytes, threads, C.byref(nrec), C.byref(nb))
     else:
         rc = L.lib().ntk_scan_file_parallel(ctx._h, str(path).encode(), C.byref(p), batch_bytes, threads, C.byref(nrec), C.byref(nb))
+        if rc == 6 and streaming_fallback:
+            # a gzip file that cannot be inflated into memory (no libdeflate, or beyond the limit): the streaming reader
+            return scan_file(ctx, path, k, path_kind, pre, batch_bytes=batch_bytes, w=w, quality_cutoff=quality_cutoff)
     L.check(rc, "ntk_scan_file_parallel")
     out = ctx.accum_read()
     out["n_records"], out["n_bases"] = int(nrec.value), int(nb.value)
