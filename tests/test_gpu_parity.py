@@ -307,8 +307,9 @@ def test_scan_file_pipeline(ctx, golden_dir, tmp_path):
         assert e.value.status == 8
     else:
         with pytest.raises(nt.NtkError) as e:
-            nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+            nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, streaming_fallback=False)
         assert e.value.status == 6
+        assert_stats_equal(nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), seq_st, "fallback")
     with pytest.raises(nt.NtkError) as e:
         nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, data=gz.read_bytes())
     assert e.value.status == 6
