@@ -214,7 +214,7 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t b
 /* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into n_threads pieces,
  * each parsed by its own thread into its own pinned batches (record order across pieces is not preserved; the reduced
  * result does not depend on it).  A gzip stream is sequential: ntk_scan_buffer_parallel refuses it (NTK_ERR_UNSUPPORTED, use
- * ntk_scan_reader); ntk_scan_file_parallel inflates the whole file into memory first (all members) when libdeflate.so.0 can
+ * ntk_scan_reader; the same for bzip2 / xz / zstd); ntk_scan_file_parallel inflates the whole file into memory first (all members) when libdeflate.so.0 can
  * be loaded and the output stays under 16 GiB (NTK_GZ_INMEM_LIMIT_BYTES), and is NTK_ERR_UNSUPPORTED otherwise.
  * Parse errors return NTK_ERR_PARSE without position detail. */
 /* The cut points the parallel producer uses: cuts[0] = 0 <= cuts[1] <= ... <= cuts[n_pieces] = n, every cut a record start. */

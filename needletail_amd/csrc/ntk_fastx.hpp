@@ -5,14 +5,16 @@
 //
 // What is mirrored (and tested against the reference's own data files):
 //   * parse_fastx_reader's sniffing: fewer than 2 bytes -> EmptyFile; gzip magic 1F 8B -> concatenated-member inflate
-//     (MultiGzDecoder); first byte '>' -> FASTA, '@' -> FASTQ, else UnknownFormat   (reference src/parser/mod.rs:85-147)
+//     (MultiGzDecoder); 'BZ' -> bzip2, FD 37 -> xz, 28 B5 -> zstd (their run-time libraries are loaded on demand; an Io
+//     error when one is not installed); first byte '>' -> FASTA, '@' -> FASTQ, else UnknownFormat
+//     (reference src/parser/mod.rs:27-35,85-147)
 //   * FASTA: records split at "\n>", raw sequence = everything between the header's '\n' and the record's last '\n'
 //     (interior line breaks kept, one trailing '\r' trimmed); header without any newline at EOF -> UnexpectedEnd
 //     (reference src/parser/fasta.rs:55-63,196-243,291-367)
 //   * FASTQ: strict 4-line records, '@' / '+' checks, equal sequence/quality lengths, last record may lack its newline,
 //     trailing blank lines allowed, otherwise UnexpectedEnd   (reference src/parser/fastq.rs:155-187,240-285,335-355)
 //   * buffer policy: 64 KiB, doubling to 8 MiB, then +8 MiB steps (reference src/parser/utils.rs:8,24-30)
-// Not mirrored (out of scope): bz2/xz/zstd, header masking (record writers live in the host mirrors).
+// Not mirrored here: header masking and the record writers (they live in the host mirrors).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -21,6 +23,8 @@
 #include <vector>
 
 struct z_stream_s;
+
+namespace ntk { struct StreamDecoder; }
 
 namespace ntk {
 
@@ -70,6 +74,7 @@ private:
     const uint8_t *mem_ = nullptr; uint64_t mem_n_ = 0, mem_pos_ = 0;
     size_t read_raw(uint8_t *dst, size_t cap);
     // gzip layer
+    StreamDecoder *dec_ = nullptr;   // bzip2 / xz / zstd, through their run-time libraries
     bool gz_ = false; z_stream_s *zs_ = nullptr; std::vector<uint8_t> zin_; size_t zin_pos_ = 0, zin_len_ = 0; bool z_eof_ = false;
     size_t read_plain(uint8_t *dst, size_t cap);   // after optional inflate; 0 = EOF; (size_t)-1 = error
     // record buffer

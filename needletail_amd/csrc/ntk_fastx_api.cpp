@@ -259,7 +259,9 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
     if (n_records) *n_records = 0;
     if (n_bases) *n_bases = 0;
     if (n < 2) return NTK_ERR_PARSE;                       // EmptyFile (reference src/parser/mod.rs:88-91)
-    if (data[0] == 0x1F && data[1] == 0x8B) return NTK_ERR_UNSUPPORTED;  // gzip is a sequential stream: use ntk_scan_reader
+    // compressed streams (gzip, bzip2, xz, zstd) are sequential: use ntk_scan_reader
+    if ((data[0] == 0x1F && data[1] == 0x8B) || (data[0] == 0x42 && data[1] == 0x5A) || (data[0] == 0xFD && data[1] == 0x37) ||
+        (data[0] == 0x28 && data[1] == 0xB5)) return NTK_ERR_UNSUPPORTED;
     // a thread is only worth its two pinned batches if it has several batches of input to parse
     const uint64_t worth = n / (4 * batch_bytes) + 1;
     if (n_threads > worth) n_threads = (uint32_t)worth;

@@ -820,3 +820,24 @@ def test_minimizers_in_chunks(monkeypatch):
                 c.accum_reset()
                 c.minimizers_reduce_device(t, len(buf), k, w, path, nt.PRE_NORMALIZE if accept_u else nt.PRE_NONE)
                 assert_stats_equal(c.accum_read(), O.minimizers_reduce(buf, k, w, accept_u, tie_rc), (k, w, "chunked"))
+
+
+def test_compressed_inputs_through_the_pipeline(ctx, golden_dir, tmp_path):
+    """bzip2 / xz / zstd / gzip inputs (reference tests/test_compressed.rs data files and larger streams written here) through
+    parser -> pinned batches -> scan give the plain file's result."""
+    import bz2
+    import lzma
+    plain = nt.scan_file(ctx, os.path.join(golden_dir, "test.fa"), 3, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    for ext in ("gz", "bz2", "xz", "zst"):
+        st = nt.scan_file(ctx, os.path.join(golden_dir, "test.fa." + ext), 3, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+        assert_stats_equal(st, plain, ext)
+        assert st["n_records"] == 2 and st["n_total"] > 0
+    fa = os.path.join(golden_dir, "28S.fasta")
+    data = open(fa, "rb").read()
+    want = nt.scan_file(ctx, fa, 21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS)
+    for name, blob in (("x.bz2", bz2.compress(data)), ("x.xz", lzma.compress(data))):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        assert_stats_equal(nt.scan_file(ctx, str(p), 21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS, batch_bytes=1 << 16), want, name)
+        # the parallel entry point cannot split these streams: it falls back to the streaming reader
+        assert_stats_equal(nt.scan_file_parallel(ctx, str(p), 21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS), want, name + " parallel")

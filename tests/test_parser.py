@@ -273,3 +273,26 @@ def test_bgzf_through_the_streaming_reader(golden_dir, tmp_path):
     p.write_bytes(bgzf_compress(data, block=30000))
     recs = list(nt.parse_fastx_file(str(p)))
     assert len(recs) == 570 and sum(r.num_bases for r in recs) == 738_580
+
+
+def test_compressed_files_are_read_automatically(golden_dir, tmp_path):
+    """reference tests/test_compressed.rs:12-38: the same two records from test.fa.{gz,bz2,xz,zst} (the reference's own data
+    files), plus larger bzip2 / xz streams written here (several reader-buffer refills, concatenated records)."""
+    import bz2
+    import lzma
+    for ext in ("gz", "bz2", "xz", "zst"):
+        recs = list(nt.parse_fastx_file(os.path.join(golden_dir, "test.fa." + ext)))
+        assert [(r.id, r.raw_seq, r.qual) for r in recs] == [("test", b"AGCTGATCGA", None), ("test2", b"TAGC", None)], ext
+        assert all(r.is_fasta() for r in recs)
+    data = open(os.path.join(golden_dir, "28S.fasta"), "rb").read()
+    for name, blob in (("x.bz2", bz2.compress(data)), ("x.xz", lzma.compress(data)), ("x9.bz2", bz2.compress(data * 3, 1))):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        recs = list(nt.parse_fastx_file(str(p)))
+        mult = 3 if name == "x9.bz2" else 1
+        assert len(recs) == 570 * mult and sum(r.num_bases for r in recs) == 738_580 * mult, name
+    bad = tmp_path / "bad.bz2"
+    blob = bytearray(bz2.compress(data)); blob[len(blob) // 2] ^= 0xFF
+    bad.write_bytes(bytes(blob))
+    with pytest.raises(nt.NeedletailError):
+        list(nt.parse_fastx_file(str(bad)))
