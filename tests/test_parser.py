@@ -6,6 +6,8 @@ import os
 
 import numpy as np
 import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
 
 import needletail_amd as nt
 from _fastx import fasta_raw_seqs, fastq_raw_seqs
@@ -296,3 +298,71 @@ def test_compressed_files_are_read_automatically(golden_dir, tmp_path):
     bad.write_bytes(bytes(blob))
     with pytest.raises(nt.NeedletailError):
         list(nt.parse_fastx_file(str(bad)))
+
+
+# ---- randomised differential test against a pure-Python model of the reference's record rules -------------------
+
+def _model_fasta(data: bytes):
+    """reference src/parser/fasta.rs:196-243: a record runs to the last line feed before the next line starting with '>'."""
+    out, starts = [], [0] + [i + 1 for i in range(len(data) - 1) if data[i] == 10 and data[i + 1] == ord(">")]
+    line = 1
+    for a, b in zip(starts, starts[1:] + [len(data)]):
+        rec = data[a:b]
+        body = rec[:-1] if rec.endswith(b"\n") else rec          # the record's last line end is not part of it
+        first = body.find(b"\n")
+        if first < 0:
+            hdr, seq = body, b""
+        else:
+            hdr, seq = body[:first], body[first + 1:]
+        if hdr.endswith(b"\r"):
+            hdr = hdr[:-1]
+        if seq.endswith(b"\r"):
+            seq = seq[:-1]
+        out.append((hdr[1:], seq, None, line, len(seq) - seq.count(b"\n") - seq.count(b"\r")))
+        line += rec.count(b"\n") + (0 if rec.endswith(b"\n") else 1)
+    return out
+
+
+def _model_fastq(data: bytes):
+    lines = data.split(b"\n")
+    while lines and lines[-1].rstrip(b"\r") == b"":
+        lines.pop()
+    out = []
+    for i in range(0, len(lines), 4):
+        h, s, _, q = [x[:-1] if x.endswith(b"\r") else x for x in lines[i:i + 4]]
+        out.append((h[1:], s, q, i + 1, len(s)))
+    return out
+
+
+@settings(max_examples=120, deadline=None)
+@given(st.data())
+def test_reader_matches_model_on_random_files(data):
+    rng = np.random.default_rng(data.draw(st.integers(0, 2**32 - 1)))
+    fastq = data.draw(st.booleans())
+    nl = b"\r\n" if data.draw(st.booleans()) else b"\n"
+    n_rec = data.draw(st.integers(1, 40))
+    big = data.draw(st.booleans())
+    parts = []
+    for r in range(n_rec):
+        L = int(rng.integers(0, 90_000 if (big and r % 7 == 0) else 300))
+        seq = bytes(np.frombuffer(b"ACGTNacgt>@+", dtype=np.uint8)[rng.integers(0, 9 if not fastq else 9, L)])
+        hdr = b"id%d >odd @hdr + tab\t" % r
+        if fastq:
+            qual = bytes(np.frombuffer(b"IJ@>+!~", dtype=np.uint8)[rng.integers(0, 7, L)])   # '@', '>' and '+' are legal here
+            parts.append(b"@" + hdr + nl + seq + nl + b"+" + (hdr if r % 2 else b"") + nl + qual + nl)
+        else:
+            w = int(rng.integers(1, 120))
+            body = nl.join(seq[j:j + w] for j in range(0, L, w))
+            parts.append(b">" + hdr + nl + body + (nl if L else b""))
+    text = b"".join(parts)
+    tail = data.draw(st.sampled_from(["keep", "strip", "blank"]))
+    if tail == "strip" and text.endswith(nl) and not (not fastq and text.endswith(nl) and parts[-1].count(b"\n") == 1):
+        text = text[: -len(nl)]
+    elif tail == "blank" and fastq:
+        text += nl + nl
+    model = _model_fastq(text) if fastq else _model_fasta(text)
+    got = [(rid, seq, qual, line, nb) for rid, seq, qual, line, nb in recs(text)]
+    assert got == model
+    # gzip on top must not change anything
+    if len(text) < 200_000:
+        assert [(a, b, c, d, e) for a, b, c, d, e in recs(gzip.compress(text))] == model
