@@ -42,7 +42,8 @@ int main(int argc, char **argv)
 #endif
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     std::vector<float> ts;
-    for (int it = 0; it < iters + 2; it++) {
+    const int warm = 300;  // ~0.2 s of load before timing: steady-state clocks
+    for (int it = 0; it < iters + warm; it++) {
         CHK(hipMemsetAsync(d_acc, 0, (8 + kHistBins + 64) * 8, 0));
         CHK(hipMemsetAsync(d_work, 0, 512, 0));
         CHK(hipEventRecord(e0, 0));
@@ -62,7 +63,7 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, 0, (const uint32_t *)d_ph, (const uint64_t *)d_ps, blocks, d_acc);
         CHK(hipEventSynchronize(e1));
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-        if (it >= 2) ts.push_back(ms);
+        if (it >= warm) ts.push_back(ms);
     }
     CHK(hipDeviceSynchronize());
     std::vector<uint64_t> acc(8 + kHistBins + 64);

@@ -23,7 +23,7 @@ ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 ctx.synth_reads_device(0x5EED0002, 0, args.reads, L, 1, seq)
 out = {}
 for name, kw in (("plain", {}), ("quality", {"d_qual": qual, "quality_cutoff": args.cutoff})):
-    for _ in range(3):
+    for _ in range(400):   # ~0.3 s of load first: the clocks need ~40 ms to reach their steady state (see bench.py --preheat-ms)
         ctx.accum_reset(); ctx.reduce_device(seq, n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, **kw)
     torch.cuda.synchronize()
     ctx.scan_time_ms(); ctx.enable_timing(True)
