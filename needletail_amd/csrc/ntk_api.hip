@@ -175,8 +175,8 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 }
 
 // The scan kernel build for a mode: k-specialised builds where they exist, the runtime-k build otherwise.
-// Reduce mode: every 17 <= k <= 32 runs the scalar-validity variant (k is a template constant there: the window-mask
-// algebra indexes lane masks by k), -10..15 % against the generic runtime-k build; with a quality stream only k = 21 and
+// Reduce mode, canonical paths: every k runs a scalar-validity variant (k is a template constant there: the window-mask
+// algebra indexes lane masks by k; 64-bit values for k >= 17, 32-bit for k <= 16), -10..20 % against the generic runtime-k build; with a quality stream only k = 21 and
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
 template <bool REDUCE, bool QM>
@@ -188,6 +188,12 @@ const void *pick_scan(const Mode &m, uint32_t k)
 #define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
     NTK_PICK_SV4(17) NTK_PICK_SV4(18) NTK_PICK_SV4(19) NTK_PICK_SV4(20) NTK_PICK_SV4(21) NTK_PICK_SV4(22) NTK_PICK_SV4(23) NTK_PICK_SV4(24)
     NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
+#undef NTK_PICK_SV
+#define NTK_PICK_SV(KF, T, U)                                                                       \
+    if (REDUCE && !QM && m.kw == 1 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \
+        return (const void *)&scan_kernel<1, true, T, U, true, KF, true>;
+    NTK_PICK_SV4(1) NTK_PICK_SV4(2) NTK_PICK_SV4(3) NTK_PICK_SV4(4) NTK_PICK_SV4(5) NTK_PICK_SV4(6) NTK_PICK_SV4(7) NTK_PICK_SV4(8)
+    NTK_PICK_SV4(9) NTK_PICK_SV4(10) NTK_PICK_SV4(11) NTK_PICK_SV4(12) NTK_PICK_SV4(13) NTK_PICK_SV4(14) NTK_PICK_SV4(15) NTK_PICK_SV4(16)
 #undef NTK_PICK_SV4
 #undef NTK_PICK_SV
 #define NTK_PICK_SVQ(KF, T, U)                                                                      \

@@ -159,9 +159,22 @@ struct DevMasks {
 #pragma unroll
             for (int i = 0; i < 16; i++) B[i] &= __builtin_amdgcn_ballot_w64(lane_base + i < (int64_t)n_bytes);
         }
-        window_masks<K>(B, V);
+        if constexpr (K >= 17) window_masks<K>(B, V); else window_masks1<K>(B, V);
     }
 
+    // k <= 16: a 32-bit value
+    template <int K, class S>
+    __device__ __forceinline__ void emit1(S &sink, int j, bool take_fwd, uint32_t v)
+    {
+        uint32_t hi = 0;
+        // histogram byte offset: (v >> (2K - 12)) * 4 = one shift + one AND for K >= 7, v * 4 below (the value is the bin)
+        uint32_t off = K >= 7 ? ((v >> ((2 * K - 14) & 31)) & 0x3FFCu) : (v << 2);
+        asm volatile("" : "+v"(v), "+v"(off));
+        const uint64_t fwd = __builtin_amdgcn_ballot_w64(take_fwd);
+        if (__builtin_amdgcn_inverse_ballot_w64(V[j])) sink.add(hi, v, off);
+        if (__builtin_amdgcn_inverse_ballot_w64(V[j] & fwd))
+            __hip_atomic_fetch_add(fwd_cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     // (t, lo): top and low 32 bits of the chosen value (ntk_tile.hpp lane_tile_sv)
     template <int K, class S>
     __device__ __forceinline__ void emit(S &sink, int j, bool take_fwd, uint32_t t, uint32_t lo)
@@ -192,8 +205,9 @@ struct DevMasks {
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0, bool SV = false, bool QM = false>
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
-    static_assert(!SV || (REDUCE && KW == 2 && KFIX >= 17), "the scalar-validity path is a k-specialised reduce path");
-    using Sink = typename std::conditional<SV, ReduceSinkSV<(KFIX >= 17 ? KFIX : 17)>, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
+    static_assert(!SV || (REDUCE && ((KW == 2 && KFIX >= 17 && KFIX <= 32) || (KW == 1 && KFIX >= 1 && KFIX <= 16))),
+                  "the scalar-validity path is a k-specialised reduce path");
+    using Sink = typename std::conditional<SV, ReduceSinkSV<(KFIX >= 1 ? KFIX : 17)>, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
     __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
     __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
     __shared__ uint32_t s_nfwd[SV ? 1024 : 1];  // sv builds: per-thread forward-strand counters
@@ -283,7 +297,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
             if constexpr (SV) {
                 const EncSV en = encode16_sv<ACCEPT_U>(raw);
                 mp.template compute<KFIX>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-                lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
+                if constexpr (KW == 2) lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
+                else lane_tile_sv1<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
             } else {
                 lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, raw,
                                                              (int64_t)tile_byte - 32 + lane * 16, halo_lane, tail);

@@ -435,4 +435,53 @@ NTK_HD void lane_tile_sv(Sink &sink, XL &xl, MP &mp, const EncSV &en)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "sv" variant for k <= 16 (32-bit values).  The window ending at byte j covers bytes j-K+1 .. j: inside the lane when
+// j >= K-1, else reaching into the previous lane (never further: K <= 16).  With E = [previous lane's 16 masks shifted
+// one lane up, own 16 masks] the validity masks are a sliding AND of width K over E, built by doubling (widths 1, 2, 4,
+// 8) and one overlap step; only the entries a later level reads are generated (everything is unrolled).
+// ---------------------------------------------------------------------------------------------
+template <int K>
+NTK_HD void window_masks1(const uint64_t (&G)[16], uint64_t (&OK)[16])
+{
+    static_assert(K >= 1 && K <= 16, "k <= 16 variant");
+    constexpr int P = K >= 16 ? 16 : (K >= 8 ? 8 : (K >= 4 ? 4 : (K >= 2 ? 2 : 1)));  // largest power of two <= K
+    uint64_t A[32];  // A[16 + i] = own byte i, A[i] = previous lane's byte i (a lane shift is a 1-bit shift of the mask)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { A[16 + i] = G[i]; A[i] = G[i] << 1; }
+    A[16] &= ~3ull;  // halo lanes 0/1 emit nothing: cleared in own byte 0 ...
+#pragma unroll
+    for (int w = 1; w < P; w *= 2) {   // A[e] becomes the AND of the 2w entries ending at e
+#pragma unroll
+        for (int e = 31; e >= 2 * w - 1; e--) A[e] &= A[e - w];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint64_t v = A[16 + j];
+        if (K > P) v &= A[16 + j - (K - P)];
+        OK[j] = v;
+    }
+    // ... and, since own byte 0 is only part of windows ending at j <= K-1, in the remaining positions explicitly
+#pragma unroll
+    for (int j = K; j < 16; j++) OK[j] &= ~3ull;
+}
+
+template <bool CANON, bool TIE_RC, int K, class Sink, class XL, class MP>
+NTK_HD void lane_tile_sv1(Sink &sink, XL &xl, MP &mp, const EncSV &en)
+{
+    constexpr int S = 32 - 2 * K;
+    constexpr uint32_t mask = K == 16 ? 0xFFFFFFFFu : ((1u << ((2 * K) & 31)) - 1u);
+    const uint32_t c1 = xl.prev(kSlotCode, en.code);
+    const uint32_t r1 = xl.prev(kSlotRcode, en.rcode);
+    const uint32_t Q[2] = {S ? en.rcode >> S : en.rcode, alignbit(en.rcode, r1, S)};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t fl = (j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j)) & mask;
+        const uint32_t rl = win32(Q, 2 * (15 - j)) & mask;
+        bool take_fwd = true;
+        if (CANON) take_fwd = TIE_RC ? (fl < rl) : (fl <= rl);
+        mp.template emit1<K>(sink, j, take_fwd, take_fwd ? fl : rl);
+    }
+}
+
 }  // namespace ntk

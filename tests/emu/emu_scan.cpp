@@ -103,6 +103,8 @@ struct EmuMP {
     uint64_t V[16];
     int lane = 0;
     template <int K, class S>
+    void emit1(S &sink, int j, bool take_fwd, uint32_t v) { sink.emit(j, (V[j] >> lane) & 1, take_fwd, 0u, v); }  // k <= 16
+    template <int K, class S>
     void emit(S &sink, int j, bool take_fwd, uint32_t t, uint32_t lo)  // (t, lo): top and low 32 bits of the value
     {
         sink.emit(j, (V[j] >> lane) & 1, take_fwd, K == 32 ? t : t >> (64 - 2 * K), lo);
@@ -113,7 +115,7 @@ template <bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX>
 void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st)
 {
     const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
-    HostSink<2> sink;
+    HostSink<(KFIX >= 17 ? 2 : 1)> sink;
     sink.st = st; sink.bin_shift = a.bin_shift; sink.values = nullptr; sink.valid16 = nullptr; sink.rc16 = nullptr; sink.n_bytes = n;
     for (uint64_t t = 0; t < n_tiles; t++) {
         const bool tail = (t + 1) * kTileStride > n;
@@ -129,13 +131,14 @@ void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostS
             }
         }
         EmuMP mp;
-        window_masks<KFIX>(G, mp.V);
+        if constexpr (KFIX >= 17) window_masks<KFIX>(G, mp.V); else window_masks1<KFIX>(G, mp.V);
         EmuXL xl;
         for (int l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             mp.lane = l;
             sink.skip = true;
-            lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en[l]);
+            if constexpr (KFIX >= 17) lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en[l]);
+            else lane_tile_sv1<CANON, TIE_RC, KFIX>(sink, xl, mp, en[l]);
         }
     }
 }
@@ -159,9 +162,11 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     // tiles_per_wave doubles as a switch in this emulation: an odd value selects the k-specialised build when one exists
     const bool fix = (tiles_per_wave & 1) && canon && (k == 21 || k == 31);
     // bit 1 of tiles_per_wave: the scalar-validity variant (statistics only), built for every 17 <= k <= 32 like the product
-    const bool sv = (tiles_per_wave & 2) && canon && k >= 17 && !values;
+    const bool sv = (tiles_per_wave & 2) && canon && !values;
 #define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
 #define EMU_SV4(KF) EMU_SV(KF, false, false) EMU_SV(KF, false, true) EMU_SV(KF, true, false) EMU_SV(KF, true, true)
+    EMU_SV4(1) EMU_SV4(2) EMU_SV4(3) EMU_SV4(4) EMU_SV4(5) EMU_SV4(6) EMU_SV4(7) EMU_SV4(8)
+    EMU_SV4(9) EMU_SV4(10) EMU_SV4(11) EMU_SV4(12) EMU_SV4(13) EMU_SV4(14) EMU_SV4(15) EMU_SV4(16)
     EMU_SV4(17) EMU_SV4(18) EMU_SV4(19) EMU_SV4(20) EMU_SV4(21) EMU_SV4(22) EMU_SV4(23) EMU_SV4(24)
     EMU_SV4(25) EMU_SV4(26) EMU_SV4(27) EMU_SV4(28) EMU_SV4(29) EMU_SV4(30) EMU_SV4(31) EMU_SV4(32)
 #define EMU_FIX(KF, T, U) if (fix && k == KF && !!tie_rc == T && !!accept_u == U) { run<2, true, T, U, KF>(buf, n, n_padded, a, st, values, valid16, rc16); } else
