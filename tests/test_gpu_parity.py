@@ -841,3 +841,33 @@ def test_compressed_inputs_through_the_pipeline(ctx, golden_dir, tmp_path):
         assert_stats_equal(nt.scan_file(ctx, str(p), 21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS, batch_bytes=1 << 16), want, name)
         # the parallel entry point cannot split these streams: it falls back to the streaming reader
         assert_stats_equal(nt.scan_file_parallel(ctx, str(p), 21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS), want, name + " parallel")
+
+
+def test_scan_larger_than_one_launch(ctx):
+    """A 35 GB resident batch: beyond 2^25 tiles (33 GB) the scan is split into several launches with 32-bit launch-relative
+    tile indices.  The result over the whole buffer must equal the sum of the results over two single-launch halves cut at a
+    record boundary, and a prefix sample must match the oracle."""
+    free, _ = torch.cuda.mem_get_info()
+    reads, L = 232_000_000, 150
+    n = reads * (L + 1)
+    if free < n + (4 << 30):
+        pytest.skip("not enough free device memory for the 35 GB case")
+    assert n > (8 << 22) * 992
+    seq = torch.empty(n + 4096, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0004, 0, reads, L, 1, seq)
+    k, path, pre = 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE
+    ctx.accum_reset(); ctx.reduce_device(seq, n, k, path, pre); whole = ctx.accum_read()
+    half = (reads // 2) * (L + 1)                      # a record boundary, a multiple of 16 bytes? make it one
+    half -= half % (16 * (L + 1))
+    ctx.accum_reset(); ctx.reduce_device(seq, half, k, path, pre); a = ctx.accum_read()
+    ctx.accum_reset(); ctx.reduce_device(seq[half:], n - half, k, path, pre); b = ctx.accum_read()
+    for key in ("n_total", "n_fwd", "n_rc"):
+        assert whole[key] == a[key] + b[key], key
+    assert whole["sum"] == (a["sum"] + b["sum"]) % (1 << 64) and whole["xor"] == a["xor"] ^ b["xor"]
+    assert np.array_equal(whole["hist"], a["hist"] + b["hist"])
+    assert whole["n_total"] > reads * 100
+    sample = 20_000
+    ctx.accum_reset(); ctx.reduce_device(seq, sample * (L + 1), k, path, pre)
+    assert_stats_equal(ctx.accum_read(), O.reduce_fused(O.synth_reads(0x5EED0004, 0, sample, L, 1), k, True, True, True), "prefix")
+    del seq
+    torch.cuda.empty_cache()
