@@ -869,5 +869,19 @@ def test_scan_larger_than_one_launch(ctx):
     sample = 20_000
     ctx.accum_reset(); ctx.reduce_device(seq, sample * (L + 1), k, path, pre)
     assert_stats_equal(ctx.accum_read(), O.reduce_fused(O.synth_reads(0x5EED0004, 0, sample, L, 1), k, True, True, True), "prefix")
+    # windowed minimizers over 6 GB (24 chunks of 256 MiB with left context, byte offsets beyond 2^32): linear over a cut at
+    # a record boundary too, and equal to the oracle on the prefix sample
+    n6 = 40_000_000 * (L + 1)
+    h6 = 17_000_000 * (L + 1)
+    h6 -= h6 % (16 * (L + 1))
+    ctx.accum_reset(); ctx.reduce_device(seq, n6, k, path, pre, w=11); mw = ctx.accum_read()
+    ctx.accum_reset(); ctx.reduce_device(seq, h6, k, path, pre, w=11); ma = ctx.accum_read()
+    ctx.accum_reset(); ctx.reduce_device(seq[h6:], n6 - h6, k, path, pre, w=11); mb = ctx.accum_read()
+    for key in ("n_total", "n_fwd", "n_rc"):
+        assert mw[key] == ma[key] + mb[key], ("minimizers", key)
+    assert mw["sum"] == (ma["sum"] + mb["sum"]) % (1 << 64) and mw["xor"] == ma["xor"] ^ mb["xor"]
+    assert np.array_equal(mw["hist"], ma["hist"] + mb["hist"]) and mw["n_total"] > 40_000_000 * 100
+    ctx.accum_reset(); ctx.reduce_device(seq, sample * (L + 1), k, path, pre, w=11)
+    assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(O.synth_reads(0x5EED0004, 0, sample, L, 1), k, 11, True, True), "minimizer prefix")
     del seq
     torch.cuda.empty_cache()
