@@ -282,7 +282,7 @@ def main():
             "result": {"n_total": res["n_total"], "n_fwd": res["n_fwd"], "sum": hex(res["sum"]), "xor": hex(res["xor"])},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ntk::scan_kernel<2,true,true,true,true,21,true>" if args.k == 21 else "ntk::scan_kernel<KW,true,true,true,true,...>",
+                "kernel": f"ntk::scan_kernel<{2 if args.k > 16 else 1}, true, true, true, true, {args.k}, true, false>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
