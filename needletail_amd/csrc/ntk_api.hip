@@ -891,9 +891,21 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
         uint64_t *d_val = (uint64_t *)c->scratch[3].p;
         uint16_t *d_v16 = (uint16_t *)c->scratch[4].p, *d_r16 = (uint16_t *)c->scratch[5].p;
         if ((rc = run_scan(c, d_seq + start, n_sub, p, m, false, d_val, d_v16, d_r16, d_qual ? d_qual + start : nullptr))) return rc;
-        hipLaunchKernelGGL(window_min_reduce_kernel, dim3(blocks), dim3(kWmThreads), 0, c->stream, (const uint64_t *)d_val,
-                           (const uint16_t *)d_v16, (const uint16_t *)d_r16, n_sub, w, a.bin_shift, c->d_part_hist,
-                           c->d_part_scalars, c0 - start);
+#define NTK_WM(WW)                                                                                                    \
+    case WW:                                                                                                          \
+        hipLaunchKernelGGL(window_min_reduce_kernel<WW>, dim3(blocks), dim3(kWmThreads), 0, c->stream, (const uint64_t *)d_val, \
+                           (const uint16_t *)d_v16, (const uint16_t *)d_r16, n_sub, w, a.bin_shift, c->d_part_hist,    \
+                           c->d_part_scalars, c0 - start);                                                            \
+        break;
+        switch (w <= 16 ? w : 0u) {   // compile-time windows up to 16 (register van Herk), the run-time walk otherwise
+            NTK_WM(2) NTK_WM(3) NTK_WM(4) NTK_WM(5) NTK_WM(6) NTK_WM(7) NTK_WM(8) NTK_WM(9) NTK_WM(10) NTK_WM(11) NTK_WM(12)
+            NTK_WM(13) NTK_WM(14) NTK_WM(15) NTK_WM(16)
+        default:
+            hipLaunchKernelGGL(window_min_reduce_kernel<0>, dim3(blocks), dim3(kWmThreads), 0, c->stream, (const uint64_t *)d_val,
+                               (const uint16_t *)d_v16, (const uint16_t *)d_r16, n_sub, w, a.bin_shift, c->d_part_hist,
+                               c->d_part_scalars, c0 - start);
+        }
+#undef NTK_WM
         hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
                            (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc);
         HIPCHK(hipGetLastError());

@@ -545,6 +545,12 @@ __device__ __forceinline__ bool wm_all_set(const uint32_t *bits, uint32_t start,
     return true;
 }
 
+// W = 0: window size at run time (one LDS walk per window).  2 <= W <= 16: compile-time window, register van Herk - a thread
+// takes a group of B = min(W-1, 4) consecutive window ends, loads the B+W-1 values they cover once, builds the running
+// minimum of the first B values from the right (ties move left) and of the rest from the left (ties stay left) in
+// registers, and every window is min(left part, right part) with ties to the left part: (2B+W-3)/B compare-selects and
+// (B+W-1)/B LDS reads per window instead of W-1 and W.
+template <int W>
 __global__ __launch_bounds__(kWmThreads) void window_min_reduce_kernel(const uint64_t *values, const uint16_t *valid16, const uint16_t *rc16,
                                                                        uint64_t n, uint32_t w, uint32_t bin_shift,
                                                                        uint32_t *part_hist, uint64_t *part_scalars,
@@ -562,23 +568,78 @@ __global__ __launch_bounds__(kWmThreads) void window_min_reduce_kernel(const uin
     const uint64_t n_tiles = (n + kWmTile - 1) / kWmTile;
     const uint32_t span = kWmTile + halo;
     uint64_t sum = 0, xr = 0, nv = 0, nf = 0;
-    for (uint64_t tile = blockIdx.x + first_end / kWmTile; tile < n_tiles; tile += gridDim.x) {
+    // The next tile's values and flag words are fetched into registers while the current tile is processed out of LDS
+    // (one global round trip per tile would otherwise sit between the two barriers of every tile).
+    constexpr int kPer = (kWmTile + kWmMaxHalo + kWmThreads - 1) / kWmThreads;   // values per thread per tile (9)
+    uint64_t pv[kPer];
+    uint32_t pb[2] = {0, 0};   // this thread's word of the valid / rc flag planes (threads 0 .. span/32)
+    auto fetch = [&](uint64_t tile) {
         const int64_t region = (int64_t)(tile * kWmTile) - halo;   // first position held in LDS (may be negative)
-        __syncthreads();   // the previous tile's readers are done (and the histogram is zeroed)
-        for (uint32_t q = threadIdx.x; q < span; q += kWmThreads) {
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const uint32_t q = threadIdx.x + j * kWmThreads;
             const int64_t e = region + q;
-            s_val[q] = (e >= 0 && (uint64_t)e < (n16 << 4)) ? values[e] : 0ull;
+            pv[j] = (q < span && e >= 0 && (uint64_t)e < (n16 << 4)) ? values[e] : 0ull;
         }
-        for (uint32_t i = threadIdx.x; i < (span + 31) / 32; i += kWmThreads) {
-            const int64_t w16 = (region >> 4) + 2 * (int64_t)i;   // region is a multiple of 16
+        if (threadIdx.x < (span + 31) / 32) {
+            const int64_t w16 = (region >> 4) + 2 * (int64_t)threadIdx.x;   // region is a multiple of 16
             uint32_t v0 = 0, v1 = 0, r0 = 0, r1 = 0;
             if (w16 >= 0 && (uint64_t)w16 < n16) { v0 = valid16[w16]; r0 = rc16[w16]; }
             if (w16 + 1 >= 0 && (uint64_t)(w16 + 1) < n16) { v1 = valid16[w16 + 1]; r1 = rc16[w16 + 1]; }
             // plane words are MSB-first (bit 15 - e % 16); LDS words are LSB-first (bit = position % 32)
-            s_vbits[i] = (__brev(v0) >> 16) | (__brev(v1) & 0xFFFF0000u);
-            s_rbits[i] = (__brev(r0) >> 16) | (__brev(r1) & 0xFFFF0000u);
+            pb[0] = (__brev(v0) >> 16) | (__brev(v1) & 0xFFFF0000u);
+            pb[1] = (__brev(r0) >> 16) | (__brev(r1) & 0xFFFF0000u);
         }
+    };
+    const uint64_t tile0 = blockIdx.x + first_end / kWmTile;
+    if (tile0 < n_tiles) fetch(tile0);
+    for (uint64_t tile = tile0; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();   // the previous tile's readers are done (and the histogram is zeroed)
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const uint32_t q = threadIdx.x + j * kWmThreads;
+            if (q < span) s_val[q] = pv[j];
+        }
+        if (threadIdx.x < (span + 31) / 32) { s_vbits[threadIdx.x] = pb[0]; s_rbits[threadIdx.x] = pb[1]; }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);   // in flight while this tile is processed
+        if constexpr (W >= 2) {
+            constexpr int B = W - 1 < 4 ? W - 1 : 4;          // window ends per group (more would only cost registers)
+            constexpr int Z = B + W - 1;                      // values a group covers
+            constexpr uint32_t n_groups = (kWmTile + B - 1) / B;
+#pragma unroll 1
+            for (uint32_t g = threadIdx.x; g < n_groups; g += kWmThreads) {
+                const uint32_t p0 = g * B;                       // first window end of the group, tile-relative
+                if (tile * kWmTile + p0 >= n) break;
+                const uint32_t base = halo + p0 - (W - 1);       // LDS index of z[0]; window i of the group is z[i .. i+W-1]
+                uint64_t z[Z];
+                uint32_t zi[Z];
+#pragma unroll
+                for (int i = 0; i < Z; i++) {
+                    const uint32_t q = base + i < span ? base + i : span - 1;   // past the tile: not used by a counted window
+                    z[i] = s_val[q]; zi[i] = q;
+                }
+#pragma unroll
+                for (int i = B - 2; i >= 0; i--)                 // left part z[0..B-1]: running minimum from its right end
+                    if (!(z[i] <= z[i + 1])) { z[i] = z[i + 1]; zi[i] = zi[i + 1]; }
+#pragma unroll
+                for (int j = B + 1; j < Z; j++)                  // right part z[B..Z-1]: running minimum from its left end
+                    if (!(z[j] < z[j - 1])) { z[j] = z[j - 1]; zi[j] = zi[j - 1]; }
+#pragma unroll
+                for (int i = 0; i < B; i++) {                    // window i = z[i..B-1] + z[B..i+W-1]
+                    const uint32_t pos = p0 + i;
+                    const uint64_t e = tile * kWmTile + pos;
+                    if (pos >= (uint32_t)kWmTile || e >= n || e < first_end) continue;
+                    if (!wm_all_set(s_vbits, base + i, W)) continue;
+                    const bool right = z[i + W - 1] < z[i];      // tie: the older (left) part wins
+                    const uint64_t best = right ? z[i + W - 1] : z[i];
+                    const uint32_t at = right ? zi[i + W - 1] : zi[i];
+                    const uint32_t flag = (s_rbits[at >> 5] >> (at & 31u)) & 1u;
+                    sum += best; xr ^= best; nv++; nf += flag ? 0 : 1;
+                    atomicAdd(&s_hist[(uint32_t)(best >> bin_shift)], 1u);
+                }
+            }
+        } else {
 #pragma unroll 1
         for (uint32_t pos = threadIdx.x; pos < (uint32_t)kWmTile; pos += kWmThreads) {
             if (tile * kWmTile + pos >= n) break;
@@ -595,6 +656,7 @@ __global__ __launch_bounds__(kWmThreads) void window_min_reduce_kernel(const uin
             const uint32_t flag = (s_rbits[at >> 5] >> (at & 31u)) & 1u;
             sum += best; xr ^= best; nv++; nf += flag ? 0 : 1;
             atomicAdd(&s_hist[(uint32_t)(best >> bin_shift)], 1u);
+        }
         }
     }
 #pragma unroll
