@@ -10,11 +10,12 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # property tests draw the same examples on every run (a round-end run must not depend on luck); explore other examples with
-# `pytest --hypothesis-seed=N`, which overrides this
+# NTK_HYPOTHESIS_RANDOM=1 (fresh random examples every run)
 try:
     from hypothesis import settings as _hs
     _hs.register_profile("deterministic", derandomize=True, deadline=None)
-    _hs.load_profile("deterministic")
+    if not os.environ.get("NTK_HYPOTHESIS_RANDOM"):
+        _hs.load_profile("deterministic")
 except ImportError:
     pass
 
