@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--n-per-1024", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=0)
-    ap.add_argument("--threads", type=int, default=512)
+    ap.add_argument("--threads", type=int, default=0, help="threads per block (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--no-verify", action="store_true")
@@ -275,14 +275,15 @@ def main():
                 "outputs": "n_total,n_fwd,n_rc,4096-bin prefix histogram,sum64,xor64",
                 "parallelism": f"records sharded over {world} GPU(s), one RCCL all-reduce per step" if world > 1
                                else "single GPU",
-                "launch": {"blocks": args.blocks or "auto", "threads": args.threads},
+                "launch": {"blocks": args.blocks or "auto", "threads": args.threads or "auto"},
                 **({"test_mode": f"{args.backend} backend, all ranks on cuda:0 - NOT a measurement"}
                    if (args.single_device or args.backend != "nccl") else {}),
             },
             "result": {"n_total": res["n_total"], "n_fwd": res["n_fwd"], "sum": hex(res["sum"]), "xor": hex(res["xor"])},
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"ntk::scan_kernel<{2 if args.k > 16 else 1}, true, true, true, true, {args.k}, true, false>",
+                "kernel": (f"ntk::scan2_kernel<{args.k}, true, true, false, 14>" if args.k > 16
+                           else f"ntk::scan_kernel<1, true, true, true, true, {args.k}, true, false>"),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -110,7 +110,8 @@ int ntk_ctx_create(int device, ntk_ctx **out);
 int ntk_ctx_create_on_stream(int device, void *hip_stream, ntk_ctx **out);
 void ntk_ctx_destroy(ntk_ctx *ctx);
 int ntk_ctx_synchronize(ntk_ctx *ctx);
-/* Launch geometry of the scan kernel: blocks (0 = auto: resident grid) x threads (256/512/1024; default 512). */
+/* Launch geometry of the scan kernel: blocks (0 = auto: the resident grid) x threads per block (a multiple of 64 up to
+ * 1024; 0 = auto: 768 for the canonical 17 <= k <= 32 reduce builds, 512 otherwise). */
 int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
 /* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */

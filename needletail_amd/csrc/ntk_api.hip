@@ -88,11 +88,11 @@ struct ntk_ctx {
     hipStream_t copy_stream = nullptr;  // H2D copies of pinned batches
     bool owns_stream = false;
     int n_cu = 256;
-    int launch_blocks = 0, launch_threads = 512;
+    int launch_blocks = 0, launch_threads = 0;   // 0 = automatic
     uint64_t *d_acc = nullptr;      // accumulators in use (own or caller-bound)
     uint64_t *d_acc_own = nullptr;
     uint32_t *d_part_hist = nullptr;
-    uint32_t *d_work = nullptr;     // 8 work counters, one per 64-B line
+    uint32_t *d_work = nullptr;     // kMaxShards work counters, one per 64-B line
     bool work_dirty = true;         // not known to be zero
     uint64_t minimizer_chunk = (uint64_t)256 << 20;  // bytes of input per minimizer pass (NTK_MINIMIZER_CHUNK_BYTES: test hook)
     uint64_t *d_part_scalars = nullptr;
@@ -179,12 +179,16 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // algebra indexes lane masks by k; 64-bit values for k >= 17, 32-bit for k <= 16), -10..20 % against the generic runtime-k build; with a quality stream only k = 21 and
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
+constexpr int kScan2HistBits = 14;   // LDS histogram of the sv2 builds: 64 KiB, two 768-thread blocks per CU
+constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
+inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && m.canon && k >= 17 && (!qm || k == 21 || k == 31); }
+
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
 {
 #define NTK_PICK_SV(KF, T, U)                                                                       \
     if (REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \
-        return (const void *)&scan_kernel<2, true, T, U, true, KF, true>;
+        return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits>;
 #define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
     NTK_PICK_SV4(17) NTK_PICK_SV4(18) NTK_PICK_SV4(19) NTK_PICK_SV4(20) NTK_PICK_SV4(21) NTK_PICK_SV4(22) NTK_PICK_SV4(23) NTK_PICK_SV4(24)
     NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
@@ -198,7 +202,7 @@ const void *pick_scan(const Mode &m, uint32_t k)
 #undef NTK_PICK_SV
 #define NTK_PICK_SVQ(KF, T, U)                                                                      \
     if (REDUCE && QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)        \
-        return (const void *)&scan_kernel<2, true, T, U, true, KF, true, true>;
+        return (const void *)&scan2_kernel<KF, T, U, true, kScan2HistBits>;
     NTK_PICK_SVQ(21, false, false) NTK_PICK_SVQ(21, false, true) NTK_PICK_SVQ(21, true, false) NTK_PICK_SVQ(21, true, true)
     NTK_PICK_SVQ(31, false, false) NTK_PICK_SVQ(31, false, true) NTK_PICK_SVQ(31, true, false) NTK_PICK_SVQ(31, true, true)
 #undef NTK_PICK_SVQ
@@ -236,7 +240,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
-    const int threads = reduce ? c->launch_threads : 256;
+    const bool sv2 = is_scan2(m, p->k, reduce, cutoff != 0);
+    const int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : (sv2 ? 768 : 512));
     const int waves_per_block = threads / 64;
     const void *fn = cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
                             : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));
@@ -271,8 +276,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
         const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
         const uint64_t tiles = te - tb;
-        uint64_t chunk = tiles / ((uint64_t)blocks_max * waves_per_block * 4);  // >= ~4 pulls per wave, <= 16 tiles each
-        chunk = chunk < 1 ? 1 : (chunk > 16 ? 16 : chunk);
+        uint64_t chunk = tiles / ((uint64_t)blocks_max * waves_per_block * 4);  // >= ~4 pulls per wave, <= 32 tiles each
+        chunk = chunk < 1 ? 1 : (chunk > 32 ? 32 : chunk);
         const uint64_t want_blocks = (tiles + chunk * waves_per_block - 1) / (chunk * waves_per_block);
         const int blocks = (int)(want_blocks < (uint64_t)blocks_max ? want_blocks : (uint64_t)blocks_max);
         a.tile_begin = tb; a.tile_end = te;
@@ -280,13 +285,13 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
             const uint64_t first_tail = n / kTileStride;
             a.tail_tile_rel = first_tail < tb ? 0u : (first_tail - tb > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)(first_tail - tb));
         }
-        a.n_shards = blocks < 8 ? (uint32_t)blocks : 8u;
+        a.n_shards = blocks < kMaxShards ? (uint32_t)blocks : (uint32_t)kMaxShards;
         a.tiles_per_shard = (uint32_t)((tiles + a.n_shards - 1) / a.n_shards);
         a.chunk_tiles = (uint32_t)chunk;
         a.work_counters = c->d_work;
         // the work counters are zero on entry: the fold kernel of the previous reduce scan re-armed them; anything else
         // (first use, a materialise scan, an error on the way) leaves work_dirty set and costs a memset here
-        if (c->work_dirty) HIPCHK(hipMemsetAsync(c->d_work, 0, 8 * 64, c->stream));
+        if (c->work_dirty) HIPCHK(hipMemsetAsync(c->d_work, 0, kMaxShards * 64, c->stream));
         c->work_dirty = true;
         if (reduce) {
             int rc = ensure_partials(c, blocks);
@@ -307,7 +312,7 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         }
         if (reduce) {
             hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
-                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, c->d_work);
+                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, c->d_work, (int)a.n_shards);
             HIPCHK(hipGetLastError());
             c->work_dirty = false;
         }
@@ -348,7 +353,7 @@ int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
     HIPCHK(hipMalloc(&c->d_acc_own, NTK_ACC_WORDS * sizeof(uint64_t)));
     c->d_acc = c->d_acc_own;
     HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
-    HIPCHK(hipMalloc(&c->d_work, 8 * 64));
+    HIPCHK(hipMalloc(&c->d_work, kMaxShards * 64));
     HIPCHK(hipMalloc(&c->d_lut, 4 * 256 * sizeof(uint16_t)));
     HIPCHK(hipHostMalloc(&c->h_pinned, 64 * 1024, hipHostMallocDefault));
     uint16_t *h = (uint16_t *)c->h_pinned;
@@ -424,7 +429,7 @@ int ntk_ctx_synchronize(ntk_ctx *c)
 
 int ntk_ctx_set_launch(ntk_ctx *c, int blocks, int threads)
 {
-    if (!c || blocks < 0 || (threads != 256 && threads != 512 && threads != 1024)) return NTK_ERR_BAD_ARG;
+    if (!c || blocks < 0 || threads < 0 || threads > 1024 || (threads & 63)) return NTK_ERR_BAD_ARG;   // threads 0 = automatic
     c->launch_blocks = blocks; c->launch_threads = threads;
     return NTK_OK;
 }

@@ -357,13 +357,322 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "sv2" reduce kernel (17 <= K <= 32, canonical): see ntk_tile.hpp (lane_tile_sv2) for the scheme.
+//   HB     bits of the value's prefix the LDS histogram is indexed by: 12 (16 KiB, the bins of the result) or 14 (64 KiB,
+//          four cells per result bin, folded when the block writes its partials; the address is then one AND of the top half)
+// ---------------------------------------------------------------------------------------------
+template <int K, int HB>
+struct DevMasks2 {
+    static constexpr bool kLight = Sv2Light<K>::value;
+    uint64_t V[16];          // lane masks: window ending at byte j is emitted
+    uint64_t sum = 0;        // per-lane digests: sum of (hi:lo) (of the lo words when kLight); xor words of T and lo
+    uint32_t xT = 0, xlo = 0;
+    uint32_t cell = 0;       // LDS byte address of this thread's forward-strand counter
+    uint32_t one = 1;
+    uint32_t nf_s = 0;       // NTK_SV2_NFWD_SALU: forward-strand count of the wave, scalar
+    uint32_t nf_v = 0;       // NTK_SV2_NFWD_VALU: forward-strand count of the lane
+
+    template <class Enc>
+    __device__ __forceinline__ void compute(const Enc &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
+    {
+        uint64_t B[16];
+#ifdef NTK_ABL_NOSDWA
+#pragma unroll
+        for (int i = 0; i < 16; i++) B[i] = __builtin_amdgcn_ballot_w64(en.ex[i & 3] != (uint32_t)i);
+        if (false) {
+#endif
+        NTK_SDWA_EQ(B[0], en.ex[0], en.uu[0], BYTE_0);  NTK_SDWA_EQ(B[1], en.ex[0], en.uu[0], BYTE_1);
+        NTK_SDWA_EQ(B[2], en.ex[0], en.uu[0], BYTE_2);  NTK_SDWA_EQ(B[3], en.ex[0], en.uu[0], BYTE_3);
+        NTK_SDWA_EQ(B[4], en.ex[1], en.uu[1], BYTE_0);  NTK_SDWA_EQ(B[5], en.ex[1], en.uu[1], BYTE_1);
+        NTK_SDWA_EQ(B[6], en.ex[1], en.uu[1], BYTE_2);  NTK_SDWA_EQ(B[7], en.ex[1], en.uu[1], BYTE_3);
+        NTK_SDWA_EQ(B[8], en.ex[2], en.uu[2], BYTE_0);  NTK_SDWA_EQ(B[9], en.ex[2], en.uu[2], BYTE_1);
+        NTK_SDWA_EQ(B[10], en.ex[2], en.uu[2], BYTE_2); NTK_SDWA_EQ(B[11], en.ex[2], en.uu[2], BYTE_3);
+        NTK_SDWA_EQ(B[12], en.ex[3], en.uu[3], BYTE_0); NTK_SDWA_EQ(B[13], en.ex[3], en.uu[3], BYTE_1);
+        NTK_SDWA_EQ(B[14], en.ex[3], en.uu[3], BYTE_2); NTK_SDWA_EQ(B[15], en.ex[3], en.uu[3], BYTE_3);
+#ifdef NTK_ABL_NOSDWA
+        }
+#endif
+        if (tail_tile) {  // wave-uniform: bytes at or beyond n_bytes are breaks (the last 16-B line may carry padding)
+#pragma unroll
+            for (int i = 0; i < 16; i++) B[i] &= __builtin_amdgcn_ballot_w64(lane_base + i < (int64_t)n_bytes);
+        }
+#ifdef NTK_ABL_NOMASKALG
+#pragma unroll
+        for (int i = 0; i < 16; i++) V[i] = B[i];
+#else
+        window_masks<K>(B, V);
+#endif
+    }
+
+    // min(a >> 16, b >> 16) == min(a, b) >> 16: the top half of the chosen T word in one SDWA op
+    __device__ __forceinline__ uint32_t min_top16(uint32_t a, uint32_t b) const
+    {
+        uint32_t r;
+        asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+
+    // Side effects of four positions jb .. jb+3.  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
+    // Per position, under the validity mask: histogram cell += 1 and the digests; under validity & strand mask: the
+    // thread's own forward counter += 1 (non-returning LDS atomics: no VALU work for either count).
+    template <class S>
+    __device__ __forceinline__ void emit4(S &, int jb, const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4],
+                                          const uint32_t (&lo)[4])
+    {
+        uint64_t F[4], val[4];
+        uint32_t off[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            F[i] = __builtin_amdgcn_ballot_w64(fwd[i]);   // the compare's own SGPR pair
+            val[i] = ((uint64_t)hi[i] << 32) | lo[i];
+            // byte offset of the histogram cell: the value's top HB bits, * 4
+#ifdef NTK_SV2_MISALIGNED   // experiment: LDS atomics that ignore address bits 1:0
+            if (kLight) off[i] = HB == 14 ? T[i] : T[i] >> 2;
+            else off[i] = T[i] >> (HB == 14 ? 16 : 18);
+#else
+            if (kLight) off[i] = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
+            else off[i] = HB == 14 ? ((T[i] >> 16) & 0xFFFCu) : ((T[i] >> 18) & 0x3FFCu);
+#endif
+        }
+#ifdef NTK_ABL_NOLDS
+#define NTK_DS_HIST(i) ""
+#define NTK_DS_CELL ""
+#else
+#define NTK_DS_HIST(i) "ds_add_u32 %[o" #i "], %[one]\n"
+#define NTK_DS_CELL "ds_add_u32 %[cell], %[one]\n"
+#endif
+#ifdef NTK_ABL_NOEXEC
+#define NTK_SETEXEC(i) ""
+#else
+#define NTK_SETEXEC(i) "s_mov_b64 exec, %[V" #i "]\n"
+#endif
+#ifdef NTK_ABL_NODIGEST
+#define NTK_DIGEST_L(i) ""
+#else
+#define NTK_DIGEST_L(i) "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n" "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
+#endif
+#if defined(NTK_ABL_NOEXEC)
+#define NTK_NFWD(i) NTK_DS_CELL
+#define NTK_NF_OUT
+#define NTK_CELL_IN [cell] "v"(cell), [one] "v"(one)
+#define NTK_NF_ZERO
+#elif defined(NTK_SV2_NFWD_VALU)
+#define NTK_NFWD(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n v_add_u32 %[nfv], %[nfv], %[one]\n"
+#define NTK_NF_OUT , [nfv] "+v"(nf_v)
+#define NTK_CELL_IN [one] "v"(one)
+#define NTK_NF_ZERO
+#elif defined(NTK_SV2_NFWD_SALU)
+#define NTK_NFWD(i) "s_and_b64 vcc, %[V" #i "], %[F" #i "]\n s_bcnt1_i32_b64 vcc_lo, vcc\n s_add_u32 %[nf], %[nf], vcc_lo\n"
+#define NTK_NF_OUT , [nf] "=&s"(nf_grp)
+#define NTK_CELL_IN [one] "v"(one)
+#define NTK_NF_ZERO "s_mov_b32 %[nf], 0\n"
+        uint32_t nf_grp = 0;
+#else
+#define NTK_NF_ZERO
+#define NTK_NFWD(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n" NTK_DS_CELL
+#define NTK_NF_OUT
+#define NTK_CELL_IN [cell] "v"(cell), [one] "v"(one)
+#endif
+        if constexpr (kLight) {
+#define NTK_EMIT1(i)                                             \
+        NTK_SETEXEC(i)                                           \
+        NTK_DS_HIST(i)                                           \
+        NTK_DIGEST_L(i)                                          \
+        NTK_NFWD(i)
+            asm volatile(NTK_NF_ZERO NTK_EMIT1(0) NTK_EMIT1(1) NTK_EMIT1(2) NTK_EMIT1(3) "s_mov_b64 exec, -1\n"
+                         : [sum] "+v"(sum), [xlo] "+v"(xlo) NTK_NF_OUT
+                         : [o0] "v"(off[0]), [l0] "v"(lo[0]), [V0] "s"(V[jb + 0]), [F0] "s"(F[0]),
+                           [o1] "v"(off[1]), [l1] "v"(lo[1]), [V1] "s"(V[jb + 1]), [F1] "s"(F[1]),
+                           [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[jb + 2]), [F2] "s"(F[2]),
+                           [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[jb + 3]), [F3] "s"(F[3]),
+                           NTK_CELL_IN
+                         : "memory", "vcc", "scc");
+#undef NTK_EMIT1
+        } else {
+#define NTK_EMIT1(i)                                             \
+        "s_mov_b64 exec, %[V" #i "]\n"                          \
+        NTK_DS_HIST(i)                                           \
+        "v_lshl_add_u64 %[sum], %[v" #i "], 0, %[sum]\n"        \
+        "v_xor_b32 %[xT], %[xT], %[T" #i "]\n"                  \
+        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"                \
+        NTK_NFWD(i)
+            asm volatile(NTK_NF_ZERO NTK_EMIT1(0) NTK_EMIT1(1) NTK_EMIT1(2) NTK_EMIT1(3) "s_mov_b64 exec, -1\n"
+                         : [sum] "+v"(sum), [xT] "+v"(xT), [xlo] "+v"(xlo) NTK_NF_OUT
+                         : [o0] "v"(off[0]), [v0] "v"(val[0]), [l0] "v"(lo[0]), [T0] "v"(T[0]), [V0] "s"(V[jb + 0]), [F0] "s"(F[0]),
+                           [o1] "v"(off[1]), [v1] "v"(val[1]), [l1] "v"(lo[1]), [T1] "v"(T[1]), [V1] "s"(V[jb + 1]), [F1] "s"(F[1]),
+                           [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[jb + 2]), [F2] "s"(F[2]),
+                           [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[jb + 3]), [F3] "s"(F[3]),
+                           NTK_CELL_IN
+                         : "memory", "vcc", "scc");
+#undef NTK_EMIT1
+        }
+#undef NTK_DS_HIST
+#undef NTK_DS_CELL
+#undef NTK_NFWD
+#undef NTK_NF_OUT
+#undef NTK_CELL_IN
+#undef NTK_NF_ZERO
+#undef NTK_SETEXEC
+#undef NTK_DIGEST_L
+#ifdef NTK_SV2_NFWD_SALU
+        nf_s += nf_grp;
+#endif
+    }
+};
+
+struct NoSink {};
+
+#ifndef NTK_SV2_MINWAVES
+#define NTK_SV2_MINWAVES 1
+#endif
+template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12>
+__global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs a)
+{
+    static_assert(K >= 17 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 17 <= k <= 32");
+    constexpr bool LIGHT = Sv2Light<K>::value;
+    constexpr int kCells = 1 << HB;
+    // One LDS object, histogram first: the masked regions address the histogram with the cell's byte offset alone, which
+    // is only right while the histogram sits at LDS address 0 (checked below; the kernel has no other LDS object).
+    struct Lds { uint32_t hist[kCells]; uint32_t nfwd[1024]; uint64_t red[16 * 6]; };
+    __shared__ Lds L;
+    uint32_t *const s_hist = L.hist, *const s_nfwd = L.nfwd;  // nfwd: per-thread forward-strand counters
+    uint64_t *const s_red = L.red;
+    if ((uint32_t)(uintptr_t)&L.hist[0] != 0u) __builtin_trap();
+
+    for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
+    s_nfwd[threadIdx.x] = 0;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t shard = blockIdx.x % a.n_shards;
+    const uint32_t launch_tiles = (uint32_t)(a.tile_end - a.tile_begin);
+    const uint32_t shard_begin = shard * a.tiles_per_shard;
+    uint32_t shard_end = shard_begin + a.tiles_per_shard;
+    if (shard_end > launch_tiles) shard_end = launch_tiles;
+    uint32_t *ctr = a.work_counters + shard * 16;
+    const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
+    DevXL xl;
+    DevMasks2<K, HB> mp;
+    NoSink sink;
+    mp.cell = (uint32_t)(uintptr_t)&s_nfwd[threadIdx.x];   // LDS byte address: the asm blocks address LDS directly
+
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+    next = __builtin_amdgcn_readfirstlane(next);
+    while (next < shard_tiles) {
+        const uint32_t r0 = shard_begin + next;
+        uint32_t r1 = r0 + a.chunk_tiles;
+        if (r1 > shard_end) r1 = shard_end;
+        if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+        const uint64_t t0 = a.tile_begin + r0;
+        const uint64_t run_byte = t0 * kTileStride;
+        const uint32_t halo = t0 ? 32u : 0u;
+        const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
+        uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - (run_byte - halo);
+        if (rem > 0xFFFFFF00ull) rem = 0xFFFFFF00ull;
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
+        const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+        __amdgpu_buffer_rsrc_t rq = rs;
+        if constexpr (QM) {
+            const uint64_t qbase = (uint64_t)a.qual + run_byte - halo;
+            const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase);
+            const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
+            rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qhi << 32) | qlo), 0, nrec, 0x00020000);
+        }
+        uint32_t voff = lane * 16u - (32u - halo);
+        uint64_t tile_byte = run_byte;
+        // two tiles of load in flight per wave
+        u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        u32x4 nx1 = cur, curq = cur, nx1q = cur;
+        if constexpr (QM) curq = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
+        if (r0 + 1 < r1) {
+            nx1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);
+            if constexpr (QM) nx1q = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + kTileStride, 0, 0);
+        }
+        for (uint32_t r = r0; r < r1; r++) {
+            u32x4 nx2 = nx1, nx2q = nx1q;
+            if (r + 2 < r1) {  // wave-uniform
+                nx2 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 2 * kTileStride, 0, 0);
+                if constexpr (QM) nx2q = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + 2 * kTileStride, 0, 0);
+            }
+            const bool tail = r >= a.tail_tile_rel;
+            Raw16 raw{cur.x, cur.y, cur.z, cur.w};
+            if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
+#ifdef NTK_ABL_LOADSONLY
+            mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
+#else
+            const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
+            mp.compute(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
+            lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
+#endif
+            cur = nx1; nx1 = nx2; curq = nx1q; nx1q = nx2q; voff += kTileStride; tile_byte += kTileStride;
+        }
+        next = __builtin_amdgcn_readfirstlane(next);
+    }
+
+    // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
+    constexpr int S = 64 - 2 * K;
+    uint64_t sum = mp.sum, xr = ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
+    uint64_t shi = 0, xf = 0;   // LIGHT: high parts of the digests, from the histogram
+    uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
+#if defined(NTK_SV2_NFWD_VALU)
+    nf = mp.nf_v;
+#elif defined(NTK_SV2_NFWD_SALU)
+    nf = lane == 0 ? mp.nf_s : 0u;
+#else
+    nf = s_nfwd[threadIdx.x];
+#endif
+    __syncthreads();
+    for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int q = 0; q < kCells / kHistBins; q++) {
+            const uint32_t f = c * (kCells / kHistBins) + q, h = s_hist[f];
+            tot += h;
+            if constexpr (LIGHT) {   // cell f = the value's top HB bits: hi word = f >> (32 + HB - 2K), xor bits 2K-HB and up = f
+                shi += (uint64_t)(f >> (32 + HB - 2 * K)) * h;
+                xf ^= (h & 1u) ? f : 0u;
+            }
+        }
+        ph[c] = tot; nv += tot;
+    }
+    if constexpr (LIGHT) {
+        // the lo words and the histogram cells overlap in bits [2K-HB, 32) of the value: those bits are taken from the cells
+        constexpr uint32_t low_mask = 2 * K - HB >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * K - HB) & 31)) - 1u);
+        sum += shi << 32;
+        xr = (xf << (2 * K - HB)) | (uint64_t)(mp.xlo & low_mask);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o, 64);
+        xr ^= __shfl_xor(xr, o, 64);
+        nf += __shfl_xor(nf, o, 64);
+        nv += __shfl_xor(nv, o, 64);
+    }
+    if (lane == 0) { s_red[wave * 4 + 0] = nv; s_red[wave * 4 + 1] = nf; s_red[wave * 4 + 2] = sum; s_red[wave * 4 + 3] = xr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {
+            tv += s_red[w * 4 + 0]; tf += s_red[w * 4 + 1]; ts += s_red[w * 4 + 2]; tx ^= s_red[w * 4 + 3];
+        }
+        uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
+        ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
+    }
+}
+
 // Sums the per-block partials into the ctx accumulators (same stream, after the scan kernel).
 // Grid: kFoldBinGroups x kFoldRowGroups blocks sum disjoint (bin range, row subset) pieces and add them with one
 // u64 atomic per bin; one extra block reduces the scalar partials.  (A single pass over <= 8 MiB, a few microseconds.)
 constexpr int kFoldThreads = 256, kFoldBinGroups = kHistBins / kFoldThreads, kFoldRowGroups = 32;
 constexpr int kFoldBlocks = kFoldBinGroups * kFoldRowGroups + 1;
 __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part_hist, const uint64_t *part_scalars, int nblocks,
-                                                            uint64_t *acc, uint32_t *work_counters = nullptr)
+                                                            uint64_t *acc, uint32_t *work_counters = nullptr, int n_counters = 8)
 {
     if (blockIdx.x < kFoldBinGroups * kFoldRowGroups) {
         const int bin = (blockIdx.x % kFoldBinGroups) * kFoldThreads + threadIdx.x;
@@ -374,8 +683,9 @@ __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part
         return;
     }
     __shared__ uint64_t s_red[kFoldThreads / 64][4];
-    // the scan that filled these partials is complete: re-arm its 8 work counters for the next scan (saves a memset launch)
-    if (work_counters && threadIdx.x < 8) work_counters[threadIdx.x * 16] = 0;
+    // the scan that filled these partials is complete: re-arm its work counters for the next scan (saves a memset launch)
+    if (work_counters)
+        for (int i = threadIdx.x; i < n_counters; i += kFoldThreads) work_counters[i * 16] = 0;
     uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
     for (int b = threadIdx.x; b < nblocks; b += kFoldThreads) {
         tv += part_scalars[b * 4 + 0]; tf += part_scalars[b * 4 + 1];

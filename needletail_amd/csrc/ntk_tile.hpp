@@ -126,6 +126,16 @@ NTK_HD uint32_t brev32(uint32_t x)
 #endif
 }
 
+NTK_HD uint32_t dot4(uint32_t a, uint32_t b, uint32_t c)  // v_dot4_u32_u8: sum of the four byte products + c
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return c;
+#endif
+}
+
 // 32 bits of a big-endian word stream starting `off` bits after the MSB of W[0].
 template <int N>
 NTK_HD uint32_t win32(const uint32_t (&W)[N], int off)
@@ -237,7 +247,8 @@ constexpr int kHaloLanes = 2;
 constexpr int kTileSlots = 64 - kHaloLanes;         // emitting 16-byte slots per tile
 constexpr int kTileStride = kTileSlots * 16;        // 992 bytes
 
-enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 = 20, kSlotCode1 = 21, kNumSlots = 22 };
+enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 = 20, kSlotCode1 = 21,
+       kSlotFw = 22, kSlotRw = 38, kNumSlots = 54 };  // kSlotFw + g / kSlotRw + g, g = 0..15: window words handed to the next lane
 
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX, class Sink, class XL>
 NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t lane_base, bool halo_lane, bool tail_tile)
@@ -481,6 +492,117 @@ NTK_HD void lane_tile_sv1(Sink &sink, XL &xl, MP &mp, const EncSV &en)
         bool take_fwd = true;
         if (CANON) take_fwd = TIE_RC ? (fl < rl) : (fl <= rl);
         mp.template emit1<K>(sink, j, take_fwd, take_fwd ? fl : rl);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// "sv2": the scalar-validity reduce path, second generation (17 <= K <= 32, canonical).
+//
+// * No byte transpose: the four dwords are used as loaded (byte b of dword i = base 4i + b).  The 2-bit codes of a
+//   dword are gathered by ONE v_dot4_u32_u8 (byte & 6 = 2 * code; weights 64, 16, 4, 1), and the "is a base" test is a
+//   nibble LUT: v_perm_b32 with the byte's low nibble as selector returns the only letter with that nibble (selectors
+//   8..15 return 0x00 / 0xFF, which no case-folded byte equals), compared with the case-folded byte by SDWA.
+// * Strand choice on 32 bits.  With T = the TOP 32 bits (first 16 bases) of a 2K-bit value, K <= 32:
+//       T_fwd != T_rc  ->  the values order like their T words (T is the most significant part);
+//       T_fwd == T_rc  ->  base i = complement of base K-1-i for i = 0..15, and (i <-> K-1-i is the same condition)
+//                          therefore for every i as long as K <= 32: the k-mer is its own reverse complement, the two
+//                          values are EQUAL, and `<` / `<=` on T gives what it gives on the values.
+//   So one v_cmp_*_u32 decides, no 64-bit register pairs are built (reference src/kmer.rs:124-128, src/bitkmer.rs:136-143).
+// * Window words are shared: fw[g] = the 32 bits of the forward stream ENDING at base g, rw[g] = the 32 bits of the
+//   reverse-complement stream whose TOP group is base g (g = -D .. 15, D = K - 16; g < 0 = the previous lane's word, one
+//   DPP move).  The window ending at base j has  fwd (T, lo) = (fw[j-D], fw[j]),  rc (T, lo) = (rw[j], rw[j-D]):
+//   2 (16 + D) / 16 half-rate ops per position instead of 4.
+// * Everything that does not depend on validity runs under the full exec mask for four positions at a time; the side
+//   effects of those four positions are then applied in ONE masked region that moves the validity mask into exec per
+//   position and restores exec once (MP::emit4; on the device a single asm block).
+// ---------------------------------------------------------------------------------------------
+struct EncSV2 {
+    uint32_t code, rcode;
+    uint32_t ex[4];  // expected letter per byte (byte b of word i = base 4i + b)
+    uint32_t uu[4];  // the byte as read, case-folded
+};
+
+template <bool ACCEPT_U>
+NTK_HD EncSV2 encode16_sv2(Raw16 d)
+{
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    EncSV2 r;
+    uint32_t p[4];
+    // nibble LUT: 1 -> A, 3 -> C, 4 -> T, 5 -> U (normalize pipeline only, reference src/sequence.rs:30), 7 -> G; 0xFF elsewhere
+    constexpr uint32_t kLutLo = 0x43FF41FFu, kLutHi = ACCEPT_U ? 0x47FF5554u : 0x47FFFF54u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        p[i] = dot4(w[i] & 0x06060606u, 0x01041040u, 0u);   // 2 * (c0 c1 c2 c3 as one byte), ASCII bits 2:1: A0 C1 T2 G3
+        r.ex[i] = perm(kLutHi, kLutLo, w[i] & 0x0F0F0F0Fu);
+        r.uu[i] = w[i] & 0xDFDFDFDFu;
+    }
+    const uint32_t m = (((p[0] << 8) + p[1]) << 15) | (((p[2] << 8) + p[3]) >> 1);
+    r.code = bitop3<0x6C>(m >> 1, m, 0x55555555u);            // m ^ ((m >> 1) & 0x5555...): A0 C1 G2 T3 (reference src/bitkmer.rs:8-15)
+    const uint32_t t = brev32(r.code);
+    r.rcode = bitop3<0x35>(0x55555555u, t >> 1, t + t);        // complement, pairs swapped back after the bit reversal
+    return r;
+}
+
+NTK_HD bool sv2_base_is_break(const EncSV2 &e, int i)  // host side of the SDWA compare: base i = byte i%4 of word i/4
+{
+    const int sh = 8 * (i & 3);
+    return ((e.ex[i >> 2] >> sh) & 0xFFu) != ((e.uu[i >> 2] >> sh) & 0xFFu);
+}
+
+// LIGHT (K <= 22): the top 12 bits of a value (its histogram bin) reach down to bit 2K-12 <= 32, so bin and lo word
+// together cover every bit of the value.  The per-position work then only touches the lo word (sum of lo words in 64
+// bits, xor of lo words); the high part of both digests follows from the block's histogram when it is written out:
+//     sum of hi words = sum_b (b >> (44 - 2K)) * H[b]          xor, bits 2K-12 and up = xor_b (H[b] odd ? b : 0)
+// and the histogram address only needs the top 16 bits of the chosen T word = min of the two top halves (one SDWA min).
+template <int K> struct Sv2Light { static constexpr bool value = K <= 22; };
+
+template <bool TIE_RC, int K, class Sink, class XL, class MP>
+NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
+{
+    static_assert(K >= 17 && K <= 32, "sv2 is the 64-bit-value path");
+    constexpr int D = K - 16, S = 64 - 2 * K;
+    constexpr bool LIGHT = MP::kLight;
+    uint32_t fw[16 + D], rw[16 + D];   // index g + D
+    const uint32_t c1 = xl.prev(kSlotCode, code), r1 = xl.prev(kSlotRcode, rcode);
+    fw[D + 15] = code; rw[D + 15] = rcode;
+    fw[D - 1] = c1;    rw[D - 1] = r1;
+#ifdef NTK_ABL_NOWINDOWS   // ablation: no funnel shifts, no cross-lane words
+#pragma unroll
+    for (int j = 0; j < 15; j++) { fw[D + j] = code ^ (uint32_t)j; rw[D + j] = rcode ^ (uint32_t)j; }
+#pragma unroll
+    for (int g = 2; g <= D; g++) { fw[D - g] = c1 ^ (uint32_t)g; rw[D - g] = r1 ^ (uint32_t)g; }
+#else
+#pragma unroll
+    for (int j = 0; j < 15; j++) {
+        fw[D + j] = alignbit(c1, code, 30 - 2 * j);
+        rw[D + j] = alignbit(rcode, r1, 2 * j + 2);
+    }
+#pragma unroll
+    for (int g = 2; g <= D; g++) {     // the previous lane's words 16-g: its window ending / starting g bases before our base 0
+        fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+        rw[D - g] = xl.prev(kSlotRw + 16 - g, rw[D + 16 - g]);
+    }
+#endif
+#pragma unroll
+    for (int jb = 0; jb < 16; jb += 4) {
+        uint32_t T[4], lo[4], hi[4];
+        bool fwd[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = jb + i;
+            const uint32_t ft = fw[j], rt = rw[D + j];            // fw[(j - D) + D], rw[j + D]
+            fwd[i] = TIE_RC ? (ft < rt) : (ft <= rt);
+            lo[i] = fwd[i] ? fw[D + j] : rw[j];
+            if (LIGHT) {
+                T[i] = mp.min_top16(ft, rt);                      // top 16 bits of the chosen T word, in bits 15:0
+                hi[i] = 0;
+            } else {
+                T[i] = fwd[i] ? ft : rt;
+                hi[i] = S ? T[i] >> S : T[i];
+            }
+        }
+        mp.emit4(sink, jb, fwd, T, hi, lo);
     }
 }
 

@@ -143,6 +143,88 @@ void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostS
     }
 }
 
+
+// "sv2" variant (ntk_tile.hpp lane_tile_sv2): same mask algebra; the digests are kept the way the device keeps them -
+// sum of (hi:lo) / xor words of (T, lo), or for K <= 22 ("light") only the lo words plus a per-block histogram from
+// which the high parts are rebuilt - so that the reconstruction arithmetic of scan2_kernel is what gets checked.
+template <int K, int HB>
+struct EmuMP2 {
+    static constexpr bool kLight = Sv2Light<K>::value;
+    uint64_t V[16];
+    int lane = 0;
+    uint64_t sum = 0, n_fwd = 0;
+    uint32_t xT = 0, xlo = 0;
+    std::vector<uint32_t> cells = std::vector<uint32_t>(1u << HB, 0u);
+    uint32_t min_top16(uint32_t a, uint32_t b) const { return (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16); }
+    template <class S>
+    void emit4(S &, int jb, const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
+    {
+        for (int i = 0; i < 4; i++) {
+            if (!((V[jb + i] >> lane) & 1)) continue;
+            uint32_t off;
+            if (kLight) off = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
+            else off = HB == 14 ? ((T[i] >> 16) & 0xFFFCu) : ((T[i] >> 18) & 0x3FFCu);
+            cells[off >> 2]++;
+            if (kLight) { sum += lo[i]; xlo ^= lo[i]; }
+            else { sum += ((uint64_t)hi[i] << 32) | lo[i]; xT ^= T[i]; xlo ^= lo[i]; }
+            n_fwd += fwd[i] ? 1 : 0;
+        }
+    }
+    void finish(HostStats *st)   // the block-end arithmetic of scan2_kernel
+    {
+        constexpr int S = 64 - 2 * K;
+        uint64_t s = sum, xr = ((uint64_t)(S ? xT >> S : xT) << 32) | xlo, shi = 0, xf = 0, nv = 0;
+        const uint32_t per = (1u << HB) / kHistBins;
+        for (uint32_t c = 0; c < (uint32_t)kHistBins; c++) {
+            uint32_t tot = 0;
+            for (uint32_t q = 0; q < per; q++) {
+                const uint32_t f = c * per + q, h = cells[f];
+                tot += h;
+                if (kLight) { shi += (uint64_t)(f >> (32 + HB - 2 * K)) * h; xf ^= (h & 1u) ? f : 0u; }
+            }
+            st->hist[c] += tot; nv += tot;
+        }
+        if (kLight) {
+            constexpr uint32_t low_mask = 2 * K - HB >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * K - HB) & 31)) - 1u);
+            s += shi << 32;
+            xr = (xf << (2 * K - HB)) | (uint64_t)(xlo & low_mask);
+        }
+        st->n_total += nv; st->n_fwd += n_fwd; st->sum += s; st->xr ^= xr;
+    }
+};
+
+struct EmuNoSink {};
+
+template <bool TIE_RC, bool ACCEPT_U, int K, int HB>
+void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
+{
+    const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
+    EmuMP2<K, HB> mp;
+    EmuNoSink sink;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        const bool tail = (t + 1) * kTileStride > n;
+        EncSV2 en[64];
+        uint64_t G[16] = {0};
+        for (int l = 0; l < 64; l++) {
+            const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
+            en[l] = encode16_sv2<ACCEPT_U>(load16q(buf, n_padded, lane_base));
+            for (int i = 0; i < 16; i++) {
+                bool good = !sv2_base_is_break(en[l], i);
+                if (tail && lane_base + i >= (int64_t)n) good = false;
+                if (good) G[i] |= 1ull << l;
+            }
+        }
+        window_masks<K>(G, mp.V);
+        EmuXL xl;
+        for (int l = 0; l < 64; l++) {
+            xl.next_lane(l == 0);
+            mp.lane = l;
+            lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en[l].code, en[l].rcode);
+        }
+    }
+    mp.finish(st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +245,13 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     const bool fix = (tiles_per_wave & 1) && canon && (k == 21 || k == 31);
     // bit 1 of tiles_per_wave: the scalar-validity variant (statistics only), built for every 17 <= k <= 32 like the product
     const bool sv = (tiles_per_wave & 2) && canon && !values;
+    // bit 2 of tiles_per_wave: the second-generation scalar-validity variant (17 <= k <= 32); bit 3 picks its 14-bit histogram
+    const bool sv2 = (tiles_per_wave & 4) && canon && !values && k >= 17;
+    const bool hb14 = (tiles_per_wave & 8) != 0;
+#define EMU_SV2(KF, T, U) if (sv2 && k == KF && !!tie_rc == T && !!accept_u == U) { if (hb14) run_sv2<T, U, KF, 14>(buf, n, n_padded, st); else run_sv2<T, U, KF, 12>(buf, n, n_padded, st); } else
+#define EMU_SV24(KF) EMU_SV2(KF, false, false) EMU_SV2(KF, false, true) EMU_SV2(KF, true, false) EMU_SV2(KF, true, true)
+    EMU_SV24(17) EMU_SV24(18) EMU_SV24(19) EMU_SV24(20) EMU_SV24(21) EMU_SV24(22) EMU_SV24(23) EMU_SV24(24)
+    EMU_SV24(25) EMU_SV24(26) EMU_SV24(27) EMU_SV24(28) EMU_SV24(29) EMU_SV24(30) EMU_SV24(31) EMU_SV24(32)
 #define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
 #define EMU_SV4(KF) EMU_SV(KF, false, false) EMU_SV(KF, false, true) EMU_SV(KF, true, false) EMU_SV(KF, true, true)
     EMU_SV4(1) EMU_SV4(2) EMU_SV4(3) EMU_SV4(4) EMU_SV4(5) EMU_SV4(6) EMU_SV4(7) EMU_SV4(8)

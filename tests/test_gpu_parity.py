@@ -191,11 +191,11 @@ def test_launch_geometry_invariance(ctx):
     buf = O.synth_reads(0x5EED0002, 100, 20000, 150, 1).tobytes()
     want = O.reduce_fused(buf, 21, True, True, True)
     try:
-        for blocks, threads in ((0, 1024), (1, 256), (3, 512), (7, 1024), (512, 256), (2048, 256), (100000, 256)):
+        for blocks, threads in ((0, 1024), (1, 256), (3, 512), (7, 1024), (512, 256), (2048, 256), (100000, 256), (0, 768), (5, 896), (0, 0)):
             ctx.set_launch(blocks, threads)
             assert_stats_equal(gpu_reduce(ctx, buf, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), want, (blocks, threads))
     finally:
-        ctx.set_launch(0, 1024)
+        ctx.set_launch(0, 0)   # back to the automatic geometry: the ctx is shared by the module's tests
 
 
 def test_unsupported_and_bad_args_are_errors(ctx):

@@ -90,7 +90,8 @@ def test_emu_vs_oracle_synthetic(emu, k):
     buf = O.synth_reads(0x5EED0002, 0, 40, 150, 8).tobytes()  # ~0.8% N, '\n' separators
     for canon, tie_rc, accept_u in ((1, 1, 1), (1, 0, 0), (0, 0, 0)):
         want = O.reduce_fused(buf, k, bool(canon), bool(tie_rc), bool(accept_u))
-        for tpw in (1, 2, 3, 7):  # bit 0: k-specialised build (k = 21, 31), bit 1: scalar-validity variant
+        # bit 0: k-specialised build (k = 21, 31), bit 1: scalar-validity variant, bit 2: sv2 (k >= 17), bit 3: its 14-bit histogram
+        for tpw in (1, 2, 3, 7, 4, 12):
             got = emu_scan(emu, buf, k, canon, tie_rc, accept_u, tpw)
             assert_stats_equal(got, want, (k, canon, tie_rc, accept_u, tpw))
 
@@ -115,7 +116,7 @@ def test_emu_random_alphabet_and_lengths(emu):
         k = int(rng.integers(1, 33))
         for canon, tie_rc, accept_u in ((1, 1, 1), (1, 0, 0), (0, 0, 1)):
             want = O.reduce_fused(buf, k, bool(canon), bool(tie_rc), bool(accept_u))
-            got = emu_scan(emu, buf, k, canon, tie_rc, accept_u, int(rng.integers(1, 4)))
+            got = emu_scan(emu, buf, k, canon, tie_rc, accept_u, int(rng.integers(1, 16)))
             assert_stats_equal(got, want, (trial, n, k, canon, tie_rc, accept_u))
 
 
@@ -144,7 +145,7 @@ _ALPHABET = b"ACGT" * 6 + b"acgt" + b"NnUuRYKM-.* \t\r\n\x00\x7f\x80\xff0@>"
 @settings(max_examples=150, deadline=None)
 @given(data=st_.lists(st_.sampled_from(list(_ALPHABET)), min_size=0, max_size=1400).map(bytes),
        k=st_.integers(1, 32), mode=st_.sampled_from([(1, 1, 1), (1, 0, 0), (0, 0, 0), (1, 0, 1), (1, 1, 0)]),
-       variant=st_.integers(0, 3))
+       variant=st_.integers(0, 15))
 def test_emu_matches_oracle_property(data, k, mode, variant):
     L = _emu_lib()
     canon, tie_rc, accept_u = mode
@@ -197,6 +198,6 @@ def test_emu_quality_scan_matches_masked_oracle(emu):
         # the reference masks (base, quality) pairs first, then runs the chain (src/sequence.rs:285-296)
         masked = O.quality_mask(buf, qual, cutoff)
         want = O.reduce_fused(masked, k, bool(canon), bool(tie_rc), bool(accept_u))
-        for tpw in (0, 3):
+        for tpw in (0, 3, 4, 12):
             got = emu_scan_quality(emu, buf, qual, cutoff, k, canon, tie_rc, accept_u, tpw)
             assert_stats_equal(got, want, (trial, k, cutoff, tpw))

@@ -32,8 +32,8 @@ int main(int argc, char **argv)
     a.seq = d_seq; a.n_bytes = n; a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots; a.tile_begin = 0; a.tile_end = a.n_tiles;
     const int wpb = threads / 64;
     const uint32_t chunk = argc > 7 ? atoi(argv[7]) : 16;
-    uint32_t *d_work; CHK(hipMalloc(&d_work, 512));
-    a.n_shards = blocks < 8 ? blocks : 8; a.tiles_per_shard = (uint32_t)((a.n_tiles + a.n_shards - 1) / a.n_shards);
+    uint32_t *d_work; CHK(hipMalloc(&d_work, 65536));
+    a.n_shards = argc > 8 ? atoi(argv[8]) : (blocks < 8 ? blocks : 8); a.tiles_per_shard = (uint32_t)((a.n_tiles + a.n_shards - 1) / a.n_shards);
     a.chunk_tiles = chunk; a.work_counters = d_work; a.tail_tile_rel = (uint32_t)(n / kTileStride);
     CHK(hipMalloc(&d_ph, (size_t)blocks * kHistBins * 4)); CHK(hipMalloc(&d_ps, (size_t)blocks * 32)); CHK(hipMalloc(&d_acc, (8 + kHistBins + 64) * 8));
     a.part_hist = d_ph; a.part_scalars = d_ps;
@@ -45,8 +45,17 @@ int main(int argc, char **argv)
     const int warm = 300;  // ~0.2 s of load before timing: steady-state clocks
     for (int it = 0; it < iters + warm; it++) {
         CHK(hipMemsetAsync(d_acc, 0, (8 + kHistBins + 64) * 8, 0));
-        CHK(hipMemsetAsync(d_work, 0, 512, 0));
+        CHK(hipMemsetAsync(d_work, 0, 65536, 0));
         CHK(hipEventRecord(e0, 0));
+#ifdef NTK_KB_SV2
+#ifndef NTK_KB_HB
+#define NTK_KB_HB 12
+#endif
+        if (k == 21) hipLaunchKernelGGL((scan2_kernel<21, true, true, false, NTK_KB_HB>), dim3(blocks), dim3(threads), 0, 0, a);
+        else if (k == 31) hipLaunchKernelGGL((scan2_kernel<31, true, true, false, NTK_KB_HB>), dim3(blocks), dim3(threads), 0, 0, a);
+        else if (k == 23) hipLaunchKernelGGL((scan2_kernel<23, true, true, false, NTK_KB_HB>), dim3(blocks), dim3(threads), 0, 0, a);
+        else
+#endif
 #ifdef NTK_KB_FIX
 #ifdef NTK_KB_SV
         if (k == 21) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true, 21, true>), dim3(blocks), dim3(threads), 0, 0, a);
