@@ -27,6 +27,17 @@ struct DevXL {
     {
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kDppWaveShr1, 0xf, 0xf, true);
     }
+    // take ? a : (the previous lane's b) - the cross-lane move rides on the select (v_cndmask_b32_dpp, src0 = DPP operand).
+    // s_nop 1: a VGPR written by the preceding VALU instruction may not be read through DPP for two wait states, and the
+    // compiler does not look inside the asm.
+    __device__ __forceinline__ uint32_t select_prev(int, bool take, uint32_t a, uint32_t b) const
+    {
+        uint32_t r;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(take);
+        asm("s_nop 1\n s_mov_b64 vcc, %3\n v_cndmask_b32_dpp %0, %2, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "=v"(r) : "v"(a), "v"(b), "s"(m) : "vcc");
+        return r;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -405,19 +416,20 @@ struct DevMasks2 {
 #endif
     }
 
-    // min(a >> 16, b >> 16) == min(a, b) >> 16: the top half of the chosen T word in one SDWA op
-    __device__ __forceinline__ uint32_t min_top16(uint32_t a, uint32_t b) const
+    // (min(a.hi16, b.lo16) : min(a.lo16, b.hi16)): the T words of positions j and j+8 share registers with crossed halves
+    __device__ __forceinline__ uint32_t pk_min16_crossed(uint32_t a, uint32_t b) const
     {
         uint32_t r;
-        asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+        asm("v_pk_min_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
         return r;
     }
 
-    // Side effects of four positions jb .. jb+3.  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
+    // Side effects of four positions pos[0..3].  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
     // Per position, under the validity mask: histogram cell += 1 and the digests; under validity & strand mask: the
     // thread's own forward counter += 1 (non-returning LDS atomics: no VALU work for either count).
+    // LIGHT: T[0], T[1] carry their position's histogram prefix in bits 31:16, T[2], T[3] in bits 15:0.
     template <class S>
-    __device__ __forceinline__ void emit4(S &, int jb, const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4],
+    __device__ __forceinline__ void emit4(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4],
                                           const uint32_t (&lo)[4])
     {
         uint64_t F[4], val[4];
@@ -427,13 +439,13 @@ struct DevMasks2 {
             F[i] = __builtin_amdgcn_ballot_w64(fwd[i]);   // the compare's own SGPR pair
             val[i] = ((uint64_t)hi[i] << 32) | lo[i];
             // byte offset of the histogram cell: the value's top HB bits, * 4
-#ifdef NTK_SV2_MISALIGNED   // experiment: LDS atomics that ignore address bits 1:0
-            if (kLight) off[i] = HB == 14 ? T[i] : T[i] >> 2;
-            else off[i] = T[i] >> (HB == 14 ? 16 : 18);
-#else
-            if (kLight) off[i] = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
-            else off[i] = HB == 14 ? ((T[i] >> 16) & 0xFFFCu) : ((T[i] >> 18) & 0x3FFCu);
-#endif
+            // (LDS atomics at an address that is not 4-byte aligned raise a memory violation on gfx950 - measured - so the low
+            //  two bits have to be cleared)
+            if (kLight && i >= 2) off[i] = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
+            else if (HB == 14) {
+                const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
+                asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off[i]) : "s"(kMask), "v"(T[i]));
+            } else off[i] = (T[i] >> 18) & 0x3FFCu;
         }
 #ifdef NTK_ABL_NOLDS
 #define NTK_DS_HIST(i) ""
@@ -450,7 +462,11 @@ struct DevMasks2 {
 #ifdef NTK_ABL_NODIGEST
 #define NTK_DIGEST_L(i) ""
 #else
+#ifdef NTK_SV2_XOR_LDS
+#define NTK_DIGEST_L(i) "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n" "ds_xor_b32 %[xcell], %[l" #i "]\n"
+#else
 #define NTK_DIGEST_L(i) "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n" "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
+#endif
 #endif
 #if defined(NTK_ABL_NOEXEC)
 #define NTK_NFWD(i) NTK_DS_CELL
@@ -465,7 +481,7 @@ struct DevMasks2 {
 #elif defined(NTK_SV2_NFWD_SALU)
 #define NTK_NFWD(i) "s_and_b64 vcc, %[V" #i "], %[F" #i "]\n s_bcnt1_i32_b64 vcc_lo, vcc\n s_add_u32 %[nf], %[nf], vcc_lo\n"
 #define NTK_NF_OUT , [nf] "=&s"(nf_grp)
-#define NTK_CELL_IN [one] "v"(one)
+#define NTK_CELL_IN [one] "v"(one), [xcell] "v"(cell)
 #define NTK_NF_ZERO "s_mov_b32 %[nf], 0\n"
         uint32_t nf_grp = 0;
 #else
@@ -482,10 +498,10 @@ struct DevMasks2 {
         NTK_NFWD(i)
             asm volatile(NTK_NF_ZERO NTK_EMIT1(0) NTK_EMIT1(1) NTK_EMIT1(2) NTK_EMIT1(3) "s_mov_b64 exec, -1\n"
                          : [sum] "+v"(sum), [xlo] "+v"(xlo) NTK_NF_OUT
-                         : [o0] "v"(off[0]), [l0] "v"(lo[0]), [V0] "s"(V[jb + 0]), [F0] "s"(F[0]),
-                           [o1] "v"(off[1]), [l1] "v"(lo[1]), [V1] "s"(V[jb + 1]), [F1] "s"(F[1]),
-                           [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[jb + 2]), [F2] "s"(F[2]),
-                           [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[jb + 3]), [F3] "s"(F[3]),
+                         : [o0] "v"(off[0]), [l0] "v"(lo[0]), [V0] "s"(V[pos[0]]), [F0] "s"(F[0]),
+                           [o1] "v"(off[1]), [l1] "v"(lo[1]), [V1] "s"(V[pos[1]]), [F1] "s"(F[1]),
+                           [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
+                           [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
                            NTK_CELL_IN
                          : "memory", "vcc", "scc");
 #undef NTK_EMIT1
@@ -499,10 +515,10 @@ struct DevMasks2 {
         NTK_NFWD(i)
             asm volatile(NTK_NF_ZERO NTK_EMIT1(0) NTK_EMIT1(1) NTK_EMIT1(2) NTK_EMIT1(3) "s_mov_b64 exec, -1\n"
                          : [sum] "+v"(sum), [xT] "+v"(xT), [xlo] "+v"(xlo) NTK_NF_OUT
-                         : [o0] "v"(off[0]), [v0] "v"(val[0]), [l0] "v"(lo[0]), [T0] "v"(T[0]), [V0] "s"(V[jb + 0]), [F0] "s"(F[0]),
-                           [o1] "v"(off[1]), [v1] "v"(val[1]), [l1] "v"(lo[1]), [T1] "v"(T[1]), [V1] "s"(V[jb + 1]), [F1] "s"(F[1]),
-                           [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[jb + 2]), [F2] "s"(F[2]),
-                           [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[jb + 3]), [F3] "s"(F[3]),
+                         : [o0] "v"(off[0]), [v0] "v"(val[0]), [l0] "v"(lo[0]), [T0] "v"(T[0]), [V0] "s"(V[pos[0]]), [F0] "s"(F[0]),
+                           [o1] "v"(off[1]), [v1] "v"(val[1]), [l1] "v"(lo[1]), [T1] "v"(T[1]), [V1] "s"(V[pos[1]]), [F1] "s"(F[1]),
+                           [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
+                           [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
                            NTK_CELL_IN
                          : "memory", "vcc", "scc");
 #undef NTK_EMIT1
@@ -585,23 +601,12 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         }
         uint32_t voff = lane * 16u - (32u - halo);
         uint64_t tile_byte = run_byte;
-        // two tiles of load in flight per wave
-        u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-        u32x4 nx1 = cur, curq = cur, nx1q = cur;
-        if constexpr (QM) curq = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
-        if (r0 + 1 < r1) {
-            nx1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + kTileStride, 0, 0);
-            if constexpr (QM) nx1q = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + kTileStride, 0, 0);
-        }
-        for (uint32_t r = r0; r < r1; r++) {
-            u32x4 nx2 = nx1, nx2q = nx1q;
-            if (r + 2 < r1) {  // wave-uniform
-                nx2 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 2 * kTileStride, 0, 0);
-                if constexpr (QM) nx2q = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + 2 * kTileStride, 0, 0);
-            }
+        auto load_tile = [&](uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); };
+        auto load_qual = [&](uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0); };
+        auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r) {
             const bool tail = r >= a.tail_tile_rel;
-            Raw16 raw{cur.x, cur.y, cur.z, cur.w};
-            if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
+            Raw16 raw{t.x, t.y, t.z, t.w};
+            if constexpr (QM) raw = quality_break16(raw, Raw16{q.x, q.y, q.z, q.w}, a.q_add, a.q_sel);
 #ifdef NTK_ABL_LOADSONLY
             mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
 #else
@@ -609,7 +614,27 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             mp.compute(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
             lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
-            cur = nx1; nx1 = nx2; curq = nx1q; nx1q = nx2q; voff += kTileStride; tile_byte += kTileStride;
+            voff += kTileStride; tile_byte += kTileStride;
+        };
+        // the next tile's load is in flight while the current one is processed; two tiles per loop trip so that the two
+        // register sets swap roles without moves
+        u32x4 ta = load_tile(voff), qa = ta, tb = ta, qb = ta;
+        if constexpr (QM) qa = load_qual(voff);
+#ifndef NTK_SV2_PINGPONG   // (two tiles per loop trip without register moves doubles the loop body: measured 5 - 25 % slower, profiles/r02b)
+        for (uint32_t r = r0; r < r1; r++) {
+            if (r + 1 < r1) { tb = load_tile(voff + kTileStride); if constexpr (QM) qb = load_qual(voff + kTileStride); }
+            process(ta, qa, r);
+            ta = tb; qa = qb;
+        }
+        if (false)
+#endif
+        for (uint32_t r = r0; r < r1; r += 2) {
+            const bool has_b = r + 1 < r1;   // wave-uniform
+            if (has_b) { tb = load_tile(voff + kTileStride); if constexpr (QM) qb = load_qual(voff + kTileStride); }
+            process(ta, qa, r);
+            if (!has_b) break;
+            if (r + 2 < r1) { ta = load_tile(voff + kTileStride); if constexpr (QM) qa = load_qual(voff + kTileStride); }
+            process(tb, qb, r + 1);
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }
@@ -620,6 +645,9 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     uint64_t sum = mp.sum, xr = ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
     uint64_t shi = 0, xf = 0;   // LIGHT: high parts of the digests, from the histogram
     uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
+#ifdef NTK_SV2_XOR_LDS
+    mp.xlo = s_nfwd[threadIdx.x];   // the cell holds the lane's xor of lo words
+#endif
 #if defined(NTK_SV2_NFWD_VALU)
     nf = mp.nf_v;
 #elif defined(NTK_SV2_NFWD_SALU)

@@ -499,10 +499,10 @@ NTK_HD void lane_tile_sv1(Sink &sink, XL &xl, MP &mp, const EncSV &en)
 // ---------------------------------------------------------------------------------------------
 // "sv2": the scalar-validity reduce path, second generation (17 <= K <= 32, canonical).
 //
-// * No byte transpose: the four dwords are used as loaded (byte b of dword i = base 4i + b).  The 2-bit codes of a
-//   dword are gathered by ONE v_dot4_u32_u8 (byte & 6 = 2 * code; weights 64, 16, 4, 1), and the "is a base" test is a
-//   nibble LUT: v_perm_b32 with the byte's low nibble as selector returns the only letter with that nibble (selectors
-//   8..15 return 0x00 / 0xFF, which no case-folded byte equals), compared with the case-folded byte by SDWA.
+// * No byte transpose: the four dwords are used as loaded (byte b of dword i = base 4i + b).  Two 8-entry LUTs
+//   (v_perm_b32, selector = the byte's low 3 bits) give the only letter with those bits and twice its 2-bit code; the
+//   "is a base" test is an SDWA byte compare of that letter with the case-folded byte, and the four codes of a dword
+//   are gathered by ONE v_dot4_u32_u8 (weights 64, 16, 4, 1).
 // * Strand choice on 32 bits.  With T = the TOP 32 bits (first 16 bases) of a 2K-bit value, K <= 32:
 //       T_fwd != T_rc  ->  the values order like their T words (T is the most significant part);
 //       T_fwd == T_rc  ->  base i = complement of base K-1-i for i = 0..15, and (i <-> K-1-i is the same condition)
@@ -529,16 +529,21 @@ NTK_HD EncSV2 encode16_sv2(Raw16 d)
     const uint32_t w[4] = {d.x, d.y, d.z, d.w};
     EncSV2 r;
     uint32_t p[4];
-    // nibble LUT: 1 -> A, 3 -> C, 4 -> T, 5 -> U (normalize pipeline only, reference src/sequence.rs:30), 7 -> G; 0xFF elsewhere
+    // 8-entry LUTs (v_perm_b32, selector = the byte's low 3 bits):
+    //   letter: 1 -> A, 3 -> C, 4 -> T, 5 -> U (normalize pipeline only, reference src/sequence.rs:30), 7 -> G; 0xFF elsewhere.
+    //           A byte is a base iff its case-folded value EQUALS the letter its low bits select (SDWA compare).
+    //   code  : 2 * the letter's 2-bit code A0 C1 G2 T3 (reference src/bitkmer.rs:8-15); 0 elsewhere (every window over a
+    //           non-letter is dropped, and 0 cannot spill into the neighbouring bases' bits in the dot product)
     constexpr uint32_t kLutLo = 0x43FF41FFu, kLutHi = ACCEPT_U ? 0x47FF5554u : 0x47FFFF54u;
+    constexpr uint32_t kCodeLo = 0x02000000u, kCodeHi = ACCEPT_U ? 0x04000606u : 0x04000006u;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        p[i] = dot4(w[i] & 0x06060606u, 0x01041040u, 0u);   // 2 * (c0 c1 c2 c3 as one byte), ASCII bits 2:1: A0 C1 T2 G3
-        r.ex[i] = perm(kLutHi, kLutLo, w[i] & 0x0F0F0F0Fu);
+        const uint32_t n = w[i] & 0x07070707u;
+        r.ex[i] = perm(kLutHi, kLutLo, n);
+        p[i] = dot4(perm(kCodeHi, kCodeLo, n), 0x01041040u, 0u);   // 2 * (c0 c1 c2 c3 as one byte)
         r.uu[i] = w[i] & 0xDFDFDFDFu;
     }
-    const uint32_t m = (((p[0] << 8) + p[1]) << 15) | (((p[2] << 8) + p[3]) >> 1);
-    r.code = bitop3<0x6C>(m >> 1, m, 0x55555555u);            // m ^ ((m >> 1) & 0x5555...): A0 C1 G2 T3 (reference src/bitkmer.rs:8-15)
+    r.code = ((((p[0] << 8) + p[1]) << 15) | (((p[2] << 8) + p[3]) >> 1));
     const uint32_t t = brev32(r.code);
     r.rcode = bitop3<0x35>(0x55555555u, t >> 1, t + t);        // complement, pairs swapped back after the bit reversal
     return r;
@@ -567,42 +572,53 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
     const uint32_t c1 = xl.prev(kSlotCode, code), r1 = xl.prev(kSlotRcode, rcode);
     fw[D + 15] = code; rw[D + 15] = rcode;
     fw[D - 1] = c1;    rw[D - 1] = r1;
-#ifdef NTK_ABL_NOWINDOWS   // ablation: no funnel shifts, no cross-lane words
-#pragma unroll
-    for (int j = 0; j < 15; j++) { fw[D + j] = code ^ (uint32_t)j; rw[D + j] = rcode ^ (uint32_t)j; }
-#pragma unroll
-    for (int g = 2; g <= D; g++) { fw[D - g] = c1 ^ (uint32_t)g; rw[D - g] = r1 ^ (uint32_t)g; }
-#else
 #pragma unroll
     for (int j = 0; j < 15; j++) {
         fw[D + j] = alignbit(c1, code, 30 - 2 * j);
         rw[D + j] = alignbit(rcode, r1, 2 * j + 2);
     }
+    // The previous lane's forward words 16-g (its window ending g bases before our base 0) are T words here: compared and
+    // min-ed, so they are fetched once (DPP move).  Its reverse-complement words are only ever the lo candidate of one
+    // position: they are fetched inside that position's select (select_prev: v_cndmask_b32_dpp on the device).
 #pragma unroll
-    for (int g = 2; g <= D; g++) {     // the previous lane's words 16-g: its window ending / starting g bases before our base 0
-        fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
-        rw[D - g] = xl.prev(kSlotRw + 16 - g, rw[D + 16 - g]);
-    }
-#endif
+    for (int g = 2; g <= D; g++) fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+    // Positions are taken in groups {jp, jp+1, jp+8, jp+9}: the T words of positions j and j+8 sit in ONE register on
+    // either strand - fw[j-D] = (top half of T_fwd(j) : top half of T_fwd(j+8)), rw[j+8] = (top half of T_rc(j+8) : top half
+    // of T_rc(j)) - so in the LIGHT build one packed 16-bit min with crossed halves yields both histogram prefixes.
 #pragma unroll
-    for (int jb = 0; jb < 16; jb += 4) {
+    for (int jp = 0; jp < 8; jp += 2) {
+        const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
         uint32_t T[4], lo[4], hi[4];
         bool fwd[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int j = jb + i;
+            const int j = pos[i];
             const uint32_t ft = fw[j], rt = rw[D + j];            // fw[(j - D) + D], rw[j + D]
             fwd[i] = TIE_RC ? (ft < rt) : (ft <= rt);
-            lo[i] = fwd[i] ? fw[D + j] : rw[j];
-            if (LIGHT) {
-                T[i] = mp.min_top16(ft, rt);                      // top 16 bits of the chosen T word, in bits 15:0
-                hi[i] = 0;
-            } else {
+            if (j - D >= -1) lo[i] = fwd[i] ? fw[D + j] : rw[j];  // rw[(j - D) + D]: own word, or r1
+#ifndef NTK_SV2_SELPREV   // (fusing the cross-lane move into the select - select_prev - measured slower: profiles/r02b)
+            else { const uint32_t pw = xl.prev(kSlotRw + 16 + j - D, rw[16 + j]); lo[i] = fwd[i] ? fw[D + j] : pw; }
+#else
+            else lo[i] = xl.select_prev(kSlotRw + 16 + j - D, fwd[i], fw[D + j], rw[16 + j]);   // previous lane's word 16 + (j - D)
+#endif
+            if (!LIGHT) {
                 T[i] = fwd[i] ? ft : rt;
                 hi[i] = S ? T[i] >> S : T[i];
+            } else {
+                hi[i] = 0;
             }
         }
-        mp.emit4(sink, jb, fwd, T, hi, lo);
+        if (LIGHT) {
+            // (min of the halves == half of the min, whatever the tie rule)
+#ifdef NTK_SV2_NO_PKMIN
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const uint32_t ft = fw[pos[i]], rt = rw[D + pos[i]], m = ft < rt ? ft : rt; T[i] = i < 2 ? m : m >> 16; }
+#else
+            T[0] = T[2] = mp.pk_min16_crossed(fw[pos[0]], rw[D + pos[2]]);   // bits 31:16 -> position jp, bits 15:0 -> jp+8
+            T[1] = T[3] = mp.pk_min16_crossed(fw[pos[1]], rw[D + pos[3]]);
+#endif
+        }
+        mp.emit4(sink, pos, fwd, T, hi, lo);
     }
 }
 

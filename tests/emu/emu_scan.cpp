@@ -53,6 +53,7 @@ struct EmuXL {
     void next_lane(bool first) { if (!first) memcpy(last, cur, sizeof(last)); else memset(last, 0, sizeof(last)); first_lane = first; }
     uint32_t prev(int slot, uint32_t x) { cur[slot] = x; return last[slot]; }
     uint32_t prev_and(int slot, uint32_t x, uint32_t mask) { return prev(slot, x) & mask; }
+    uint32_t select_prev(int slot, bool take, uint32_t a, uint32_t b) { const uint32_t p = prev(slot, b); return take ? a : p; }
 };
 
 Raw16 load16(const uint8_t *buf, uint64_t n_padded, int64_t off)
@@ -155,14 +156,18 @@ struct EmuMP2 {
     uint64_t sum = 0, n_fwd = 0;
     uint32_t xT = 0, xlo = 0;
     std::vector<uint32_t> cells = std::vector<uint32_t>(1u << HB, 0u);
-    uint32_t min_top16(uint32_t a, uint32_t b) const { return (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16); }
+    uint32_t pk_min16_crossed(uint32_t a, uint32_t b) const   // v_pk_min_u16 op_sel:[0,1] op_sel_hi:[1,0]
+    {
+        const uint32_t h = (a >> 16) < (b & 0xFFFFu) ? (a >> 16) : (b & 0xFFFFu), l = (a & 0xFFFFu) < (b >> 16) ? (a & 0xFFFFu) : (b >> 16);
+        return (h << 16) | l;
+    }
     template <class S>
-    void emit4(S &, int jb, const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
+    void emit4(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
     {
         for (int i = 0; i < 4; i++) {
-            if (!((V[jb + i] >> lane) & 1)) continue;
+            if (!((V[pos[i]] >> lane) & 1)) continue;
             uint32_t off;
-            if (kLight) off = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
+            if (kLight && i >= 2) off = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
             else off = HB == 14 ? ((T[i] >> 16) & 0xFFFCu) : ((T[i] >> 18) & 0x3FFCu);
             cells[off >> 2]++;
             if (kLight) { sum += lo[i]; xlo ^= lo[i]; }
