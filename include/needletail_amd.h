@@ -46,10 +46,12 @@ enum {
     NTK_ERR_UNSUPPORTED = 6, /* combination not available on the device path (never falls back) */
     NTK_ERR_NOMEM = 7,
     NTK_ERR_PARSE = 8,       /* FASTA/FASTQ parse error; ntk_reader_error() has kind / line / id / message */
+    NTK_ERR_RCCL = 9,        /* librccl could not be loaded or a collective failed; ntk_last_rccl_error() has the ncclResult_t */
     NTK_EOF = 100            /* ntk_reader_next: no more records (not an error)                 */
 };
 const char *ntk_strerror(int status);
 int ntk_last_hip_error(void);
+int ntk_last_rccl_error(void);   /* ncclResult_t of the last failed RCCL call on this thread; -1 = librccl not loadable */
 int ntk_abi_version(void);
 
 /* ---- parameters (mirror the arguments of the reference's trait methods) --------------------- */
@@ -117,6 +119,26 @@ int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */
 int ntk_ctx_enable_timing(ntk_ctx *ctx, int on);
 int ntk_ctx_scan_time_ms(ntk_ctx *ctx, double *total_ms, uint64_t *launches);
+
+/* ---- multi-GPU: ONE RCCL sum all-reduce of the accumulators -------------------
+ * Record batches shard across the GPUs of a node with no other exchange (the reference has no counterpart: it is a
+ * single-threaded CPU library, Cargo.toml:28-54; a k-mer never spans two records, reference src/sequence.rs:237-252, so the
+ * reduced result is a plain sum over shards).  Every ctx accumulates its own shard; ntk_allreduce_accumulators then runs
+ *     ncclAllReduce(acc, acc, NTK_ACC_WORDS, ncclUint64, ncclSum)
+ * on each ctx's stream (the xor digest travels as 64 one-bit counters, so the one sum carries everything) and rebuilds the
+ * xor word.  librccl is loaded on first use (the copy already in the process, else librccl.so.1). */
+typedef struct ntk_comm ntk_comm;
+#define NTK_COMM_ID_BYTES 128
+/* one process drives n GPUs (ncclCommInitAll): ctxs[i] are contexts on n distinct devices */
+int ntk_comm_init_all(ntk_ctx *const *ctxs, int n, ntk_comm **out);
+/* one process per GPU (ncclCommInitRank): rank 0 makes the id, ships its 128 bytes to the other ranks by any means */
+int ntk_comm_unique_id(uint8_t id[NTK_COMM_ID_BYTES]);
+int ntk_comm_init_rank(ntk_ctx *ctx, int n_ranks, int rank, const uint8_t id[NTK_COMM_ID_BYTES], ntk_comm **out);
+int ntk_comm_size(const ntk_comm *comm);     /* ranks in the communicator */
+/* All ranks (all local ctxs of an init_all communicator): accumulators <- sum over ranks, in place, asynchronous on the
+ * ctx streams; ntk_accum_read / ntk_ctx_synchronize order after it.  Call it once, after the last batch of the run. */
+int ntk_allreduce_accumulators(ntk_comm *comm);
+void ntk_comm_destroy(ntk_comm *comm);
 
 /* ---- batch face, reduce mode ----------------------------------------------------------------
  * Device batch layout: the records' sequence bytes back to back, each followed by ONE break byte

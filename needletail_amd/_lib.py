@@ -19,7 +19,8 @@ ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 
 # every symbol include/needletail_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
-    "ntk_strerror", "ntk_last_hip_error", "ntk_abi_version",
+    "ntk_strerror", "ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version",
+    "ntk_comm_init_all", "ntk_comm_unique_id", "ntk_comm_init_rank", "ntk_comm_size", "ntk_allreduce_accumulators", "ntk_comm_destroy",
     "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
     "ntk_ctx_set_launch", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
     "ntk_accum_reset", "ntk_reduce_device", "ntk_reduce_device_quality", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
@@ -59,7 +60,7 @@ class Record(C.Structure):
 class NtkError(RuntimeError):
     def __init__(self, status: int, what: str):
         self.status = status
-        super().__init__(f"{what}: status {status} ({strerror(status)}; hip={last_hip_error()})")
+        super().__init__(f"{what}: status {status} ({strerror(status)}; hip={last_hip_error()}, rccl={lib().ntk_last_rccl_error()})")
 
 
 _lib = None
@@ -80,6 +81,14 @@ def lib() -> C.CDLL:
     L.ntk_strerror.argtypes = [i32]
     L.ntk_last_hip_error.restype = i32
     L.ntk_abi_version.restype = i32
+    L.ntk_last_rccl_error.restype = i32
+    L.ntk_comm_init_all.argtypes = [C.POINTER(C.c_void_p), i32, pp]
+    L.ntk_comm_unique_id.argtypes = [C.c_char_p]
+    L.ntk_comm_init_rank.argtypes = [vp, i32, i32, C.c_char_p, pp]
+    L.ntk_comm_size.argtypes = [vp]
+    L.ntk_allreduce_accumulators.argtypes = [vp]
+    L.ntk_comm_destroy.restype = None
+    L.ntk_comm_destroy.argtypes = [vp]
     L.ntk_ctx_create.argtypes = [i32, pp]
     L.ntk_ctx_create_on_stream.argtypes = [i32, vp, pp]
     L.ntk_ctx_destroy.restype = None
@@ -130,7 +139,7 @@ def lib() -> C.CDLL:
     L.ntk_quality_mask.argtypes = [vp, C.c_char_p, C.c_char_p, u64, C.c_uint8, C.c_char_p]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("ntk_last_hip_error", "ntk_abi_version"):
+        if fn.restype is C.c_int and name not in ("ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -3,6 +3,8 @@
 #include "../../include/needletail_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is loaded at run time (load_rccl)
+#include <dlfcn.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +21,7 @@ using namespace ntk;
 namespace {
 
 thread_local int g_last_hip = 0;
+thread_local int g_last_rccl = 0;
 
 // HIP caps gridDim.x * blockDim.x below 2^32 and silently wraps beyond it: element-wise kernels are grid-stride and are
 // launched with at most 2^20 blocks.
@@ -387,11 +390,13 @@ const char *ntk_strerror(int s)
     case NTK_ERR_UNSUPPORTED: return "combination not supported on the device path (no CPU fallback exists)";
     case NTK_ERR_NOMEM: return "out of memory";
     case NTK_ERR_PARSE: return "FASTA/FASTQ parse error (see ntk_reader_error)";
+    case NTK_ERR_RCCL: return "RCCL error (see ntk_last_rccl_error)";
     case NTK_EOF: return "end of input";
     default: return "unknown status";
     }
 }
 int ntk_last_hip_error(void) { return g_last_hip; }
+int ntk_last_rccl_error(void) { return g_last_rccl; }
 int ntk_abi_version(void) { return NTK_ABI_VERSION; }
 
 int ntk_ctx_create(int device, ntk_ctx **out) { return create_ctx(device, nullptr, false, out); }
@@ -1038,3 +1043,142 @@ int ntk_reverse_complement_records_device(ntk_ctx *c, const uint8_t *d_in, uint8
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: one RCCL all-reduce of the accumulators
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    bool ok = false;
+};
+const RcclApi &load_rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy already mapped into the process first (a torch process brings its own librccl.so), then the ROCm one
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!h) for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+#define NTK_RCCL_SYM(f) api.f = (decltype(api.f))dlsym(h, "nccl" #f); if (!api.f) return;
+        NTK_RCCL_SYM(GetUniqueId) NTK_RCCL_SYM(CommInitRank) NTK_RCCL_SYM(CommInitAll) NTK_RCCL_SYM(CommDestroy)
+        NTK_RCCL_SYM(AllReduce) NTK_RCCL_SYM(GroupStart) NTK_RCCL_SYM(GroupEnd)
+#undef NTK_RCCL_SYM
+        api.ok = true;
+    });
+    return api;
+}
+#define RCCLCHK(x)                                                  \
+    do {                                                            \
+        ncclResult_t r__ = (x);                                     \
+        if (r__ != ncclSuccess) { g_last_rccl = (int)r__; return NTK_ERR_RCCL; } \
+    } while (0)
+
+// after the all-reduce the xor word holds a SUM of xors: rebuild it from the 64 one-bit counters (parity of each sum)
+__global__ void xor_from_bit_counters_kernel(uint64_t *acc)
+{
+    const uint64_t bit = acc[NTK_ACC_XOR_BITS + threadIdx.x] & 1ull;
+    const uint64_t word = __builtin_amdgcn_ballot_w64(bit != 0);
+    if (threadIdx.x == 0) acc[NTK_ACC_XOR] = word;
+}
+}  // namespace
+
+extern "C" {
+
+struct ntk_comm {
+    std::vector<ntk_ctx *> ctxs;     // local contexts (1 for init_rank, n for init_all)
+    std::vector<ncclComm_t> comms;   // one communicator handle per local context
+    int size = 0;
+};
+
+int ntk_comm_unique_id(uint8_t id[NTK_COMM_ID_BYTES])
+{
+    if (!id) return NTK_ERR_BAD_ARG;
+    const RcclApi &R = load_rccl();
+    if (!R.ok) { g_last_rccl = -1; return NTK_ERR_RCCL; }
+    static_assert(sizeof(ncclUniqueId) == NTK_COMM_ID_BYTES, "NTK_COMM_ID_BYTES follows ncclUniqueId");
+    ncclUniqueId u;
+    RCCLCHK(R.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return NTK_OK;
+}
+
+int ntk_comm_init_rank(ntk_ctx *c, int n_ranks, int rank, const uint8_t id[NTK_COMM_ID_BYTES], ntk_comm **out)
+{
+    if (!c || !id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return NTK_ERR_BAD_ARG;
+    *out = nullptr;
+    const RcclApi &R = load_rccl();
+    if (!R.ok) { g_last_rccl = -1; return NTK_ERR_RCCL; }
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t h = nullptr;
+    RCCLCHK(R.CommInitRank(&h, n_ranks, u, rank));
+    ntk_comm *m = new (std::nothrow) ntk_comm();
+    if (!m) { (void)R.CommDestroy(h); return NTK_ERR_NOMEM; }
+    m->ctxs.push_back(c); m->comms.push_back(h); m->size = n_ranks;
+    *out = m;
+    return NTK_OK;
+}
+
+int ntk_comm_init_all(ntk_ctx *const *ctxs, int n, ntk_comm **out)
+{
+    if (!ctxs || !out || n < 1) return NTK_ERR_BAD_ARG;
+    *out = nullptr;
+    std::vector<int> devs;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return NTK_ERR_BAD_ARG;
+        for (int d : devs) if (d == ctxs[i]->device) return NTK_ERR_BAD_ARG;   // one context per device
+        devs.push_back(ctxs[i]->device);
+    }
+    const RcclApi &R = load_rccl();
+    if (!R.ok) { g_last_rccl = -1; return NTK_ERR_RCCL; }
+    std::vector<ncclComm_t> hs((size_t)n, nullptr);
+    RCCLCHK(R.CommInitAll(hs.data(), n, devs.data()));
+    ntk_comm *m = new (std::nothrow) ntk_comm();
+    if (!m) { for (ncclComm_t h : hs) (void)R.CommDestroy(h); return NTK_ERR_NOMEM; }
+    m->ctxs.assign(ctxs, ctxs + n); m->comms = hs; m->size = n;
+    *out = m;
+    return NTK_OK;
+}
+
+int ntk_comm_size(const ntk_comm *m) { return m ? m->size : 0; }
+
+int ntk_allreduce_accumulators(ntk_comm *m)
+{
+    if (!m) return NTK_ERR_BAD_ARG;
+    const RcclApi &R = load_rccl();
+    if (!R.ok) { g_last_rccl = -1; return NTK_ERR_RCCL; }
+    RCCLCHK(R.GroupStart());
+    for (size_t i = 0; i < m->ctxs.size(); i++) {
+        ntk_ctx *c = m->ctxs[i];
+        ncclResult_t r = R.AllReduce(c->d_acc, c->d_acc, NTK_ACC_WORDS, ncclUint64, ncclSum, m->comms[i], c->stream);
+        if (r != ncclSuccess) { (void)R.GroupEnd(); g_last_rccl = (int)r; return NTK_ERR_RCCL; }
+    }
+    RCCLCHK(R.GroupEnd());
+    for (ntk_ctx *c : m->ctxs) {
+        HIPCHK(hipSetDevice(c->device));
+        hipLaunchKernelGGL(xor_from_bit_counters_kernel, dim3(1), dim3(64), 0, c->stream, c->d_acc);
+        HIPCHK(hipGetLastError());
+    }
+    return NTK_OK;
+}
+
+void ntk_comm_destroy(ntk_comm *m)
+{
+    if (!m) return;
+    const RcclApi &R = load_rccl();
+    if (R.ok) for (ncclComm_t h : m->comms) if (h) (void)R.CommDestroy(h);
+    delete m;
+}
+
+}  // extern "C"
+

@@ -6,9 +6,79 @@ buffer at the end of a pass.  The xor digest cannot be summed, so the fold kerne
 counters (NTK_ACC_XOR_BITS) whose parities survive a sum."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
+from . import _lib as L
 from ._lib import ACC_HIST, ACC_N_FWD, ACC_N_RC, ACC_N_TOTAL, ACC_SUM, ACC_WORDS, ACC_XOR, ACC_XOR_BITS, HIST_BINS
+
+COMM_ID_BYTES = 128
+BATCH_RECORDS = 1 << 20   # SURVEY.md 8d/8e: record i -> GPU (i / BATCH_RECORDS) mod n_gpus
+
+
+def round_robin_batches(n_records: int, rank: int, world: int, batch_records: int = BATCH_RECORDS):
+    """[(first_record, n_records), ...] of the record batches `rank` owns when batches of `batch_records` records are
+    dealt round-robin to `world` GPUs (config 4 of BASELINE.json)."""
+    if not (0 <= rank < world) or batch_records < 1:
+        raise ValueError("bad rank / batch size")
+    out = []
+    n_batches = (n_records + batch_records - 1) // batch_records
+    for b in range(rank, n_batches, world):
+        first = b * batch_records
+        out.append((first, min(batch_records, n_records - first)))
+    return out
+
+
+class Communicator:
+    """RCCL communicator behind the C ABI (ntk_comm_*): the accumulators of all ranks are summed by ONE ncclAllReduce
+    (ncclUint64, ncclSum, NTK_ACC_WORDS words) on each context's stream.
+
+    `Communicator.for_rank(ctx, n_ranks, rank, id_bytes)`: one process per GPU; rank 0 makes `unique_id()` and ships it.
+    `Communicator.all_local(ctxs)`: one process driving several GPUs (ncclCommInitAll)."""
+
+    def __init__(self, handle, ctxs):
+        self._h = handle
+        self._ctxs = list(ctxs)   # keep the contexts alive
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        L.check(L.lib().ntk_comm_unique_id(buf), "ntk_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def for_rank(cls, ctx, n_ranks: int, rank: int, id_bytes: bytes) -> "Communicator":
+        if len(id_bytes) != COMM_ID_BYTES:
+            raise ValueError("the communicator id has 128 bytes")
+        h = C.c_void_p()
+        L.check(L.lib().ntk_comm_init_rank(ctx._h, n_ranks, rank, id_bytes, C.byref(h)), "ntk_comm_init_rank")
+        return cls(h, [ctx])
+
+    @classmethod
+    def all_local(cls, ctxs) -> "Communicator":
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        h = C.c_void_p()
+        L.check(L.lib().ntk_comm_init_all(arr, len(ctxs), C.byref(h)), "ntk_comm_init_all")
+        return cls(h, ctxs)
+
+    @property
+    def size(self) -> int:
+        return int(L.lib().ntk_comm_size(self._h))
+
+    def allreduce_accumulators(self):
+        L.check(L.lib().ntk_allreduce_accumulators(self._h), "ntk_allreduce_accumulators")
+
+    def close(self):
+        if self._h:
+            L.lib().ntk_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def shard_range(n_items: int, rank: int, world: int):

@@ -31,6 +31,24 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def use_native_build() -> str:
+    """Switch this process to a `-O3 -march=native` build of the same source (the CPU baseline is timed
+    with the host's own instruction set).  It is compiled where it runs (oracle/_native/, git-ignored): an object built
+    for another machine's `native` could fault here.  Returns the compiler flags used; falls back to the portable
+    build (and says so) when gcc is not available."""
+    global _SO, _lib
+    out_dir = os.path.join(_HERE, "_native")
+    out = os.path.join(out_dir, "libntk_oracle_native.so")
+    flags = "-O3 -march=native -fPIC -std=c11"
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc", *flags.split(), "-shared", "-o", out, os.path.join(_HERE, "ntk_oracle.c"), "-lpthread"])
+    except (OSError, subprocess.CalledProcessError):
+        return "-O3 -march=x86-64-v2 (portable build: gcc -march=native failed here)"
+    _SO, _lib = out, None
+    return flags
+
+
 class BitKmer(C.Structure):
     _fields_ = [("seq", C.c_uint64), ("k", C.c_uint8)]
 
@@ -62,7 +80,8 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
+        if not _SO.endswith("_native.so"):
+            build()
         L = C.CDLL(_SO)
         u8p, u64p, sz = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_size_t
         L.ntko_normalize.restype = sz

@@ -27,9 +27,16 @@ def _worker(rank, world, port, n_reads, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        b, e = D.shard_range(n_reads, rank, world)
-        buf = O.synth_reads(0x5EED0004, b, e - b, 150, 4)
-        st = O.reduce_fused(buf, 21, True, True, True)
+        # config-4 partition: record batches dealt round-robin (record i -> rank (i / batch) mod world), SURVEY.md 8d
+        parts = [O.reduce_fused(O.synth_reads(0x5EED0004, first, n, 150, 4), 21, True, True, True)
+                 for first, n in D.round_robin_batches(n_reads, rank, world, batch_records=64)]
+        st = {"n_total": 0, "n_fwd": 0, "n_rc": 0, "sum": 0, "xor": 0, "hist": np.zeros(4096, dtype=np.uint64)}
+        for q in parts:
+            for key in ("n_total", "n_fwd", "n_rc"):
+                st[key] += q[key]
+            st["sum"] = (st["sum"] + q["sum"]) & (2 ** 64 - 1)
+            st["xor"] ^= q["xor"]
+            st["hist"] = st["hist"] + q["hist"]
         acc = torch.from_numpy(D.encode_accumulators(st).copy())
         D.allreduce_accumulators(acc)
         got = D.decode_accumulators(acc)
@@ -74,3 +81,18 @@ def test_encode_decode_roundtrip():
     st = O.reduce_fused(O.synth_reads(1, 0, 50, 150, 8), 21, True, True, True)
     got = D.decode_accumulators(D.encode_accumulators(st))
     assert got["xor"] == st["xor"] and got["sum"] == st["sum"] and np.array_equal(got["hist"], st["hist"])
+
+
+def test_round_robin_batches_partition_the_records():
+    for n, world, batch in ((1001, 2, 64), (1 << 12, 8, 1 << 9), (5, 3, 2), (0, 2, 4), (100, 4, 1000)):
+        seen = []
+        for r in range(world):
+            got = D.round_robin_batches(n, r, world, batch)
+            for first, cnt in got:
+                assert cnt >= 1 and first % batch == 0 and (first // batch) % world == r
+                seen.extend(range(first, first + cnt))
+        assert sorted(seen) == list(range(n))
+    with pytest.raises(ValueError):
+        D.round_robin_batches(10, 2, 2)
+    b, e = D.shard_range(10, 1, 3)
+    assert (b, e) == (4, 7)

@@ -885,3 +885,22 @@ def test_scan_larger_than_one_launch(ctx):
     assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(O.synth_reads(0x5EED0004, 0, sample, L, 1), k, 11, True, True), "minimizer prefix")
     del seq
     torch.cuda.empty_cache()
+
+
+def test_rccl_allreduce_through_the_c_abi_single_rank(ctx):
+    """The RCCL path of the C ABI (ntk_comm_* / ntk_allreduce_accumulators: ncclAllReduce(ncclUint64, ncclSum) on the scan
+    stream + the xor rebuild) with a one-rank communicator: the sum over one rank is the rank's own result."""
+    from needletail_amd import distributed as D
+    buf = O.synth_reads(0x5EED0004, 0, 5000, 150, 2).tobytes()
+    want = O.reduce_fused(buf, 21, True, True, True)
+    t = to_dev(buf)
+    for make in (lambda: D.Communicator.for_rank(ctx, 1, 0, D.Communicator.unique_id()), lambda: D.Communicator.all_local([ctx])):
+        with make() as comm:
+            assert comm.size == 1
+            for _ in range(2):
+                ctx.accum_reset()
+                ctx.reduce_device(t, len(buf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+                comm.allreduce_accumulators()
+                assert_stats_equal(ctx.accum_read(), want, "rccl single rank")
+    with pytest.raises(nt.NtkError):
+        D.Communicator.for_rank(ctx, 2, 5, b"\0" * 128)   # rank out of range: an argument error, not a hang
