@@ -268,6 +268,9 @@ def main():
                     help="untimed GPU activity before the warm-up steps: a step lasts ~0.5 ms and the clocks take ~40 ms of load to "
                          "reach their steady state")
     ap.add_argument("--reads", type=int, default=None, help="reads in total (default: 10 M at N = 1, 100 M at N > 1)")
+    ap.add_argument("--workload", default="auto", choices=("auto", "c2", "c4"),
+                    help="auto: configs[1] at N = 1, configs[3] at N > 1; c4 at N = 1 scans the whole config-4 read set on one GPU "
+                         "(what the N > 1 result must equal)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--n-per-1024", type=int, default=1)
@@ -325,7 +328,9 @@ def main():
 
     # ---- workload ------------------------------------------------------------------------------------------------
     stride = args.read_len + 1
-    if world == 1:
+    if args.workload == "c2" and world > 1:
+        raise SystemExit("--workload c2 is the single-GPU configuration")
+    if world == 1 and args.workload != "c4":
         seed, total_reads = SEED_C2, (args.reads or 10_000_000)
         batches = [(0, total_reads)]
         workload = (f"configs[1]: synthetic FASTQ {total_reads / 1e6:g}M x {args.read_len} bp, k={args.k} canonical k-mers "
@@ -334,7 +339,7 @@ def main():
         seed, total_reads = SEED_C4, (args.reads or C4_TOTAL_READS)
         batches = nd.round_robin_batches(total_reads, rank, world)
         workload = (f"configs[3]: synthetic FASTQ {total_reads / 1e6:g}M x {args.read_len} bp in total, k={args.k} canonical k-mers, "
-                    f"record batches of 2^20 reads dealt round-robin to {world} GPUs, one RCCL all-reduce of the accumulators per step")
+                    f"record batches of 2^20 reads dealt round-robin to {world} GPU(s), one RCCL all-reduce of the accumulators per step")
     my_reads = sum(n for _, n in batches)
     n_bytes = my_reads * stride
     seq = torch.empty(n_bytes + 2048, dtype=torch.uint8, device="cuda")
@@ -431,7 +436,7 @@ def main():
         verified = f"bit-exact vs the oracle on all {total_reads} reads (5 scalars + 4096 bins; {verify_s:.1f} s of CPU per rank, untimed)"
 
     traffic, traffic_source = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes is not None else None)
-    if traffic is None and world == 1 and (total_reads, args.read_len, args.k, args.n_per_1024) == (10_000_000, 150, 21, 1):
+    if traffic is None and world == 1 and seed == SEED_C2 and (total_reads, args.read_len, args.k, args.n_per_1024) == (10_000_000, 150, 21, 1):
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_scan_kernel.json")))
         if cands:
@@ -491,7 +496,7 @@ def main():
                 "launches_timed": launches,
             },
         }
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and seed == SEED_C2:
         out["cpu_baseline"] = None if args.no_cpu_baseline else \
             cpu_baseline(ctx, seq, args.k, args.read_len, args.n_per_1024, total_reads, args.cpu_budget_s)
         if not args.no_secondary:

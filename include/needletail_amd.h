@@ -266,6 +266,18 @@ int ntk_canonical_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k
 int ntk_bit_kmers(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t k, int canonical,
                   uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *count);
 
+/* The same for a whole batch of records in ONE call (one upload, one scan, device-side compaction, one download) - what
+ * an `impl Sequence` over a FastxReader loop should bind: a per-record call is launch-latency-bound for 150 bp reads.
+ * seq + offsets[n_records + 1]: record i = seq[offsets[i] .. offsets[i + 1]).  counts[i] = items of record i; the item
+ * arrays hold the records' items consecutively, each record's in the reference iterator's order (positions are relative
+ * to the record).  cap >= sum over records of max(0, len - k + 1) always suffices; NTK_ERR_CAPACITY sets *total = needed.
+ * ntk_canonical_kmers_batch: any k <= 255, raw-byte comparison as reference src/kmer.rs:121-128 (rc = the record's own
+ * reverse complement).  ntk_bit_kmers_batch: k <= 32, reference src/bitkmer.rs:80-109. */
+int ntk_canonical_kmers_batch(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
+                              uint64_t *counts, uint64_t *pos_out, uint8_t *is_rc_out, uint64_t cap, uint64_t *total);
+int ntk_bit_kmers_batch(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,
+                        uint64_t *counts, uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *total);
+
 /* ---- minimizers and quality masking ------------------------------------------------ */
 /* Windowed minimizers, reduce mode (BASELINE.json configs[4], "minimizers (w, k)"): for every window of w+k-1 good
  * bases the smallest canonical k-mer in it = sequence::minimizer(window, k) (reference src/sequence.rs:139-152).

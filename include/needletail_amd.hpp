@@ -153,7 +153,7 @@ inline std::pair<BitKmer, bool> canonical(BitKmer kmer, Context &c = Context::gl
 inline BitKmer minimizer(BitKmer kmer, uint8_t minmer_size, Context &c = Context::global()) {
     uint64_t out = 0;
     check(ntk_bit_minimizers(c.get(), &kmer.first, 1, kmer.second, minmer_size, &out), "ntk_bit_minimizers");
-    return BitKmer{out, minmer_size};
+    return BitKmer{out, kmer.second};   // the reference returns (lowest, kmer.1): the ORIGINAL k (src/bitkmer.rs:146-162)
 }
 }  // namespace bitkmer
 

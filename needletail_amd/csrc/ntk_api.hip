@@ -102,6 +102,7 @@ struct ntk_ctx {
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
     Scratch scratch[6];
+    void *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned staging of the batched compat face
     void *h_pinned = nullptr;  // small pinned staging for scalar read-backs
     bool timing = false;
     std::vector<hipEvent_t> ev_free;
@@ -335,6 +336,8 @@ void destroy_batch(ntk_batch *b)
     delete b;
 }
 
+int init_ctx(ntk_ctx *c, void *stream, bool borrow);
+
 int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
 {
     if (!out) return NTK_ERR_BAD_ARG;
@@ -350,6 +353,14 @@ int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
     if (!c) return NTK_ERR_NOMEM;
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int rc = init_ctx(c, stream, borrow);
+    if (rc != NTK_OK) { ntk_ctx_destroy(c); return rc; }   // nothing created so far is leaked (destroy skips what is null)
+    *out = c;
+    return NTK_OK;
+}
+
+int init_ctx(ntk_ctx *c, void *stream, bool borrow)
+{
     if (borrow) { c->stream = (hipStream_t)stream; c->owns_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -370,7 +381,6 @@ int create_ctx(int device, void *stream, bool borrow, ntk_ctx **out)
         if (v >= 4096) c->minimizer_chunk = v & ~(uint64_t)4095;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    *out = c;
     return NTK_OK;
 }
 
@@ -406,8 +416,8 @@ void ntk_ctx_destroy(ntk_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->copy_stream);
+    if (c->stream || !c->owns_stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto &p : c->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     for (auto b : c->pool) destroy_batch(b);
@@ -419,6 +429,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -863,6 +874,145 @@ int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int ca
     }
     *count = mcount;
     return mcount > cap ? NTK_ERR_CAPACITY : NTK_OK;
+}
+
+/* ---- batched compat face ------------------------------------------------------------------------------------------- */
+namespace {
+// Packs the records (one break byte after each) into pinned memory, uploads bytes and packed record starts.
+// Device: scratch[0] = packed bytes, scratch[5] = rec_start (n_records + 1 u64).
+int upload_packed_records(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint64_t *packed_n)
+{
+    if (offsets[0] > offsets[n_records]) return NTK_ERR_BAD_ARG;
+    for (uint64_t r = 0; r < n_records; r++) if (offsets[r] > offsets[r + 1]) return NTK_ERR_BAD_ARG;
+    const uint64_t n = offsets[n_records] - offsets[0] + n_records;
+    const size_t stage_bytes = (size_t)n + (size_t)(n_records + 1) * 8 + 64;
+    if (c->h_stage_bytes < stage_bytes) {
+        if (c->h_stage) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_stage)); c->h_stage = nullptr; c->h_stage_bytes = 0; }
+        HIPCHK(hipHostMalloc(&c->h_stage, stage_bytes + stage_bytes / 4, hipHostMallocDefault));
+        c->h_stage_bytes = stage_bytes + stage_bytes / 4;
+    }
+    uint64_t *h_start = (uint64_t *)c->h_stage;                       // 8-byte aligned head
+    uint8_t *h_seq = (uint8_t *)c->h_stage + (size_t)(n_records + 1) * 8;
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < n_records; r++) {
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        h_start[r] = w;
+        if (len) memcpy(h_seq + w, seq + offsets[r], len);
+        h_seq[w + len] = '\n';
+        w += len + 1;
+    }
+    h_start[n_records] = w;
+    int rc;
+    const uint64_t nt = (n + 15) / 16 * 16;
+    if ((rc = ensure_scratch(c, 0, nt + 16))) return rc;
+    if ((rc = ensure_scratch(c, 5, (size_t)(n_records + 1) * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(c->scratch[0].p, h_seq, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->scratch[5].p, h_start, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    *packed_n = n;
+    return NTK_OK;
+}
+
+// Planes -> dense per-record item arrays on the device, then to the caller.  d_values may be null (byte path).
+int compact_items(ntk_ctx *c, const uint16_t *d_v16, const uint16_t *d_r16, const uint64_t *d_values, uint64_t n, uint64_t n_records,
+                  uint32_t index_shift, uint64_t *counts, uint64_t *pos_out, uint64_t *val_out, uint8_t *flag_out, uint64_t cap,
+                  uint64_t *total)
+{
+    const uint64_t n_words = (n + 15) >> 4;
+    const uint64_t nblocks = (n_words + kCpBlockWords - 1) / kCpBlockWords;
+    int rc;
+    // one scratch slot holds: block_items u32[nblocks] | block_off u64[nblocks] | total u64 | counts u64[n_records]
+    const size_t o_off = ((size_t)nblocks * 4 + 7) & ~(size_t)7, o_total = o_off + (size_t)nblocks * 8, o_counts = o_total + 8;
+    if ((rc = ensure_scratch(c, 4, o_counts + (size_t)n_records * 8))) return rc;
+    uint8_t *base = (uint8_t *)c->scratch[4].p;
+    uint32_t *d_items = (uint32_t *)base;
+    uint64_t *d_off = (uint64_t *)(base + o_off), *d_total = (uint64_t *)(base + o_total), *d_counts = (uint64_t *)(base + o_counts);
+    hipLaunchKernelGGL(cp_count_kernel, dim3((unsigned)nblocks), dim3(kCpThreads), 0, c->stream, d_v16, n_words, d_items);
+    hipLaunchKernelGGL(cp_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_items, d_off, nblocks, d_total);
+    HIPCHK(hipGetLastError());
+    uint64_t *h = (uint64_t *)c->h_pinned;
+    HIPCHK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t m = h[0];
+    *total = m;
+    const uint64_t take = m < cap ? m : cap;
+    // dense outputs on the device: scratch[1] is free again for the byte path (flags8) but holds the values for the bit
+    // path, so the outputs get their own slots: pos -> scratch[2] / [3] hold the planes; use one fresh allocation per call
+    uint64_t *d_pos = nullptr, *d_val = nullptr; uint8_t *d_flag = nullptr;
+    void *d_out = nullptr;
+    const size_t out_bytes = (size_t)take * (8 + (d_values ? 8 : 0) + 1) + 64;
+    HIPCHK(hipMalloc(&d_out, out_bytes));
+    d_pos = (uint64_t *)d_out;
+    d_val = d_values ? d_pos + take : nullptr;
+    d_flag = (uint8_t *)(d_pos + take + (d_values ? take : 0));
+    int status = NTK_OK;
+    do {
+        if (hipMemsetAsync(d_counts, 0, (size_t)n_records * 8, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
+        hipLaunchKernelGGL(cp_scatter_kernel, dim3((unsigned)nblocks), dim3(kCpThreads), 0, c->stream, d_v16, d_r16, d_values, n_words,
+                           (const uint64_t *)d_off, (const uint64_t *)c->scratch[5].p, n_records, index_shift, take, d_pos, d_val, d_flag,
+                           (unsigned long long *)d_counts);
+        if (hipGetLastError() != hipSuccess) { status = NTK_ERR_HIP; break; }
+        if (counts && hipMemcpyAsync(counts, d_counts, (size_t)n_records * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
+        if (take && pos_out && hipMemcpyAsync(pos_out, d_pos, (size_t)take * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
+        if (take && val_out && d_val && hipMemcpyAsync(val_out, d_val, (size_t)take * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
+        if (take && flag_out && hipMemcpyAsync(flag_out, d_flag, (size_t)take, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) status = NTK_ERR_HIP;
+    } while (0);
+    if (status == NTK_ERR_HIP) g_last_hip = (int)hipGetLastError();
+    (void)hipFree(d_out);
+    if (status != NTK_OK) return status;
+    return m > cap ? NTK_ERR_CAPACITY : NTK_OK;
+}
+}  // namespace
+
+int ntk_bit_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,
+                        uint64_t *counts, uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *total)
+{
+    if (!c || !offsets || !total || (!seq && offsets[n_records] > offsets[0])) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 32) return NTK_ERR_BAD_K;
+    *total = 0;
+    if (counts) memset(counts, 0, (size_t)n_records * 8);
+    if (n_records == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    ntk_params p = {k, (uint32_t)(canonical ? NTK_PATH_BITS_CANONICAL : NTK_PATH_BITS), NTK_PRE_NONE, 0};
+    Mode m;
+    int rc = resolve_mode(&p, true, &m);
+    if (rc) return rc;
+    uint64_t n = 0;
+    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return rc;
+    const uint64_t nt = (n + 15) / 16 * 16;
+    if ((rc = ensure_scratch(c, 1, nt * 8))) return rc;
+    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return rc;
+    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return rc;
+    uint64_t *d_val = (uint64_t *)c->scratch[1].p;
+    uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
+    if ((rc = run_scan(c, (const uint8_t *)c->scratch[0].p, n, &p, m, false, d_val, d_v16, d_r16))) return rc;
+    return compact_items(c, d_v16, d_r16, d_val, n, n_records, k - 1, counts, pos_out, val_out, was_rc_out, cap, total);
+}
+
+int ntk_canonical_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
+                              uint64_t *counts, uint64_t *pos_out, uint8_t *is_rc_out, uint64_t cap, uint64_t *total)
+{
+    if (!c || !offsets || !total || (!seq && offsets[n_records] > offsets[0])) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 255) return NTK_ERR_BAD_K;
+    *total = 0;
+    if (counts) memset(counts, 0, (size_t)n_records * 8);
+    if (n_records == 0) return NTK_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    uint64_t n = 0;
+    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return rc;
+    const uint64_t nt = (n + 15) / 16 * 16;
+    if ((rc = ensure_scratch(c, 1, nt))) return rc;
+    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return rc;
+    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return rc;
+    uint8_t *d_flags = (uint8_t *)c->scratch[1].p;
+    uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
+    // raw-byte comparison exactly as the reference (src/kmer.rs:84-129): any k <= 255, mixed case compares as bytes
+    hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
+                       (const uint8_t *)c->scratch[0].p, n, k, (const uint16_t *)(c->d_lut + 768), d_flags);
+    hipLaunchKernelGGL(pack_flags8_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, c->stream, (const uint8_t *)d_flags, n, d_v16, d_r16);
+    HIPCHK(hipGetLastError());
+    return compact_items(c, d_v16, d_r16, nullptr, n, n_records, 0, counts, pos_out, nullptr, is_rc_out, cap, total);
 }
 
 /* ---- minimizers, quality mask --------------------------------------------------------------------------------- */

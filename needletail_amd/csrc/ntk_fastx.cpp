@@ -53,6 +53,9 @@ struct StreamDecoder {
     // consumes from [in, in+in_n), produces into [out, out+cap); returns false on a stream error.  *end is set when the
     // compressed stream is complete.
     virtual bool step(const uint8_t *in, size_t in_n, size_t *used, uint8_t *out, size_t cap, size_t *made, bool *end) = 0;
+    // input that runs out while this is true is a TRUNCATED stream (an error, like the reference's decoders: UnexpectedEof),
+    // not an end of file.  bzip2 / xz: true until the stream end marker has been seen (read_plain stops at the marker).
+    virtual bool mid_stream() const { return true; }
     virtual const char *name() const = 0;
 };
 
@@ -144,8 +147,13 @@ struct ZstdDecoder : StreamDecoder {
         const size_t rc = dec(ds, &ob, &ib);
         *used = ib.pos; *made = ob.pos;
         *end = false;   // frames may follow one another (the zstd crate's Decoder reads them all): the input's end ends it
+        // 0: a frame has been decoded and flushed completely (a call that neither consumed nor produced anything - the
+        // probe at the input's end - says nothing about the frame before it)
+        if (!is_err(rc) && (ib.pos > 0 || ob.pos > 0)) in_frame = rc != 0;
         return !is_err(rc);
     }
+    bool mid_stream() const override { return in_frame; }
+    bool in_frame = false;
     const char *name() const override { return "zstd"; }
 };
 
@@ -191,7 +199,13 @@ size_t FastxReader::read_plain(uint8_t *dst, size_t cap)
             }
             zin_pos_ += used; produced += made;
             if (end) { z_eof_ = true; break; }
-            if (no_more_input && made == 0) { z_eof_ = true; break; }   // truncated input: ends like an empty read
+            if (no_more_input && made == 0) {
+                if (dec_->mid_stream()) {   // the reference's decoders return UnexpectedEof here (a partial download must not parse)
+                    fail(kErrIo, std::string(dec_->name()) + " stream error: unexpected end of compressed stream", line_);
+                    return (size_t)-1;
+                }
+                z_eof_ = true; break;
+            }
         }
         return produced;
     }
@@ -204,7 +218,12 @@ size_t FastxReader::read_plain(uint8_t *dst, size_t cap)
         if (zin_pos_ == zin_len_) {
             zin_len_ = read_raw(zin_.data(), zin_.size());
             zin_pos_ = 0;
-            if (zin_len_ == 0) { z_eof_ = true; break; }
+            if (zin_len_ == 0) {
+                // the input ends inside a member (no trailer seen): flate2's MultiGzDecoder reports UnexpectedEof
+                // (reference src/parser/mod.rs:95-97); a truncated download must not parse as a shorter file
+                fail(kErrIo, "gzip stream error: unexpected end of compressed stream", line_);
+                return (size_t)-1;
+            }
         }
         zs_->next_in = zin_.data() + zin_pos_;
         zs_->avail_in = (uInt)(zin_len_ - zin_pos_);

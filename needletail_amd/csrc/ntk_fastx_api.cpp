@@ -172,7 +172,16 @@ uint64_t next_record_start(const uint8_t *d, uint64_t n, uint64_t from, int form
         if (!nl) return n;
         p = (uint64_t)(nl - d) + 1;
         if (p >= n) return n;
-        if (format == ntk::kFasta) { if (d[p] == '>') return p; continue; }
+        if (format == ntk::kFasta) {
+            if (d[p] != '>') continue;
+            // Not after a header line: a record without a sequence line (">empty\n>next") must stay in one piece with its
+            // successor - a range that ENDS in a bare header is a truncated record to the reader (UnexpectedEnd), although
+            // the whole file parses (reference src/parser/fasta.rs:291-367: the next '>' line ends the empty record).
+            const uint8_t *prev_nl = p >= 2 ? (const uint8_t *)memrchr(d, '\n', p - 1) : nullptr;
+            const uint64_t prev_line = prev_nl ? (uint64_t)(prev_nl - d) + 1 : 0;
+            if (d[prev_line] == '>') continue;
+            return p;
+        }
         if (d[p] != '@') continue;
         const uint8_t *l1 = (const uint8_t *)memchr(d + p, '\n', n - p);
         if (!l1) return n;

@@ -737,6 +737,31 @@ __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part
 // compat-face kernels (per-sequence API parity; not the throughput path)
 // ---------------------------------------------------------------------------------------------
 
+// Exclusive prefix sum of one value per thread across a block (wave scan by shuffles, wave totals through LDS).
+// s_wave: THREADS/64 entries of LDS; *total (optional, every thread gets it) = the block's sum.
+template <int THREADS, class T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *s_wave, T *total = nullptr)
+{
+    T x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T y = __shfl_up(x, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) x += y;
+    }
+    __syncthreads();   // s_wave may still be read by the previous call's stragglers
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = x;
+    __syncthreads();
+    T wave_off = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) {
+        const T t = s_wave[w];
+        if (w < (int)(threadIdx.x >> 6)) wave_off += t;
+        all += t;
+    }
+    if (total) *total = all;
+    return wave_off + x - v;
+}
+
 // byte LUT map (normalize / complement): out[i] = lut[in[i]] & 0xFF
 __global__ void map_reverse_kernel(const uint8_t *in, uint8_t *out, uint64_t n, const uint16_t *lut)
 {
@@ -788,27 +813,21 @@ __global__ __launch_bounds__(kCompactThreads) void compact_count_kernel(const ui
 __global__ __launch_bounds__(1024) void compact_scan_kernel(const uint32_t *block_kept, uint64_t *block_off, uint32_t nblocks,
                                                             uint64_t *total)
 {
-    __shared__ uint64_t s_tot[1024];
+    __shared__ uint64_t s_wave[1024 / 64];
     const uint32_t per = (nblocks + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per;
     uint64_t t = 0;
     for (uint32_t i = 0; i < per; i++) if (b0 + i < nblocks) t += block_kept[b0 + i];
-    s_tot[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) { uint64_t v = s_tot[i]; s_tot[i] = run; run += v; }
-        *total = run;
-    }
-    __syncthreads();
-    uint64_t run = s_tot[threadIdx.x];
+    uint64_t all = 0;
+    uint64_t run = block_exclusive_scan<1024, uint64_t>(t, s_wave, &all);
+    if (threadIdx.x == 0) *total = all;
     for (uint32_t i = 0; i < per; i++) if (b0 + i < nblocks) { block_off[b0 + i] = run; run += block_kept[b0 + i]; }
 }
 
 __global__ __launch_bounds__(kCompactThreads) void compact_write_kernel(const uint8_t *in, uint64_t n, const uint16_t *lut,
                                                                         const uint64_t *block_off, uint8_t *out)
 {
-    __shared__ uint32_t s_off[kCompactThreads];
+    __shared__ uint32_t s_wave[kCompactThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kCompactBlockBytes + (uint64_t)threadIdx.x * kCompactPerThread;
     uint16_t m[kCompactPerThread];
     uint32_t kept = 0;
@@ -817,14 +836,7 @@ __global__ __launch_bounds__(kCompactThreads) void compact_write_kernel(const ui
         m[i] = base + i < n ? lut[in[base + i]] : (uint16_t)0x200;
         kept += (m[i] & 0x200) ? 0u : 1u;
     }
-    s_off[threadIdx.x] = kept;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < kCompactThreads; i++) { uint32_t v = s_off[i]; s_off[i] = run; run += v; }
-    }
-    __syncthreads();
-    uint64_t w = block_off[blockIdx.x] + s_off[threadIdx.x];
+    uint64_t w = block_off[blockIdx.x] + block_exclusive_scan<kCompactThreads, uint32_t>(kept, s_wave);
 #pragma unroll
     for (int i = 0; i < kCompactPerThread; i++)
         if (!(m[i] & 0x200)) out[w++] = (uint8_t)m[i];
@@ -853,6 +865,107 @@ __global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t 
     }
     flags8[p] = f;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched compat face: the items of a whole batch of records, compacted on the device
+// (Sequence::canonical_kmers / bit_kmers for every record of a FastxReader batch in one call, reference
+// src/sequence.rs:237-252).  Records are packed back to back with one break byte each; window flags come as bit planes
+// (bit 15 - i%16 of word i/16): indexed by the window's END for the packed-value scan, by its START for the raw-byte kernel.
+// ---------------------------------------------------------------------------------------------
+// flags8 (canonical_bytes_kernel: bit 0 emitted, bit 1 is_rc, by window start) -> the two bit planes; one thread per word
+__global__ void pack_flags8_kernel(const uint8_t *flags8, uint64_t n, uint16_t *valid16, uint16_t *rc16)
+{
+    const uint64_t n_words = (n + 15) >> 4;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0, r = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint64_t p = w * 16 + i;
+            const uint32_t f = p < n ? flags8[p] : 0u;
+            v |= (f & 1u) << (15 - i);
+            r |= ((f >> 1) & 1u) << (15 - i);
+        }
+        valid16[w] = (uint16_t)v; rc16[w] = (uint16_t)(r & v);
+    }
+}
+
+constexpr int kCpThreads = 256, kCpWords = 4, kCpBlockWords = kCpThreads * kCpWords;   // a block covers 16 384 positions
+__global__ __launch_bounds__(kCpThreads) void cp_count_kernel(const uint16_t *valid16, uint64_t n_words, uint32_t *block_items)
+{
+    __shared__ uint32_t s_wave[kCpThreads / 64];
+    const uint64_t w0 = (uint64_t)blockIdx.x * kCpBlockWords + (uint64_t)threadIdx.x * kCpWords;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < kCpWords; i++) c += w0 + i < n_words ? __popc((uint32_t)valid16[w0 + i]) : 0u;
+    uint32_t all = 0;
+    (void)block_exclusive_scan<kCpThreads, uint32_t>(c, s_wave, &all);
+    if (threadIdx.x == 0) block_items[blockIdx.x] = all;
+}
+
+// exclusive scan of the per-block item counts (any number of blocks: tiles of 1024 with a running carry), single block
+__global__ __launch_bounds__(1024) void cp_scan_kernel(const uint32_t *block_items, uint64_t *block_off, uint64_t nblocks, uint64_t *total)
+{
+    __shared__ uint64_t s_wave[1024 / 64];
+    uint64_t carry = 0;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        const uint64_t b = b0 + threadIdx.x;
+        const uint64_t v = b < nblocks ? block_items[b] : 0;
+        uint64_t all = 0;
+        const uint64_t ex = block_exclusive_scan<1024, uint64_t>(v, s_wave, &all);
+        if (b < nblocks) block_off[b] = carry + ex;
+        carry += all;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// rec_start[r] = packed offset of record r's first byte (n_records + 1 entries; record r ends one byte before rec_start[r+1]).
+// index_shift: window start = flag index - index_shift (k - 1 for end-indexed planes, 0 for start-indexed ones).
+__global__ __launch_bounds__(kCpThreads) void cp_scatter_kernel(const uint16_t *valid16, const uint16_t *rc16, const uint64_t *values,
+                                                                uint64_t n_words, const uint64_t *block_off, const uint64_t *rec_start,
+                                                                uint64_t n_records, uint32_t index_shift, uint64_t cap,
+                                                                uint64_t *pos_out, uint64_t *val_out, uint8_t *flag_out,
+                                                                unsigned long long *counts)
+{
+    __shared__ uint32_t s_wave[kCpThreads / 64];
+    const uint64_t w0 = (uint64_t)blockIdx.x * kCpBlockWords + (uint64_t)threadIdx.x * kCpWords;
+    uint32_t vw[kCpWords], rw[kCpWords], c = 0;
+#pragma unroll
+    for (int i = 0; i < kCpWords; i++) {
+        vw[i] = w0 + i < n_words ? valid16[w0 + i] : 0u;
+        rw[i] = w0 + i < n_words ? rc16[w0 + i] : 0u;
+        c += __popc(vw[i]);
+    }
+    uint64_t idx = block_off[blockIdx.x] + block_exclusive_scan<kCpThreads, uint32_t>(c, s_wave);
+    if (c == 0) return;
+    // record of the thread's first item: the last r with rec_start[r] <= position (binary search), then it only advances
+    uint64_t rec = 0, run = 0;
+    bool have = false;
+#pragma unroll
+    for (int i = 0; i < kCpWords; i++) {
+        uint32_t bits = vw[i];
+        while (bits) {
+            const int lead = __clz(bits) - 16;          // bit 15 - lead is the lowest remaining position
+            bits &= ~(0x8000u >> lead);
+            const uint64_t e = (w0 + i) * 16 + (uint64_t)lead;
+            if (!have) {
+                uint64_t lo = 0, hi = n_records;        // invariant: rec_start[lo] <= e < rec_start[hi]
+                while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (rec_start[mid] <= e) lo = mid; else hi = mid; }
+                rec = lo; have = true;
+            } else if (e >= rec_start[rec + 1]) {
+                atomicAdd(&counts[rec], (unsigned long long)run); run = 0;
+                do rec++; while (e >= rec_start[rec + 1]);
+            }
+            run++;
+            if (idx < cap) {
+                if (pos_out) pos_out[idx] = e - index_shift - rec_start[rec];
+                if (val_out) val_out[idx] = values[e];
+                if (flag_out) flag_out[idx] = (uint8_t)((rw[i] >> (15 - lead)) & 1u);
+            }
+            idx++;
+        }
+    }
+    if (run) atomicAdd(&counts[rec], (unsigned long long)run);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ library's C++ reader, everything sequence-related goes to the GPU through the sa
 from __future__ import annotations
 
 import ctypes as C
+import re
 from typing import Iterator, Optional
 
 from . import _lib as L
@@ -23,6 +24,9 @@ class NeedletailError(Exception):
         self.record_id = record_id
         where = (f"record '{record_id}' at " if record_id else "") + f"line {line}"
         super().__init__(f"{msg} ({self.kind} at {where})")
+
+
+_WS = re.compile(r"\s")   # Python's \s on str == Rust's char::is_whitespace for the characters a header can hold
 
 
 class Record:
@@ -54,14 +58,17 @@ class Record:
     def __str__(self):
         return f">{self.id}\n{self.seq}\n" if self.qual is None else f"@{self.id}\n{self.seq}\n+\n{self.qual}\n"
 
+    # reference src/python.rs:148-163: the id is split at its first whitespace character (char::is_whitespace, so tabs
+    # too); the description is what follows with its leading whitespace trimmed, None when there is no whitespace
     @property
     def name(self) -> str:
-        return self.id.split(" ", 1)[0] if self.id else self.id
+        m = _WS.search(self.id)
+        return self.id[: m.start()] if m else self.id
 
     @property
     def description(self) -> Optional[str]:
-        parts = self.id.split(" ", 1)
-        return parts[1] if len(parts) > 1 else None
+        m = _WS.search(self.id)
+        return self.id[m.start():].lstrip() if m else None
 
     def is_fasta(self) -> bool:
         return self.qual is None

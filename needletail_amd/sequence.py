@@ -108,6 +108,48 @@ def bit_kmers(seq: bytes, k: int, canonical: bool, ctx: Context = None) -> List[
     return [(p, (v, k), bool(f)) for p, v, f in zip(pos.tolist(), val.tolist(), flg.tolist())]
 
 
+def _pack_records(records):
+    offs = np.zeros(len(records) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in records], out=offs[1:])
+    return b"".join(records), offs
+
+
+def bit_kmers_batch(records, k: int, canonical: bool, ctx: Context = None):
+    """Sequence::bit_kmers(k, canonical) for a whole batch of records in one device pass (ntk_bit_kmers_batch):
+    returns (counts, pos, val, was_rc); record i's items are the slice [counts[:i].sum(), counts[:i+1].sum())."""
+    c = _ctx(ctx)
+    if k < 1 or k > 32:
+        raise ValueError("k must be 1..32")
+    seq, offs = _pack_records(records)
+    cap = max(int(sum(max(0, len(r) - k + 1) for r in records)), 1)
+    counts = np.zeros(max(len(records), 1), dtype=np.uint64)
+    pos = np.empty(cap, dtype=np.uint64)
+    val = np.empty(cap, dtype=np.uint64)
+    flg = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    L.check(L.lib().ntk_bit_kmers_batch(c._h, seq, offs.ctypes.data, len(records), k, int(canonical), counts.ctypes.data,
+                                        pos.ctypes.data, val.ctypes.data, flg.ctypes.data, cap, C.byref(n)), "ntk_bit_kmers_batch")
+    return counts[: len(records)], pos[: n.value], val[: n.value], flg[: n.value]
+
+
+def canonical_kmers_batch(records, k: int, ctx: Context = None):
+    """Sequence::canonical_kmers(k, &reverse_complement(record)) for a whole batch of records in one device pass
+    (ntk_canonical_kmers_batch): returns (counts, pos, is_rc); the k-mer slices are drawn on the host as
+    reference src/kmer.rs:121-128 does."""
+    c = _ctx(ctx)
+    if k < 1 or k > 255:
+        raise ValueError("k must be 1..255")
+    seq, offs = _pack_records(records)
+    cap = max(int(sum(max(0, len(r) - k + 1) for r in records)), 1)
+    counts = np.zeros(max(len(records), 1), dtype=np.uint64)
+    pos = np.empty(cap, dtype=np.uint64)
+    flg = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    L.check(L.lib().ntk_canonical_kmers_batch(c._h, seq, offs.ctypes.data, len(records), k, counts.ctypes.data,
+                                              pos.ctypes.data, flg.ctypes.data, cap, C.byref(n)), "ntk_canonical_kmers_batch")
+    return counts[: len(records)], pos[: n.value], flg[: n.value]
+
+
 def minimizer(seq: bytes, length: int, ctx: Context = None) -> bytes:
     """sequence::minimizer (reference src/sequence.rs:139-152)."""
     c = _ctx(ctx)

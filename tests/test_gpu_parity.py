@@ -440,9 +440,36 @@ def test_materialize_dense(ctx, k, path):
         start += len(r) + 1
 
 
+def oracle_whole_batch(t, n_records, L, k, path, pre, seed, chunk_records=None):
+    """The oracle's reduced result of a whole device-resident synthetic batch.  The bytes come back from the device in
+    chunks (test_synth_reads_device_matches_oracle pins the generator against the oracle's; the first chunk is re-checked
+    here) and go through the literal per-record chain on every host thread."""
+    stride = L + 1
+    chunk_records = chunk_records or max(1, (1 << 30) // stride)
+    threads = os.cpu_count() or 1
+    total = None
+    for first in range(0, n_records, chunk_records):
+        n = min(chunk_records, n_records - first)
+        host = t[first * stride:(first + n) * stride].cpu().numpy()
+        if first == 0:
+            m = min(n, 2000)
+            assert np.array_equal(host[: m * stride], O.synth_reads(seed, 0, m, L, 1))
+        offs = np.arange(n + 1, dtype=np.uint64) * stride
+        part = O.reduce_batch(host, offs, 1, k, path, pre, threads)
+        if total is None:
+            total = part
+        else:
+            for key in ("n_total", "n_fwd", "n_rc"):
+                total[key] += part[key]
+            total["sum"] = (total["sum"] + part["sum"]) & (2 ** 64 - 1)
+            total["xor"] ^= part["xor"]
+            total["hist"] = total["hist"] + part["hist"]
+    return total
+
+
 def test_full_size_properties_config3(ctx):
-    """BASELINE.json configs[2]: 1M x 10 kb contigs, k=31 bit path (strip_returns -> bit_kmers(31, true)); sample prefix vs
-    the oracle, linearity, reverse-complement invariance."""
+    """BASELINE.json configs[2]: 1M x 10 kb contigs, k=31 bit path (strip_returns -> bit_kmers(31, true)): the whole batch
+    bit-exactly against the oracle; plus linearity and reverse-complement invariance."""
     n_contigs, L, k = 1_000_000, 10_000, 31
     stride = L + 1
     nbytes = n_contigs * stride
@@ -452,9 +479,8 @@ def test_full_size_properties_config3(ctx):
     ctx.accum_reset(); ctx.reduce_device(t, nbytes, k, path, pre); whole = ctx.accum_read()
     assert whole["n_total"] == whole["n_fwd"] + whole["n_rc"] == int(whole["hist"].sum())
     assert 0 < whole["n_total"] <= n_contigs * (L - k + 1)
-    sample = 300
-    ctx.accum_reset(); ctx.reduce_device(t, sample * stride, k, path, pre)
-    assert_stats_equal(ctx.accum_read(), O.reduce_fused(O.synth_reads(0x5EED0003, 0, sample, L, 1), k, True, False, False), "sample")
+    # the ENTIRE batch against the oracle's literal per-record chain (all host threads), bit-exact: 5 scalars + 4096 bins
+    assert_stats_equal(whole, oracle_whole_batch(t, n_contigs, L, k, O.PATH_BITS_CANONICAL, O.PRE_STRIP_RETURNS, 0x5EED0003), "whole batch")
     a, b = 16 * 7_001, 16 * 40_003
     ctx.accum_reset()
     for lo, hi in ((0, a), (a, b), (b, n_contigs)):
@@ -510,8 +536,8 @@ def test_device_synth_matches_cpu_generator(ctx):
 
 
 def test_full_size_properties_config2(ctx):
-    """BASELINE.json configs[1]: 10M x 150 bp, k=21 canonical, checked through size-independent properties:
-    (1) a sample prefix equals the oracle exactly; (2) linearity: whole == sum of record-aligned parts;
+    """BASELINE.json configs[1]: 10M x 150 bp, k=21 canonical:
+    (1) the WHOLE batch equals the oracle exactly; (2) linearity: whole == sum of record-aligned parts;
     (3) reverse-complementing every read leaves histogram / sum / xor unchanged and swaps n_fwd <-> n_rc (k odd)."""
     n_reads, L, k = 10_000_000, 150, 21
     stride = L + 1
@@ -522,10 +548,8 @@ def test_full_size_properties_config2(ctx):
     ctx.accum_reset(); ctx.reduce_device(t, nbytes, k, path, pre); whole = ctx.accum_read()
     assert whole["n_total"] == whole["n_fwd"] + whole["n_rc"] == int(whole["hist"].sum())
     assert 0 < whole["n_total"] <= n_reads * (L - k + 1)
-    # (1) sample
-    sample = 20_000
-    ctx.accum_reset(); ctx.reduce_device(t, sample * stride, k, path, pre); part = ctx.accum_read()
-    assert_stats_equal(part, O.reduce_fused(O.synth_reads(0x5EED0002, 0, sample, L, 1), k, True, True, True), "sample")
+    # (1) the ENTIRE batch against the oracle's literal per-record chain (all host threads), bit-exact: 5 scalars + 4096 bins
+    assert_stats_equal(whole, oracle_whole_batch(t, n_reads, L, k, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE, 0x5EED0002), "whole batch")
     # (2) linearity over three unequal record-aligned parts (16-B aligned cuts: 16 | 151*16)
     a = 16 * 100_003  # reads; a*stride is a multiple of 16
     b = 16 * 400_001
@@ -798,7 +822,7 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank():
     2 x reads: identical reduced results.  (RCCL itself needs two GPUs; the driver's scaling run covers that.)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, READS="100000")
+    env = dict(os.environ, READS="2500000")
     r = subprocess.run(["bash", os.path.join(root, "tools", "n2_on_one_gpu.sh")], cwd=root, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "n2_on_one_gpu ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -904,3 +928,58 @@ def test_rccl_allreduce_through_the_c_abi_single_rank(ctx):
                 assert_stats_equal(ctx.accum_read(), want, "rccl single rank")
     with pytest.raises(nt.NtkError):
         D.Communicator.for_rank(ctx, 2, 5, b"\0" * 128)   # rank out of range: an argument error, not a hang
+
+
+def test_batched_compat_face_matches_the_iterators_per_record(ctx):
+    """ntk_bit_kmers_batch / ntk_canonical_kmers_batch: one call for a whole batch of records, element-wise against the
+    oracle's literal iterators (reference src/sequence.rs:237-252) record by record; ragged, empty and all-N records,
+    mixed case, k up to 255 on the byte path, and the capacity protocol."""
+    rng = np.random.default_rng(21)
+    alphabet = np.frombuffer(b"ACGTACGTACGTacgtNn-", dtype=np.uint8)
+    records = [b"", b"A", b"N" * 40, b"ACGT" * 10, b"acgtACGTnACGTTGCA" * 3]
+    for _ in range(400):
+        records.append(bytes(alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 400)))]))
+    records += [b"", bytes(alphabet[rng.integers(0, 4, 3000)])]
+    for k, canonical in ((1, True), (4, False), (21, True), (31, True), (32, False)):
+        counts, pos, val, flg = nt.bit_kmers_batch(records, k, canonical, ctx)
+        assert len(counts) == len(records)
+        o = 0
+        for r, n in zip(records, counts.tolist()):
+            p_, v_, f_ = O.bit_kmers_arrays(r, k, canonical)
+            assert n == len(p_), (k, len(r))
+            assert np.array_equal(pos[o:o + n], p_) and np.array_equal(val[o:o + n], v_) and np.array_equal(flg[o:o + n], f_)
+            o += n
+        assert o == len(pos)
+    for k in (1, 4, 21, 33, 70, 255):
+        counts, pos, flg = nt.canonical_kmers_batch(records, k, ctx)
+        o = 0
+        for r, n in zip(records, counts.tolist()):
+            p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), k)
+            assert n == len(p_), (k, len(r))
+            assert np.array_equal(pos[o:o + n], p_) and np.array_equal(flg[o:o + n], f_)
+            o += n
+        assert o == len(pos)
+    # capacity protocol: too small a buffer reports the needed count and fills what fits
+    import ctypes as C
+    from needletail_amd import _lib as L
+    seq = b"".join(records)
+    offs = np.zeros(len(records) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in records], out=offs[1:])
+    want_counts, want_pos, want_val, want_flg = nt.bit_kmers_batch(records, 21, True, ctx)
+    cap = 100
+    cnt = np.zeros(len(records), dtype=np.uint64); p2 = np.zeros(cap, dtype=np.uint64); v2 = np.zeros(cap, dtype=np.uint64)
+    f2 = np.zeros(cap, dtype=np.uint8); tot = C.c_uint64(0)
+    rc = L.lib().ntk_bit_kmers_batch(ctx._h, seq, offs.ctypes.data, len(records), 21, 1, cnt.ctypes.data, p2.ctypes.data,
+                                     v2.ctypes.data, f2.ctypes.data, cap, C.byref(tot))
+    assert rc == 5 and tot.value == len(want_pos) and np.array_equal(cnt, want_counts)
+    assert np.array_equal(p2, want_pos[:cap]) and np.array_equal(v2, want_val[:cap]) and np.array_equal(f2, want_flg[:cap])
+    # a larger batch: 20 000 reads of 150 bp in one call
+    big = [bytes(r) for r in O.synth_reads(0x5EED0002, 0, 20000, 150, 4).reshape(20000, 151)[:, :150]]
+    counts, pos, val, flg = nt.bit_kmers_batch(big, 21, True, ctx)
+    assert int(counts.sum()) == len(pos)
+    st = O.reduce_fused(b"".join(r + b"\n" for r in big), 21, True, False, False)
+    assert len(pos) == st["n_total"] and int(flg.sum()) == st["n_rc"] and int(val.sum(dtype=np.uint64)) == st["sum"]
+    for i in (0, 7, 19999):
+        o = int(counts[:i].sum())
+        p_, v_, f_ = O.bit_kmers_arrays(big[i], 21, True)
+        assert np.array_equal(pos[o:o + len(p_)], p_) and np.array_equal(val[o:o + len(p_)], v_)

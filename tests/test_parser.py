@@ -197,6 +197,68 @@ def test_parallel_split_points_are_record_starts():
     assert all(fa[c:c + 2] == b">c" or c == len(fa) for c in cuts)
 
 
+def test_parallel_split_points_skip_bare_headers():
+    """A FASTA record without a sequence line must not end a piece: the piece would be a truncated record to
+    its reader although the whole file parses."""
+    import ctypes as C
+    from needletail_amd import _lib as L
+    data = b">a\nACGTACGT\n>empty\n>b\nACGT\n>c\nAC\n"
+    whole = [(i, s) for i, s, *_ in recs(data)]
+    assert whole == [(b"a", b"ACGTACGT"), (b"empty", b""), (b"b", b"ACGT"), (b"c", b"AC")]
+    for pieces in (2, 3, 4, 5, 8):
+        cuts = (C.c_uint64 * (pieces + 1))()
+        assert L.lib().ntk_fastx_split_points(data, len(data), pieces, cuts) == 0
+        cl = list(cuts)
+        got = []
+        for lo, hi in zip(cl[:-1], cl[1:]):
+            if hi > lo:
+                got += [(i, s) for i, s, *_ in recs(data[lo:hi])]   # every piece parses on its own
+        assert got == whole, (pieces, cl)
+    rng = np.random.default_rng(9)
+    parts = []
+    for i in range(400):
+        parts.append(b">r%d\n" % i + (b"" if rng.integers(0, 3) == 0 else b"ACGT" * int(rng.integers(1, 9)) + b"\n"))
+    big = b"".join(parts) + b">last\nAC\n"
+    whole = [(i, s) for i, s, *_ in recs(big)]
+    for pieces in (2, 7, 33):
+        cuts = (C.c_uint64 * (pieces + 1))()
+        assert L.lib().ntk_fastx_split_points(big, len(big), pieces, cuts) == 0
+        cl = list(cuts)
+        got = []
+        for lo, hi in zip(cl[:-1], cl[1:]):
+            if hi > lo:
+                got += [(i, s) for i, s, *_ in recs(big[lo:hi])]
+        assert got == whole
+
+
+def test_truncated_compressed_streams_are_errors(golden_dir):
+    """A compressed stream that ends before its end marker is an Io error, not a shorter file (flate2's
+    MultiGzDecoder and the other decoders of the reference return UnexpectedEof, src/parser/mod.rs:95-108)."""
+    data = b"".join(b">r%d\n" % i + b"ACGT" * 750 + b"\n" for i in range(20))
+    gz = gzip.compress(data)
+    assert len(recs(gz)) == 20
+    for frac in (0.25, 0.5, 0.9):
+        with pytest.raises(nt.NeedletailError) as e:
+            recs(gz[: int(len(gz) * frac)])
+        assert e.value.kind == "Io"
+    with pytest.raises(nt.NeedletailError):
+        recs(gz[:-4])          # the length word of the trailer is missing
+    two = gzip.compress(b">a\nACGT\n") + gzip.compress(b">b\nTTTT\nGG\n")
+    assert len(recs(two)) == 2
+    with pytest.raises(nt.NeedletailError):
+        recs(two[:-6])
+    for ext in ("bz2", "xz", "zst"):
+        raw = open(os.path.join(golden_dir, "test.fa." + ext), "rb").read()
+        try:
+            ok = recs(raw)
+        except nt.NtkError:
+            continue           # codec library not installed on this host
+        assert len(ok) == 2
+        with pytest.raises(nt.NeedletailError) as e:
+            recs(raw[: len(raw) * 2 // 3])
+        assert e.value.kind == "Io", ext
+
+
 def test_record_position_and_line_number():
     """reference src/parser/record.rs:259-285 (test_start_line_number, test_position)."""
     r = nt.parse_fastx_string("@test\nACGT\n+\nIIII\n@test2\nACGT\n+\nIIII")

@@ -14,6 +14,12 @@ def test_record_fields_and_properties():
     r = Record("test description", "AGCTGATCGA")
     assert (r.id, r.seq, r.qual) == ("test description", "AGCTGATCGA", None)
     assert (r.name, r.description) == ("test", "description")
+    # reference src/python.rs:148-163: split at the FIRST whitespace of any kind, description left-trimmed, None without one
+    assert (Record("id\tdesc here", "A").name, Record("id\tdesc here", "A").description) == ("id", "desc here")
+    assert (Record("x  y", "A").name, Record("x  y", "A").description) == ("x", "y")
+    assert (Record("solo", "A").name, Record("solo", "A").description) == ("solo", None)
+    assert (Record("trail ", "A").name, Record("trail ", "A").description) == ("trail", "")
+    assert (Record("", "A").name, Record("", "A").description) == ("", None)
     assert r.is_fasta() and not r.is_fastq()
     q = Record("test description", "AGCTGATCGA", ";**9;;????")
     assert q.qual == ";**9;;????" and q.is_fastq() and not q.is_fasta()
