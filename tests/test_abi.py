@@ -127,3 +127,50 @@ def test_cpp_mirror_quality_and_minimizers_on_gpu():
     assert (int(lines[2]), int(lines[3])) == (cv, int(crc))
     assert int(lines[4]) == O.bit_minimizer(0x1B, 4, 2)
     assert [int(x) for x in lines[5:18]] == [2, 27, 14, 27, 14, 33, 33, 37, 37, 37, 33, 37, 27]
+
+
+def _c_smoke():
+    exe = os.path.join(ROOT, "tests", "abi_smoke")
+    src = os.path.join(ROOT, "tests", "abi_smoke.c")
+    _ensure_built()
+    subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, src,
+                           "-L" + os.path.join(ROOT, "needletail_amd"), "-lneedletail_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "needletail_amd")])
+    return exe
+
+
+def test_header_is_plain_c_and_links():
+    """include/needletail_amd.h compiled by gcc -std=c11 -pedantic (no C++, no torch types) and linked with the library;
+    without a GPU the program must report the loud NTK_ERR_NO_DEVICE and nothing else."""
+    import torch
+    r = subprocess.run([_c_smoke()], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_smoke ok" in r.stdout
+    if not torch.cuda.is_available():
+        assert "no device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_smoke_program_on_gpu():
+    r = subprocess.run([_c_smoke()], capture_output=True, text=True)
+    assert r.returncode == 0 and "abi_smoke ok (gpu)" in r.stdout, r.stdout + r.stderr
+
+
+def test_rust_binding_declares_the_header():
+    """rust/src/amd.rs (shipped uncompiled: no rustc in the image) declares every entry point of the header with the same
+    number of parameters."""
+    hdr = open(os.path.join(ROOT, "include", "needletail_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    want = {}
+    for name, args in re.findall(r"\b(ntk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr):
+        args = args.strip()
+        want[name] = 0 if args in ("", "void") else args.count(",") + 1
+    rs = open(os.path.join(ROOT, "rust", "src", "amd.rs")).read()
+    got = {}
+    for name, args in re.findall(r"pub fn (ntk_[a-z0-9_]+)\(([^)]*)\)", rs):
+        if name == "ntk_flags":
+            continue
+        got[name] = 0 if not args.strip() else args.count(":")
+    assert sorted(got) == sorted(want)
+    assert got == want
+    assert os.path.exists(os.path.join(ROOT, "rust", "build.rs"))
