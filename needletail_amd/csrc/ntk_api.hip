@@ -228,6 +228,20 @@ const void *pick_scan(const Mode &m, uint32_t k)
     return nullptr;
 }
 
+// Fused windowed-minimizer builds of the sv2 kernel (ntk_tile.hpp lane_tile_sv2_min): w = 11 for 17 <= k <= 22 (configs[4] is
+// w = 11, k = 21), plus a few neighbours of that point; every other (k, w) takes the two-pass path (materialise + window-min).
+const void *pick_scan_min(const Mode &m, uint32_t k, uint32_t w)
+{
+    if (!m.canon) return nullptr;
+#define NTK_PICK_MIN(KF, WF, T, U) if (k == KF && w == WF && m.tie_rc == T && m.accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits, WF>;
+#define NTK_PICK_MIN4(KF, WF) NTK_PICK_MIN(KF, WF, false, false) NTK_PICK_MIN(KF, WF, false, true) NTK_PICK_MIN(KF, WF, true, false) NTK_PICK_MIN(KF, WF, true, true)
+    NTK_PICK_MIN4(17, 11) NTK_PICK_MIN4(18, 11) NTK_PICK_MIN4(19, 11) NTK_PICK_MIN4(20, 11) NTK_PICK_MIN4(21, 11) NTK_PICK_MIN4(22, 11)
+    NTK_PICK_MIN4(21, 9) NTK_PICK_MIN4(21, 10) NTK_PICK_MIN4(21, 12)
+#undef NTK_PICK_MIN4
+#undef NTK_PICK_MIN
+    return nullptr;
+}
+
 int get_event(ntk_ctx *c, hipEvent_t *e)
 {
     if (!c->ev_free.empty()) { *e = c->ev_free.back(); c->ev_free.pop_back(); return NTK_OK; }
@@ -238,16 +252,17 @@ int get_event(ntk_ctx *c, hipEvent_t *e)
 // One scan over d_seq[0, n): launches cover at most kMaxTilesPerLaunch tiles each so that per-block u32
 // histogram cells and 32-bit buffer offsets cannot overflow.
 int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
-             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16, const uint8_t *d_qual = nullptr)
+             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16, const uint8_t *d_qual = nullptr, const void *fused_min_fn = nullptr)
 {
     if (n == 0) return NTK_OK;
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
-    const bool sv2 = is_scan2(m, p->k, reduce, cutoff != 0);
+    const bool sv2 = fused_min_fn || is_scan2(m, p->k, reduce, cutoff != 0);
     const int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : (sv2 ? 768 : 512));
     const int waves_per_block = threads / 64;
-    const void *fn = cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
+    const void *fn = fused_min_fn ? fused_min_fn
+                   : cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
                             : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));
     if (!fn) return NTK_ERR_BAD_ARG;
     const size_t lds = reduce ? 0 : (size_t)waves_per_block * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
@@ -1033,6 +1048,9 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     if (!m.canon) return NTK_ERR_BAD_ARG;
     if (n == 0) return NTK_OK;
     HIPCHK(hipSetDevice(c->device));
+    // fused build (one pass, nothing written to HBM) where one exists and no quality stream is involved
+    if (!(d_qual && quality_cutoff(p)) && !getenv("NTK_MINIMIZERS_TWO_PASS"))
+        if (const void *fn = pick_scan_min(m, p->k, w)) return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, nullptr, fn);
     // Long inputs are scanned in chunks so that the scratch planes stay bounded (8 B per position: 2 GiB for the default
     // 256 MiB chunk instead of 80 GB for a 10 GB batch).  A chunk is scanned together with the w+k-2 bytes of left context
     // before it (start rounded down to the 16-byte alignment of the scan); only windows ENDING inside the chunk are counted.

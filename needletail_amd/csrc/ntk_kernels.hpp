@@ -27,6 +27,13 @@ struct DevXL {
     {
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kDppWaveShr1, 0xf, 0xf, true);
     }
+    // (the previous lane's x) + c in one DPP add
+    __device__ __forceinline__ uint32_t prev_add(int, uint32_t x, uint32_t c) const
+    {
+        uint32_t r;
+        asm("s_nop 1\n v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(c));
+        return r;
+    }
     // take ? a : (the previous lane's b) - the cross-lane move rides on the select (v_cndmask_b32_dpp, src0 = DPP operand).
     // s_nop 1: a VGPR written by the preceding VALU instruction may not be read through DPP for two wait states, and the
     // compiler does not look inside the asm.
@@ -384,7 +391,7 @@ struct DevMasks2 {
     uint32_t nf_s = 0;       // NTK_SV2_NFWD_SALU: forward-strand count of the wave, scalar
     uint32_t nf_v = 0;       // NTK_SV2_NFWD_VALU: forward-strand count of the lane
 
-    template <class Enc>
+    template <int KM, class Enc>   // KM: good bases a window needs (K, or K + W - 1 for windowed minimizers)
     __device__ __forceinline__ void compute(const Enc &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
     {
         uint64_t B[16];
@@ -412,8 +419,42 @@ struct DevMasks2 {
 #pragma unroll
         for (int i = 0; i < 16; i++) V[i] = B[i];
 #else
-        window_masks<K>(B, V);
+        window_masks<KM>(B, V);
 #endif
+    }
+
+    // unsigned minimum of two keys that are positive normal doubles (bit 63 clear, bit 62 set): one v_min_f64
+    __device__ __forceinline__ uint64_t min64(uint64_t a, uint64_t b) const
+    {
+        uint64_t r;
+        asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    uint32_t nf_bits = 0;    // fused minimizers: sum of the chosen keys' strand bits
+
+    // fused minimizers: side effects of four window positions (prefix = the value's top 14 bits, lo = its low word, fb = strand bit)
+    template <class S>
+    __device__ __forceinline__ void emit_min4(S &, const int (&pos)[4], const uint32_t (&prefix)[4], const uint32_t (&lo)[4],
+                                              const uint32_t (&fb)[4])
+    {
+        uint32_t off[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) off[i] = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
+#define NTK_EMIN1(i)                                             \
+        "s_mov_b64 exec, %[V" #i "]\n"                          \
+        "ds_add_u32 %[o" #i "], %[one]\n"                       \
+        "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n"    \
+        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"                \
+        "v_add_u32 %[nf], %[nf], %[f" #i "]\n"
+        asm volatile(NTK_EMIN1(0) NTK_EMIN1(1) NTK_EMIN1(2) NTK_EMIN1(3) "s_mov_b64 exec, -1\n"
+                     : [sum] "+v"(sum), [xlo] "+v"(xlo), [nf] "+v"(nf_bits)
+                     : [o0] "v"(off[0]), [l0] "v"(lo[0]), [f0] "v"(fb[0]), [V0] "s"(V[pos[0]]),
+                       [o1] "v"(off[1]), [l1] "v"(lo[1]), [f1] "v"(fb[1]), [V1] "s"(V[pos[1]]),
+                       [o2] "v"(off[2]), [l2] "v"(lo[2]), [f2] "v"(fb[2]), [V2] "s"(V[pos[2]]),
+                       [o3] "v"(off[3]), [l3] "v"(lo[3]), [f3] "v"(fb[3]), [V3] "s"(V[pos[3]]),
+                       [one] "v"(one)
+                     : "memory", "vcc");
+#undef NTK_EMIN1
     }
 
     // (min(a.hi16, b.lo16) : min(a.lo16, b.hi16)): the T words of positions j and j+8 share registers with crossed halves
@@ -542,10 +583,12 @@ struct NoSink {};
 #ifndef NTK_SV2_MINWAVES
 #define NTK_SV2_MINWAVES 1
 #endif
-template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12>
+// W > 0: windowed minimizers fused into the scan (lane_tile_sv2_min) instead of every k-mer
+template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12, int W = 0>
 __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs a)
 {
     static_assert(K >= 17 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 17 <= k <= 32");
+    static_assert(W == 0 || Sv2MinFused<K, W>::value, "fused minimizers: see ntk_tile.hpp");
     constexpr bool LIGHT = Sv2Light<K>::value;
     constexpr int kCells = 1 << HB;
     // One LDS object, histogram first: the masked regions address the histogram with the cell's byte offset alone, which
@@ -611,8 +654,9 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
 #else
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
-            mp.compute(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-            lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
+            mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
+            if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
+            else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
             voff += kTileStride; tile_byte += kTileStride;
         };
@@ -655,6 +699,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #else
     nf = s_nfwd[threadIdx.x];
 #endif
+    if constexpr (W > 0) nf = mp.nf_bits;   // strand bits of the chosen keys: forward count (TIE_RC) or rc count
     __syncthreads();
     for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
         uint32_t tot = 0;
@@ -690,6 +735,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             tv += s_red[w * 4 + 0]; tf += s_red[w * 4 + 1]; ts += s_red[w * 4 + 2]; tx ^= s_red[w * 4 + 3];
         }
         uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
+        if constexpr (W > 0 && !TIE_RC) tf = tv - tf;   // the bits counted the reverse-complement choices
         ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
     }
 }

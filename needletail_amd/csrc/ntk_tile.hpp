@@ -248,7 +248,7 @@ constexpr int kTileSlots = 64 - kHaloLanes;         // emitting 16-byte slots pe
 constexpr int kTileStride = kTileSlots * 16;        // 992 bytes
 
 enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 = 20, kSlotCode1 = 21,
-       kSlotFw = 22, kSlotRw = 38, kNumSlots = 54 };  // kSlotFw + g / kSlotRw + g, g = 0..15: window words handed to the next lane
+       kSlotFw = 22, kSlotRw = 38, kSlotSufLo = 54, kSlotSufHi = 70, kNumSlots = 86 };  // kSlotFw + g / kSlotRw + g, g = 0..15: window words handed to the next lane
 
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX, class Sink, class XL>
 NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t lane_base, bool halo_lane, bool tail_tile)
@@ -621,5 +621,103 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
         mp.emit4(sink, pos, fwd, T, hi, lo);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// "sv2" windowed minimizers, fused into the scan (BASELINE.json configs[4]; SURVEY.md A.7: sequence::minimizer, reference
+// src/sequence.rs:139-152, applied to every window of W+K-1 good bases).  The window ending at byte e holds the W k-mers
+// ending at e-W+1 .. e; its minimizer is the smallest of their canonical values, the LEFTMOST one on ties, reported with
+// that k-mer's strand flag.  Nothing is written to HBM: the canonical values live in registers as 64-bit KEYS
+//     key = (value << 6) | (index << 1) | strand bit,   bit 62 set
+// so that one unsigned 64-bit minimum does everything at once - on the device v_min_f64: with bit 62 set and bit 63 clear
+// a key is a positive NORMAL double, and positive doubles order like their bit patterns:
+//   * strand choice: min(forward key, reverse-complement key); the strand bit is arranged so that the tie goes where the
+//     reference's iterator sends it (TIE_RC: rc carries 0, reference src/kmer.rs:124-128; else forward carries 0, bitkmer.rs:138-142);
+//   * window minimum with the leftmost tie rule: the index (own position j -> 16 + j; a key imported from the previous
+//     lane has 16 subtracted, so it is older than every own key) breaks value ties towards the older k-mer.
+// Validity is the plain window rule with K + W - 1 in place of K (mask algebra unchanged).  The window minimum uses the
+// prefix / suffix (van Herk) decomposition around the lane boundary and around own position W-1, which needs 2W - 3 >= 15.
+// The digests follow the LIGHT scheme of lane_tile_sv2 (K <= 22): lo word per position, high parts from the histogram.
+// ---------------------------------------------------------------------------------------------
+template <int K, int W> struct Sv2MinFused {
+    static constexpr bool value = K >= 17 && K <= 22 && W >= 9 && K + W - 1 <= 32;
+};
+
+template <bool TIE_RC, int K, int W, class Sink, class XL, class MP>
+NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
+{
+    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 17 <= K <= 22, 9 <= W, K + W - 1 <= 32");
+    constexpr int D = K - 16, HS = 58 - 2 * K;            // key hi word = T >> HS (| bit 30)
+    constexpr uint32_t kBit62 = 1u << (HS - 2);            // alignbit(kBit62, T, HS) == (T >> HS) | 0x40000000
+    constexpr uint32_t fbitF = TIE_RC ? 1u : 0u, fbitR = TIE_RC ? 0u : 1u;
+    uint32_t fw[16 + D], rw[16 + D];   // index g + D
+    const uint32_t c1 = xl.prev(kSlotCode, code), r1 = xl.prev(kSlotRcode, rcode);
+    fw[D + 15] = code; rw[D + 15] = rcode;
+    fw[D - 1] = c1;    rw[D - 1] = r1;
+#pragma unroll
+    for (int j = 0; j < 15; j++) {
+        fw[D + j] = alignbit(c1, code, 30 - 2 * j);
+        rw[D + j] = alignbit(rcode, r1, 2 * j + 2);
+    }
+#pragma unroll
+    for (int g = 2; g <= D; g++) {
+        fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+        rw[D - g] = xl.prev(kSlotRw + 16 - g, rw[D + 16 - g]);
+    }
+    // canonical keys of the 16 own positions
+    uint64_t key[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t idx2 = (uint32_t)(16 + j) << 1;
+        const uint64_t kf = ((uint64_t)alignbit(kBit62, fw[j], HS) << 32) | ((fw[D + j] << 6) | (idx2 | fbitF));
+        const uint64_t kr = ((uint64_t)alignbit(kBit62, rw[D + j], HS) << 32) | ((rw[j] << 6) | (idx2 | fbitR));
+        key[j] = mp.min64(kf, kr);
+    }
+    // suffix minima of the own keys, handed to the next lane; the previous lane's arrive with 16 taken off their index
+    constexpr int A0 = 17 - W;                             // the previous lane's positions A0 .. 15 can be in a window of ours
+    uint64_t suf[16], imp[16];
+    suf[15] = key[15];
+#pragma unroll
+    for (int a = 14; a >= A0; a--) suf[a] = mp.min64(key[a], suf[a + 1]);
+#pragma unroll
+    for (int a = A0; a < 16; a++) {
+        const uint32_t lo = xl.prev_add(kSlotSufLo + a, (uint32_t)suf[a], 0u - 32u);       // low word: index -= 16
+        const uint32_t hi = xl.prev(kSlotSufHi + a, (uint32_t)(suf[a] >> 32));
+        imp[a] = ((uint64_t)hi << 32) | lo;
+    }
+    uint64_t win[16];
+    // windows reaching into the previous lane: j = 0 .. W-2
+    uint64_t pre = key[0];
+#pragma unroll
+    for (int j = 0; j <= W - 2; j++) {
+        if (j) pre = mp.min64(pre, key[j]);
+        win[j] = mp.min64(imp[A0 + j], pre);
+    }
+    // own-lane windows j = W-1 .. 15: [j-W+1, W-2] (suffix ending at W-2) and [W-1, j] (prefix from W-1); 2W-3 >= 15
+    uint64_t sfx[16];
+    sfx[W - 2] = key[W - 2];
+#pragma unroll
+    for (int a = W - 3; a >= 0; a--) sfx[a] = mp.min64(key[a], sfx[a + 1]);
+    uint64_t pfx = key[W - 1];
+#pragma unroll
+    for (int j = W - 1; j < 16; j++) {
+        if (j > W - 1) pfx = mp.min64(pfx, key[j]);
+        win[j] = j - W + 1 <= W - 2 ? mp.min64(sfx[j - W + 1], pfx) : pfx;
+    }
+#pragma unroll
+    for (int jb = 0; jb < 16; jb += 4) {
+        const int pos[4] = {jb, jb + 1, jb + 2, jb + 3};
+        uint32_t lo[4], pfxw[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t mh = (uint32_t)(win[jb + i] >> 32), ml = (uint32_t)win[jb + i];
+            lo[i] = alignbit(mh, ml, 6);                                   // low 32 bits of the value
+            // the value's top 14 bits = key bits [2K-8, 2K+6)
+            pfxw[i] = (2 * K - 8 >= 32 ? mh >> ((2 * K - 40) & 31) : alignbit(mh, ml, (2 * K - 8) & 31)) & 0x3FFFu;
+            fb[i] = ml & 1u;
+        }
+        mp.emit_min4(sink, pos, pfxw, lo, fb);
+    }
+}
+
 
 }  // namespace ntk

@@ -54,6 +54,7 @@ struct EmuXL {
     uint32_t prev(int slot, uint32_t x) { cur[slot] = x; return last[slot]; }
     uint32_t prev_and(int slot, uint32_t x, uint32_t mask) { return prev(slot, x) & mask; }
     uint32_t select_prev(int slot, bool take, uint32_t a, uint32_t b) { const uint32_t p = prev(slot, b); return take ? a : p; }
+    uint32_t prev_add(int slot, uint32_t x, uint32_t c) { return prev(slot, x) + c; }
 };
 
 Raw16 load16(const uint8_t *buf, uint64_t n_padded, int64_t off)
@@ -175,6 +176,20 @@ struct EmuMP2 {
             n_fwd += fwd[i] ? 1 : 0;
         }
     }
+    uint64_t min64(uint64_t a, uint64_t b) const { return a < b ? a : b; }   // v_min_f64 on positive normal doubles
+    uint64_t nf_bits = 0;
+    bool min_mode = false, tie_rc = false;
+    template <class S>
+    void emit_min4(S &, const int (&pos)[4], const uint32_t (&prefix)[4], const uint32_t (&lo)[4], const uint32_t (&fb)[4])
+    {
+        min_mode = true;
+        for (int i = 0; i < 4; i++) {
+            if (!((V[pos[i]] >> lane) & 1)) continue;
+            const uint32_t off = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
+            cells[off >> 2]++;
+            sum += lo[i]; xlo ^= lo[i]; nf_bits += fb[i];
+        }
+    }
     void finish(HostStats *st)   // the block-end arithmetic of scan2_kernel
     {
         constexpr int S = 64 - 2 * K;
@@ -194,13 +209,14 @@ struct EmuMP2 {
             s += shi << 32;
             xr = (xf << (2 * K - HB)) | (uint64_t)(xlo & low_mask);
         }
+        if (min_mode) n_fwd = tie_rc ? nf_bits : nv - nf_bits;
         st->n_total += nv; st->n_fwd += n_fwd; st->sum += s; st->xr ^= xr;
     }
 };
 
 struct EmuNoSink {};
 
-template <bool TIE_RC, bool ACCEPT_U, int K, int HB>
+template <bool TIE_RC, bool ACCEPT_U, int K, int HB, int W = 0>
 void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
 {
     const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
@@ -219,12 +235,14 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
                 if (good) G[i] |= 1ull << l;
             }
         }
-        window_masks<K>(G, mp.V);
+        window_masks<(W ? K + W - 1 : K)>(G, mp.V);
+        mp.tie_rc = TIE_RC;
         EmuXL xl;
         for (int l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             mp.lane = l;
-            lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en[l].code, en[l].rcode);
+            if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en[l].code, en[l].rcode);
+            else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en[l].code, en[l].rcode);
         }
     }
     mp.finish(st);
@@ -294,6 +312,25 @@ int emu_scan_quality(const uint8_t *buf, const uint8_t *qual, uint32_t cutoff, u
     const int rc = emu_scan(buf, n, n_padded, k, canon, tie_rc, accept_u, tiles_per_wave, out, values, valid16, rc16);
     g_qual = nullptr;
     return rc;
+}
+
+// Fused windowed minimizers (lane_tile_sv2_min).  Returns -2 when (k, w) has no fused build.
+int emu_minimizers(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, uint32_t w, int tie_rc, int accept_u, int hb14,
+                   uint64_t *out)
+{
+    HostStats *st = new HostStats();
+    bool done = false;
+#define EMU_MIN(KF, WF, T, U) if (!done && k == KF && w == WF && !!tie_rc == T && !!accept_u == U) { \
+        if (hb14) run_sv2<T, U, KF, 14, WF>(buf, n, n_padded, st); else run_sv2<T, U, KF, 12, WF>(buf, n, n_padded, st); done = true; }
+#define EMU_MIN4(KF, WF) EMU_MIN(KF, WF, false, false) EMU_MIN(KF, WF, false, true) EMU_MIN(KF, WF, true, false) EMU_MIN(KF, WF, true, true)
+    EMU_MIN4(17, 11) EMU_MIN4(18, 11) EMU_MIN4(19, 11) EMU_MIN4(20, 11) EMU_MIN4(21, 11) EMU_MIN4(22, 11)
+    EMU_MIN4(21, 9) EMU_MIN4(21, 10) EMU_MIN4(21, 12) EMU_MIN4(17, 16) EMU_MIN4(19, 14)
+    if (done) {
+        out[0] = st->n_total; out[1] = st->n_fwd; out[2] = st->sum; out[3] = st->xr;
+        memcpy(out + 4, st->hist, sizeof(st->hist));
+    }
+    delete st;
+    return done ? 0 : -2;
 }
 
 void emu_encode16(const uint8_t *raw16, int accept_u, uint32_t *out3)

@@ -983,3 +983,34 @@ def test_batched_compat_face_matches_the_iterators_per_record(ctx):
         o = int(counts[:i].sum())
         p_, v_, f_ = O.bit_kmers_arrays(big[i], 21, True)
         assert np.array_equal(pos[o:o + len(p_)], p_) and np.array_equal(val[o:o + len(p_)], v_)
+
+
+def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatch):
+    """configs[4] kernel side: the fused minimizer builds (one pass, no scratch planes) against the literal minimizer of every
+    window (oracle) and against the two-pass path (materialise + window-min) on the same buffer, for every fused (k, w),
+    both tie rules; a (k, w) without a fused build still works."""
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNU\n", dtype=np.uint8)
+    h = bytes(rng.choice(list(b"ACGT"), size=41).astype(np.uint8))
+    buf = bytes(alphabet[rng.integers(0, len(alphabet), 60_000)]) + h + O.reverse_complement(h) + b"A" * 90 + b"T" * 90 + \
+        O.synth_reads(0x5EED0002, 9, 3000, 150, 8).tobytes()
+    t = to_dev(buf)
+    for k, w in ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12), (23, 11), (21, 5)):
+        for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
+            want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
+            monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
+            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
+            assert_stats_equal(ctx.accum_read(), want, ("fused", k, w, tie))
+            monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1")
+            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
+            assert_stats_equal(ctx.accum_read(), want, ("two-pass", k, w, tie))
+    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
+    # a 2 M-read batch: fused == two-pass (the two-pass path is pinned against the oracle above and in the chunk test)
+    n_reads = 2_000_000
+    big = torch.empty(n_reads * 151 + 1024, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0002, 0, n_reads, 150, 1, big)
+    ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); fused = ctx.accum_read()
+    monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1")
+    ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); two = ctx.accum_read()
+    assert_stats_equal(fused, two, "2 M reads")
+    assert fused["n_total"] > 0

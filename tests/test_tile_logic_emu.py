@@ -201,3 +201,42 @@ def test_emu_quality_scan_matches_masked_oracle(emu):
         for tpw in (0, 3, 4, 12):
             got = emu_scan_quality(emu, buf, qual, cutoff, k, canon, tie_rc, accept_u, tpw)
             assert_stats_equal(got, want, (trial, k, cutoff, tpw))
+
+
+# ---- fused windowed minimizers (ntk_tile.hpp lane_tile_sv2_min; BASELINE.json configs[4]) ---------------------------
+
+def emu_minimizers(L, buf: bytes, k, w, tie_rc, accept_u, hb14):
+    n = len(buf)
+    npad = (n + 15) // 16 * 16
+    arr = np.frombuffer(buf + b"\xAA" * (npad - n), dtype=np.uint8).copy()
+    out = np.zeros(4 + 4096, dtype=np.uint64)
+    L.emu_minimizers.restype = C.c_int
+    L.emu_minimizers.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.emu_minimizers(arr.ctypes.data, n, npad, k, w, int(tie_rc), int(accept_u), int(hb14), out.ctypes.data)
+    if rc == -2:
+        return None
+    assert rc == 0
+    return {"n_total": int(out[0]), "n_fwd": int(out[1]), "n_rc": int(out[0] - out[1]), "sum": int(out[2]),
+            "xor": int(out[3]), "hist": out[4:].copy()}
+
+
+FUSED_KW = ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12))
+
+
+def test_emu_fused_minimizers_match_the_literal_minimizer(emu):
+    """Keys, strand bit, leftmost tie rule, lane-boundary import and the histogram-derived digests of the fused minimizer
+    build against sequence::minimizer applied window by window (oracle, reference src/sequence.rs:139-152): random text
+    with breaks, reverse-complement palindromes, homopolymer runs (every window ties), both tie rules."""
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTacgtACGTACGTACGTACGTNU\n", dtype=np.uint8)
+    assert emu_minimizers(emu, b"ACGT", 23, 11, 1, 1, 0) is None     # no fused build: the two-pass path serves it
+    for trial in range(40):
+        n = int(rng.integers(0, 2600))
+        b = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        if trial % 4 == 0:
+            h = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(10, 60))).astype(np.uint8))
+            b = b + h + O.reverse_complement(h) + h + b"A" * 70 + b"T" * 70 + b[:80]
+        for k, w in FUSED_KW:
+            for tie, u in ((1, 1), (0, 0)):
+                want = O.minimizers_reduce(b, k, w, accept_u=bool(u), tie_rc=bool(tie))
+                assert_stats_equal(emu_minimizers(emu, b, k, w, tie, u, trial % 2), want, (trial, k, w, tie, u))
