@@ -532,18 +532,18 @@ NTK_HD EncSV2 encode16_sv2(Raw16 d)
     // 8-entry LUTs (v_perm_b32, selector = the byte's low 3 bits):
     //   letter: 1 -> A, 3 -> C, 4 -> T, 5 -> U (normalize pipeline only, reference src/sequence.rs:30), 7 -> G; 0xFF elsewhere.
     //           A byte is a base iff its case-folded value EQUALS the letter its low bits select (SDWA compare).
-    //   code  : 2 * the letter's 2-bit code A0 C1 G2 T3 (reference src/bitkmer.rs:8-15); 0 elsewhere (every window over a
+    //   code  : the letter's 2-bit code A0 C1 G2 T3 (reference src/bitkmer.rs:8-15); 0 elsewhere (every window over a
     //           non-letter is dropped, and 0 cannot spill into the neighbouring bases' bits in the dot product)
     constexpr uint32_t kLutLo = 0x43FF41FFu, kLutHi = ACCEPT_U ? 0x47FF5554u : 0x47FFFF54u;
-    constexpr uint32_t kCodeLo = 0x02000000u, kCodeHi = ACCEPT_U ? 0x04000606u : 0x04000006u;
+    constexpr uint32_t kCodeLo = 0x01000000u, kCodeHi = ACCEPT_U ? 0x02000303u : 0x02000003u;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t n = w[i] & 0x07070707u;
         r.ex[i] = perm(kLutHi, kLutLo, n);
-        p[i] = dot4(perm(kCodeHi, kCodeLo, n), 0x01041040u, 0u);   // 2 * (c0 c1 c2 c3 as one byte)
+        p[i] = dot4(perm(kCodeHi, kCodeLo, n), 0x01041040u, 0u);   // c0 c1 c2 c3 as one byte (weights 64, 16, 4, 1)
         r.uu[i] = w[i] & 0xDFDFDFDFu;
     }
-    r.code = ((((p[0] << 8) + p[1]) << 15) | (((p[2] << 8) + p[3]) >> 1));
+    r.code = (((((p[0] << 8) | p[1]) << 8) | p[2]) << 8) | p[3];   // three v_lshl_or_b32
     const uint32_t t = brev32(r.code);
     r.rcode = bitop3<0x35>(0x55555555u, t >> 1, t + t);        // complement, pairs swapped back after the bit reversal
     return r;

@@ -19,13 +19,13 @@ ks = os.path.join(src, "trace", "p_kernel_stats.csv")
 if os.path.exists(ks):
     shutil.copy(ks, os.path.join(dst, "rocprofv3_kernel_stats.csv"))
 pmc = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
     p = os.path.join(src, d, "p_counter_collection.csv")
     if not os.path.exists(p):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if "scan_kernel" in r["Kernel_Name"]:
+        if "scan_kernel" in r["Kernel_Name"] or "scan2_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc[k] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v)}
