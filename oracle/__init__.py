@@ -307,6 +307,26 @@ def reduce_fused(buf, k: int, canonical: bool, tie_rc: bool, accept_u: bool) -> 
     return st.as_dict()
 
 
+def reduce_fused_parallel(buf: np.ndarray, stride: int, k: int, canonical: bool, tie_rc: bool, accept_u: bool, threads: int) -> dict:
+    """reduce_fused over a batch of fixed-stride records (each followed by its break byte), the records split over `threads`
+    Python threads (ctypes releases the GIL; no k-mer spans a record, so the parts simply add up)."""
+    from concurrent.futures import ThreadPoolExecutor
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    n_rec = len(buf) // stride
+    threads = max(1, min(threads, n_rec or 1))
+    cuts = [n_rec * t // threads * stride for t in range(threads)] + [len(buf)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda i: reduce_fused(buf[cuts[i]:cuts[i + 1]], k, canonical, tie_rc, accept_u), range(threads)))
+    out = parts[0]
+    for q in parts[1:]:
+        for key in ("n_total", "n_fwd", "n_rc"):
+            out[key] += q[key]
+        out["sum"] = (out["sum"] + q["sum"]) & (2 ** 64 - 1)
+        out["xor"] ^= q["xor"]
+        out["hist"] = out["hist"] + q["hist"]
+    return out
+
+
 def minimizers_reduce(buf, k: int, w: int, accept_u: bool = True, tie_rc: bool = True) -> dict:
     buf = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf,
                                dtype=np.uint8)
