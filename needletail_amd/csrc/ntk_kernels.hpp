@@ -660,8 +660,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #endif
             voff += kTileStride; tile_byte += kTileStride;
         };
-        // the next tile's load is in flight while the current one is processed; two tiles per loop trip so that the two
-        // register sets swap roles without moves
+        // the next tile's load is in flight while the current one is processed
         u32x4 ta = load_tile(voff), qa = ta, tb = ta, qb = ta;
         if constexpr (QM) qa = load_qual(voff);
 #ifndef NTK_SV2_PINGPONG   // (two tiles per loop trip without register moves doubles the loop body: measured 5 - 25 % slower, profiles/r02b)
