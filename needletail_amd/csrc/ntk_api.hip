@@ -295,8 +295,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
         const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
         const uint64_t tiles = te - tb;
-        uint64_t chunk = tiles / ((uint64_t)blocks_max * waves_per_block * 4);  // >= ~4 pulls per wave, <= 32 tiles each
-        chunk = chunk < 1 ? 1 : (chunk > 32 ? 32 : chunk);
+        uint64_t chunk = tiles / ((uint64_t)blocks_max * waves_per_block * 4);  // >= ~4 pulls per wave, <= 24 tiles each (8..32 are within 1 %: profiles/r02c)
+        chunk = chunk < 1 ? 1 : (chunk > 24 ? 24 : chunk);
         const uint64_t want_blocks = (tiles + chunk * waves_per_block - 1) / (chunk * waves_per_block);
         const int blocks = (int)(want_blocks < (uint64_t)blocks_max ? want_blocks : (uint64_t)blocks_max);
         a.tile_begin = tb; a.tile_end = te;
