@@ -820,75 +820,18 @@ int ntk_reverse_complement(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *
 int ntk_canonical_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, uint64_t *pos_out, uint8_t *is_rc_out,
                         uint64_t cap, uint64_t *count)
 {
+    // one record through the batched entry point: the items are compacted on the device, only they come back
     if (!c || (!seq && n) || !count) return NTK_ERR_BAD_ARG;
-    if (k < 1 || k > 255) return NTK_ERR_BAD_K;
-    *count = 0;
-    if (n < k) return NTK_OK;
-    HIPCHK(hipSetDevice(c->device));
-    int rc;
-    if ((rc = ensure_scratch(c, 0, n))) return rc;
-    if ((rc = ensure_scratch(c, 1, n))) return rc;
-    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d_flags = (uint8_t *)c->scratch[1].p;
-    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
-                       (const uint8_t *)d_in, n, k, (const uint16_t *)(c->d_lut + 768), d_flags);
-    HIPCHK(hipGetLastError());
-    std::vector<uint8_t> flags(n);
-    HIPCHK(hipMemcpyAsync(flags.data(), d_flags, n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    uint64_t m = 0;
-    for (uint64_t p = 0; p + k <= n; p++) {
-        if (flags[p] & 1) {
-            if (m < cap) { if (pos_out) pos_out[m] = p; if (is_rc_out) is_rc_out[m] = (flags[p] >> 1) & 1; }
-            m++;
-        }
-    }
-    *count = m;
-    return m > cap ? NTK_ERR_CAPACITY : NTK_OK;
+    const uint64_t offsets[2] = {0, n};
+    return ntk_canonical_kmers_batch(c, seq, offsets, 1, k, nullptr, pos_out, is_rc_out, cap, count);
 }
 
 int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int canonical, uint64_t *pos_out,
                   uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *count)
 {
     if (!c || (!seq && n) || !count) return NTK_ERR_BAD_ARG;
-    if (k < 1 || k > 32) return NTK_ERR_BAD_K;
-    *count = 0;
-    if (n < k) return NTK_OK;
-    HIPCHK(hipSetDevice(c->device));
-    ntk_params p = {k, (uint32_t)(canonical ? NTK_PATH_BITS_CANONICAL : NTK_PATH_BITS), NTK_PRE_NONE, 0};
-    Mode m;
-    int rc = resolve_mode(&p, true, &m);
-    if (rc) return rc;
-    const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 0, nt))) return rc;
-    if ((rc = ensure_scratch(c, 1, nt * 8))) return rc;
-    if ((rc = ensure_scratch(c, 2, nt / 8))) return rc;
-    if ((rc = ensure_scratch(c, 3, nt / 8))) return rc;
-    uint8_t *d_in = (uint8_t *)c->scratch[0].p;
-    uint64_t *d_val = (uint64_t *)c->scratch[1].p;
-    uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
-    HIPCHK(hipMemcpyAsync(d_in, seq, n, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_scan(c, d_in, n, &p, m, false, d_val, d_v16, d_r16))) return rc;
-    std::vector<uint64_t> vals(nt);
-    std::vector<uint16_t> v16(nt / 16), r16(nt / 16);
-    HIPCHK(hipMemcpyAsync(vals.data(), d_val, nt * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(v16.data(), d_v16, nt / 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(r16.data(), d_r16, nt / 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    uint64_t mcount = 0;
-    for (uint64_t e = k - 1; e < n; e++) {
-        const uint32_t bit = 15 - (uint32_t)(e & 15);
-        if ((v16[e >> 4] >> bit) & 1) {
-            if (mcount < cap) {
-                if (pos_out) pos_out[mcount] = e - (k - 1);
-                if (val_out) val_out[mcount] = vals[e];
-                if (was_rc_out) was_rc_out[mcount] = (r16[e >> 4] >> bit) & 1;
-            }
-            mcount++;
-        }
-    }
-    *count = mcount;
-    return mcount > cap ? NTK_ERR_CAPACITY : NTK_OK;
+    const uint64_t offsets[2] = {0, n};
+    return ntk_bit_kmers_batch(c, seq, offsets, 1, k, canonical, nullptr, pos_out, val_out, was_rc_out, cap, count);
 }
 
 /* ---- batched compat face ------------------------------------------------------------------------------------------- */
