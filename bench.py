@@ -303,6 +303,12 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    # stdout carries the ONE JSON line and nothing else: librccl prints a version banner and gloo its connection notes
+    # through C stdio on fd 1, so fd 1 is pointed at stderr for the life of the process and the line goes to the saved fd
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -513,7 +519,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None   # timed at N = 1 only
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
     if comm is not None:
         comm.close()
