@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Instruction census of the scan2 tile loop (k = 21 headline build) straight from the compiler's ISA listing:
+hipcc -S of tools/kbench.hip, the kernel's innermost loop (the basic blocks between the tile loop's header and its back
+edge), instructions counted by mnemonic and by class.  Usage: python tools/isa_census.py [K] > profiles/<round>/isa_census.txt"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 21
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with tempfile.TemporaryDirectory() as d:
+    out = os.path.join(d, "k.s")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DNTK_KB_FIX", "-DNTK_KB_SV", "-DNTK_KB_SV2",
+                           "-DNTK_KB_HB=14", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "tools", "kbench.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+name = f"_ZN3ntk12scan2_kernelILi{K}ELb1ELb1ELb0ELi14ELi0EEEvNS_8ScanArgsE"
+body = text[text.index(name + ":"):]
+body = body[:body.index(".end_amdhsa_kernel")]
+lines = body.splitlines()
+# the tile loop: the Depth=2 loop (blocks whose label comment says "Depth=2"), i.e. from the first such label to the last
+# branch back into it
+idx = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:.*Depth=2", l)]
+first, last = idx[0], idx[-1]
+end = last
+for i in range(last, len(lines)):
+    if re.match(r"^\.LBB\d+_\d+:", lines[i]) and i > last and "Depth=2" not in lines[i]:
+        end = i
+        break
+# basic blocks of the loop region; the tail-tile block (bytes beyond n_bytes: 16 v_cmp_gt_i64 against the lane's byte
+# index) runs once per launch and is left out of the steady-state census
+blocks, cur = [], []
+for l in lines[first:end]:
+    if re.match(r"^\.LBB\d+_\d+:", l) or l.startswith("; %bb."):
+        blocks.append(cur); cur = []
+    cur.append(l)
+blocks.append(cur)
+loop = []
+for b in blocks:
+    if any("v_cmp_gt_i64" in l for l in b):
+        continue
+    loop += [l.split()[0] for l in b if l.startswith("\t") and not l.strip().startswith((";", "."))]
+    loop += [l.split()[0] for l in b if re.match(r"^(v_|s_|ds_|buffer_)", l)]   # inline-asm lines are not indented
+cnt = collections.Counter(loop)
+cls = collections.Counter()
+for m, c in cnt.items():
+    if m.startswith("v_"):
+        cls["VALU"] += c
+    elif m.startswith("ds_"):
+        cls["LDS"] += c
+    elif m.startswith("buffer_"):
+        cls["VMEM"] += c
+    elif m.startswith("s_"):
+        cls["SALU (incl. branches, waitcnt, nop)"] += c
+print(f"scan2_kernel<{K}, true, true, false, 14, 0>: tile loop, instructions per 992-base tile (steady state)")
+for k_, v in sorted(cls.items()):
+    print(f"  {k_:40s} {v}")
+for m, c in cnt.most_common():
+    print(f"    {c:4d}  {m}")
+rest = text[text.index(name + ":"):]
+m, l_ = re.search(r"; NumVgprs: (\d+)", rest), re.search(r"; LDSByteSize: (\d+)", rest)
+print("  VGPRs:", m.group(1) if m else "?", " LDS bytes:", l_.group(1) if l_ else "?")
