@@ -25,7 +25,11 @@ struct DevXL {
     __device__ __forceinline__ uint32_t prev_and(int s, uint32_t x, uint32_t mask) const { return prev(s, x) & mask; }
     __device__ __forceinline__ uint32_t prev(int, uint32_t x) const
     {
+#ifdef NTK_XL_BPERMUTE   // experiment: the cross-lane move on the LDS pipe (ds_bpermute_b32) instead of the VALU (lane 0 gets lane 63's value: a halo lane)
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + 63u) & 63u) << 2), (int)x);
+#else
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kDppWaveShr1, 0xf, 0xf, true);
+#endif
     }
     // (the previous lane's x) + c in one DPP add
     __device__ __forceinline__ uint32_t prev_add(int, uint32_t x, uint32_t c) const
