@@ -18,6 +18,10 @@
 
 using namespace ntk;
 
+// the sv2 builds (ntk_scan2.hip): nullptr when (k, flags) has none
+const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality);
+const void *ntk_pick_scan2_min(int k, int w, bool tie_rc, bool accept_u);
+
 namespace {
 
 thread_local int g_last_hip = 0;
@@ -183,20 +187,17 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // algebra indexes lane masks by k; 64-bit values for k >= 17, 32-bit for k <= 16), -10..20 % against the generic runtime-k build; with a quality stream only k = 21 and
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
-constexpr int kScan2HistBits = 14;   // LDS histogram of the sv2 builds: 64 KiB, two 768-thread blocks per CU
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
 inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && m.canon && k >= 17 && (!qm || k == 21 || k == 31); }
 
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
 {
-#define NTK_PICK_SV(KF, T, U)                                                                       \
-    if (REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \
-        return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits>;
+    // canonical reduce, 17 <= k <= 32 (and the quality-masked k = 21 / 31 builds): the sv2 kernel lives in its own translation
+    // unit (ntk_scan2.hip, built with the ILP-driven iterative scheduler)
+    if (REDUCE && m.kw == 2 && m.canon)
+        if (const void *fn = ntk_pick_scan2((int)k, m.tie_rc, m.accept_u, QM)) return fn;
 #define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
-    NTK_PICK_SV4(17) NTK_PICK_SV4(18) NTK_PICK_SV4(19) NTK_PICK_SV4(20) NTK_PICK_SV4(21) NTK_PICK_SV4(22) NTK_PICK_SV4(23) NTK_PICK_SV4(24)
-    NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
-#undef NTK_PICK_SV
 #define NTK_PICK_SV(KF, T, U)                                                                       \
     if (REDUCE && !QM && m.kw == 1 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \
         return (const void *)&scan_kernel<1, true, T, U, true, KF, true>;
@@ -204,12 +205,6 @@ const void *pick_scan(const Mode &m, uint32_t k)
     NTK_PICK_SV4(9) NTK_PICK_SV4(10) NTK_PICK_SV4(11) NTK_PICK_SV4(12) NTK_PICK_SV4(13) NTK_PICK_SV4(14) NTK_PICK_SV4(15) NTK_PICK_SV4(16)
 #undef NTK_PICK_SV4
 #undef NTK_PICK_SV
-#define NTK_PICK_SVQ(KF, T, U)                                                                      \
-    if (REDUCE && QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)        \
-        return (const void *)&scan2_kernel<KF, T, U, true, kScan2HistBits>;
-    NTK_PICK_SVQ(21, false, false) NTK_PICK_SVQ(21, false, true) NTK_PICK_SVQ(21, true, false) NTK_PICK_SVQ(21, true, true)
-    NTK_PICK_SVQ(31, false, false) NTK_PICK_SVQ(31, false, true) NTK_PICK_SVQ(31, true, false) NTK_PICK_SVQ(31, true, true)
-#undef NTK_PICK_SVQ
 #define NTK_PICK_FIX(KF, T, U)                                                                      \
     if (!REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)      \
         return (const void *)&scan_kernel<2, true, T, U, false, KF, false>;
@@ -232,14 +227,7 @@ const void *pick_scan(const Mode &m, uint32_t k)
 // w = 11, k = 21), plus a few neighbours of that point; every other (k, w) takes the two-pass path (materialise + window-min).
 const void *pick_scan_min(const Mode &m, uint32_t k, uint32_t w)
 {
-    if (!m.canon) return nullptr;
-#define NTK_PICK_MIN(KF, WF, T, U) if (k == KF && w == WF && m.tie_rc == T && m.accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits, WF>;
-#define NTK_PICK_MIN4(KF, WF) NTK_PICK_MIN(KF, WF, false, false) NTK_PICK_MIN(KF, WF, false, true) NTK_PICK_MIN(KF, WF, true, false) NTK_PICK_MIN(KF, WF, true, true)
-    NTK_PICK_MIN4(17, 11) NTK_PICK_MIN4(18, 11) NTK_PICK_MIN4(19, 11) NTK_PICK_MIN4(20, 11) NTK_PICK_MIN4(21, 11) NTK_PICK_MIN4(22, 11)
-    NTK_PICK_MIN4(21, 9) NTK_PICK_MIN4(21, 10) NTK_PICK_MIN4(21, 12)
-#undef NTK_PICK_MIN4
-#undef NTK_PICK_MIN
-    return nullptr;
+    return m.canon ? ntk_pick_scan2_min((int)k, (int)w, m.tie_rc, m.accept_u) : nullptr;
 }
 
 int get_event(ntk_ctx *c, hipEvent_t *e)

@@ -743,6 +743,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     }
 }
 
+#ifndef NTK_SCAN_TEMPLATES_ONLY   // ntk_scan2.hip instantiates scan2_kernel only; the plain kernels below belong to ntk_api.hip
 // Sums the per-block partials into the ctx accumulators (same stream, after the scan kernel).
 // Grid: kFoldBinGroups x kFoldRowGroups blocks sum disjoint (bin range, row subset) pieces and add them with one
 // u64 atomic per bin; one extra block reduces the scalar partials.  (A single pass over <= 8 MiB, a few microseconds.)
@@ -1313,5 +1314,7 @@ __global__ void synth_reads_kernel(uint64_t seed, uint64_t first_read, uint64_t 
     }
   }
 }
+
+#endif  // NTK_SCAN_TEMPLATES_ONLY
 
 }  // namespace ntk

@@ -1,0 +1,49 @@
+// ntk_scan2.hip - the instantiations of ntk::scan2_kernel (canonical reduce mode for 17 <= k <= 32, the quality-masked k = 21 / 31
+// builds and the fused windowed-minimizer builds) in their own translation unit: the tile loop is one long straight-line
+// block, and the ILP-driven iterative scheduler (-mllvm -amdgpu-sched-strategy=iterative-ilp, see the Makefile) orders it
+// 3.6 % faster than the default one - which in turn crashes the compiler on other kernels of the library, hence the split.
+#include <hip/hip_runtime.h>
+
+#define NTK_SCAN_TEMPLATES_ONLY
+#include "ntk_kernels.hpp"
+
+using namespace ntk;
+
+namespace {
+constexpr int kScan2HistBits = 14;   // LDS histogram of the sv2 builds: 64 KiB, two 768-thread blocks per CU
+}
+
+#ifndef NTK_SCAN2_MIN_BUILDS
+const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality)
+{
+#define NTK_PICK_SV(KF, T, U)                                                                       \
+    if (!quality && k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits>;
+#define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
+    NTK_PICK_SV4(17) NTK_PICK_SV4(18) NTK_PICK_SV4(19) NTK_PICK_SV4(20) NTK_PICK_SV4(21) NTK_PICK_SV4(22) NTK_PICK_SV4(23) NTK_PICK_SV4(24)
+    NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
+#undef NTK_PICK_SV4
+#undef NTK_PICK_SV
+#define NTK_PICK_SVQ(KF, T, U)                                                                      \
+    if (quality && k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, true, kScan2HistBits>;
+    NTK_PICK_SVQ(21, false, false) NTK_PICK_SVQ(21, false, true) NTK_PICK_SVQ(21, true, false) NTK_PICK_SVQ(21, true, true)
+    NTK_PICK_SVQ(31, false, false) NTK_PICK_SVQ(31, false, true) NTK_PICK_SVQ(31, true, false) NTK_PICK_SVQ(31, true, true)
+#undef NTK_PICK_SVQ
+    return nullptr;
+}
+
+#else
+// (compiled a second time with -DNTK_SCAN2_MIN_BUILDS and the DEFAULT scheduler into ntk_scan2_min.o: the iterative one crashes the
+// register allocator on these builds)
+// Fused windowed-minimizer builds (ntk_tile.hpp lane_tile_sv2_min): w = 11 for 17 <= k <= 22 (configs[4] is w = 11, k = 21), plus a
+// few neighbours of that point; every other (k, w) takes the two-pass path (materialise + window-min).
+const void *ntk_pick_scan2_min(int k, int w, bool tie_rc, bool accept_u)
+{
+#define NTK_PICK_MIN(KF, WF, T, U) if (k == KF && w == WF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits, WF>;
+#define NTK_PICK_MIN4(KF, WF) NTK_PICK_MIN(KF, WF, false, false) NTK_PICK_MIN(KF, WF, false, true) NTK_PICK_MIN(KF, WF, true, false) NTK_PICK_MIN(KF, WF, true, true)
+    NTK_PICK_MIN4(17, 11) NTK_PICK_MIN4(18, 11) NTK_PICK_MIN4(19, 11) NTK_PICK_MIN4(20, 11) NTK_PICK_MIN4(21, 11) NTK_PICK_MIN4(22, 11)
+    NTK_PICK_MIN4(21, 9) NTK_PICK_MIN4(21, 10) NTK_PICK_MIN4(21, 12)
+#undef NTK_PICK_MIN4
+#undef NTK_PICK_MIN
+    return nullptr;
+}
+#endif
