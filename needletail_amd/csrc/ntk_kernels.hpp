@@ -603,6 +603,10 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     uint64_t *const s_red = L.red;
     if ((uint32_t)(uintptr_t)&L.hist[0] != 0u) __builtin_trap();
 
+#ifdef NTK_V_CLOCKS
+    const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+    uint32_t dbg_tiles = 0;
+#endif
     for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
     s_nfwd[threadIdx.x] = 0;
     __syncthreads();
@@ -663,6 +667,9 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
             voff += kTileStride; tile_byte += kTileStride;
+#ifdef NTK_V_CLOCKS
+            dbg_tiles++;
+#endif
         };
         // the next tile's load is in flight while the current one is processed
         u32x4 ta = load_tile(voff), qa = ta, tb = ta, qb = ta;
@@ -686,6 +693,16 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         next = __builtin_amdgcn_readfirstlane(next);
     }
 
+#ifdef NTK_V_CLOCKS
+    if ((threadIdx.x & 63) == 0 && a.values) {  // per-wave census (tools/kbench.hip): start, end of the tile loop, shader cycles | tiles << 40, placement
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        a.values[w * 4 + 0] = dbg_w0; a.values[w * 4 + 1] = wall_clock64();
+        a.values[w * 4 + 2] = ((clock64() - dbg_c0) & 0xFFFFFFFFFFull) | ((uint64_t)dbg_tiles << 40); a.values[w * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
+    }
+#endif
     // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
     constexpr int S = 64 - 2 * K;

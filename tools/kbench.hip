@@ -90,7 +90,7 @@ int main(int argc, char **argv)
         std::vector<uint64_t> dbg((size_t)blocks * 4);
         CHK(hipMemcpy(dbg.data(), d_dbg, dbg.size() * 8, hipMemcpyDeviceToHost));
         uint64_t tmin = ~0ull, tmax = 0; double life = 0, cyc = 0;
-        for (int b = 0; b < blocks; b++) { tmin = std::min(tmin, dbg[b * 4]); tmax = std::max(tmax, dbg[b * 4 + 1]); life += dbg[b * 4 + 1] - dbg[b * 4]; cyc += dbg[b * 4 + 2]; }
+        for (int b = 0; b < blocks; b++) { tmin = std::min(tmin, dbg[b * 4]); tmax = std::max(tmax, dbg[b * 4 + 1]); life += dbg[b * 4 + 1] - dbg[b * 4]; cyc += dbg[b * 4 + 2] & 0xFFFFFFFFFFull; }
         printf("   census: span %.4f ms, mean block life %.4f ms, mean concurrency %.1f blocks, mean shader clock %.3f GHz\n",
                (tmax - tmin) * 1e-5, life / blocks * 1e-5, life / (double)(tmax - tmin), cyc / (life * 10.0));
         // concurrency histogram over 20 time slices, and distinct (xcc, se, sh, cu) seen
@@ -107,6 +107,16 @@ int main(int argc, char **argv)
         for (int i = 0; i < blocks; i += blocks / 16) printf(" %.1f", starts[i] * 0.01); printf("\n");
         std::vector<uint64_t> ends; for (int b = 0; b < blocks; b++) ends.push_back(dbg[b * 4 + 1] - tmin); std::sort(ends.begin(), ends.end());
         printf("   wave end-time percentiles (ms): p0 %.3f p10 %.3f p25 %.3f p50 %.3f p75 %.3f p90 %.3f p100 %.3f\n", ends[0]*1e-5, ends[blocks/10]*1e-5, ends[blocks/4]*1e-5, ends[blocks/2]*1e-5, ends[blocks*3/4]*1e-5, ends[blocks*9/10]*1e-5, ends[blocks-1]*1e-5);
+        {   // tiles per wave (scan2 builds): spread, and by hardware wave slot (HW_ID bits 3:0) - is a slot starved?
+            std::vector<uint32_t> tl; double by_slot[16] = {0}, end_slot[16] = {0}; int n_slot[16] = {0};
+            for (int b = 0; b < blocks; b++) { uint32_t t = (uint32_t)(dbg[b * 4 + 2] >> 40); tl.push_back(t); int sl = (int)(dbg[b * 4 + 3] & 15); by_slot[sl] += t; end_slot[sl] += (dbg[b * 4 + 1] - tmin) * 1e-5; n_slot[sl]++; }
+            std::sort(tl.begin(), tl.end());
+            if (tl.back()) {
+                printf("   tiles per wave: min %u p10 %u p50 %u p90 %u max %u\n   by wave slot (n, mean tiles, mean end ms):", tl[0], tl[blocks / 10], tl[blocks / 2], tl[blocks * 9 / 10], tl.back());
+                for (int i = 0; i < 16; i++) if (n_slot[i]) printf(" [%d: %d %.0f %.3f]", i, n_slot[i], by_slot[i] / n_slot[i], end_slot[i] / n_slot[i]);
+                printf("\n");
+            }
+        }
         blocks = blocks_;
     }
 #endif

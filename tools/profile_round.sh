@@ -15,9 +15,11 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- $BENCH --steps 5 --warmup 1 --no-verify --preheat-ms 5 > /dev/null 2> $O/pmc_sq2.err
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
+# one rank through the launcher: the RCCL all-reduce path of the N > 1 runs (communicator of size 1) on configs[3]'s 8-GPU shard size
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --workload c4 --reads 12500000 --no-cpu-baseline --no-secondary > $O/bench_rccl_1rank.json 2> $O/bench_rccl_1rank.err
 if [ -x tools/kb_s2_hb14 ]; then   # tools/build_kbench.sh; 2 x 768 threads per CU, 256 work counters, chunks of 32 tiles
   ( cd tools; for v in cur; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 768 512 20 r01_kernel 16 8; done
-    for v in s2_hb14 a_nolds a_noexec a_nomaskalg a_nosdwa a_nodigest a_noemit a_loads; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 512 768 20 $v 32 256; done
+    for v in s2_hb14 s2_default a_nolds a_noexec a_nomaskalg a_nosdwa a_nodigest a_noemit a_loads; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 512 768 20 $v 32 256; done
     ./kb_a_loads 10000000 21 512 768 20 loads_8_counters 16 8
     ./kb_s2_hb14 10000000 31 512 768 20 s2_hb14_k31 32 256 ) > $O/ablation.txt 2>&1
   ( cd tools; ./ubench ) > $O/ubench.txt 2>&1
