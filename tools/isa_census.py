@@ -14,7 +14,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DNTK_KB_FIX", "-DNTK_KB_SV", "-DNTK_KB_SV2",
-                           "-DNTK_KB_HB=14", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "tools", "kbench.hip")],
+                           "-DNTK_KB_HB=14", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "tools", "kbench.hip")],
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
 name = f"_ZN3ntk12scan2_kernelILi{K}ELb1ELb1ELb0ELi14ELi0EEEvNS_8ScanArgsE"
