@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Time-budgeted differential fuzz of the device paths against the oracle (run on the GPU box through gpurun; the tests hold the
+fixed-seed versions of these checks).  Inputs are STRUCTURED to hit what a streaming tile kernel can get wrong: record lengths
+around the lane (16), tile (992 / 1024) and chunk boundaries, runs of N / break bytes of every length around k, breaks exactly
+at lane and tile edges, lowercase / U / IUPAC / whitespace / high bytes, empty and one-byte inputs.
+
+    python tools/gpu_fuzz.py --seconds 150 --seed 1 > profiles/<round>/gpu_fuzz.log
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import needletail_amd as nt  # noqa: E402
+import oracle as O  # noqa: E402  (checker)
+
+MODES = [  # (path, pre, canonical, tie_rc, accept_u)
+    (nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True, True),
+    (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, True, False, False),
+    (nt.PATH_BITS, nt.PRE_STRIP_RETURNS, False, False, False),
+    (nt.PATH_BITS_CANONICAL, nt.PRE_NORMALIZE_IUPAC, True, False, True),
+    (nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE_IUPAC, True, True, True),
+]
+EDGE = [0, 1, 2, 15, 16, 17, 31, 32, 33, 150, 151, 991, 992, 993, 1007, 1008, 1009, 1023, 1024, 1025, 1984, 2016, 2048,
+        992 * 24 - 1, 992 * 24, 992 * 24 + 1]
+JUNK = np.frombuffer(b"NnUuRYKMSWBDHVrykm-.*\x00\x7f\x80\xff0@>+", dtype=np.uint8)
+
+
+def make_input(rng, k):
+    """bytes with structure; returns a uint8 array"""
+    kind = rng.integers(0, 7)
+    n = int(rng.choice(EDGE)) + int(rng.integers(-3, 4)) if rng.random() < 0.5 else int(rng.integers(0, 60000))
+    n = max(n, 0)
+    if kind == 6:
+        n = int(rng.integers(200000, 3000000))
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    if n == 0:
+        return a
+    if kind == 0:      # clean
+        pass
+    elif kind == 1:    # records of edge lengths separated by newlines
+        pos = 0
+        while pos < n:
+            pos += max(0, int(rng.choice(EDGE[:18])) + int(rng.integers(-2, 3)))
+            if pos < n:
+                a[pos] = 10
+            pos += 1
+    elif kind == 2:    # runs of N of lengths around k, at random and at lane / tile edges
+        for _ in range(int(rng.integers(1, 40))):
+            ln = max(1, k + int(rng.integers(-3, 4))) if rng.random() < 0.6 else int(rng.integers(1, 70))
+            at = int(rng.integers(0, n))
+            if rng.random() < 0.5:
+                at = (at // 16) * 16 + int(rng.integers(-1, 2))
+            if rng.random() < 0.3:
+                at = (at // 992) * 992 + int(rng.integers(-2, 3))
+            at = min(max(at, 0), n - 1)
+            a[at:at + ln] = ord("N")
+    elif kind == 3:    # mixed case, U, IUPAC, whitespace, junk
+        m = rng.random(n)
+        a[m < 0.15] |= 0x20
+        sel = m > 0.93
+        a[sel] = JUNK[rng.integers(0, len(JUNK), int(sel.sum()))]
+        ws = (m > 0.90) & (m <= 0.93)
+        a[ws] = np.frombuffer(b" \t\r\n", dtype=np.uint8)[rng.integers(0, 4, int(ws.sum()))]
+        us = (m > 0.88) & (m <= 0.90)
+        a[us] = np.frombuffer(b"Uu", dtype=np.uint8)[rng.integers(0, 2, int(us.sum()))]
+    elif kind == 4:    # single breaks exactly every k-1, k, k+1 bases (no / one / two windows between breaks)
+        step = max(1, k + int(rng.integers(-1, 2)))
+        a[step - 1::step + 1] = ord("N") if rng.random() < 0.5 else 10
+    elif kind == 5:    # low-complexity and palindromic stretches (strand ties for even k)
+        unit = np.frombuffer([b"AT", b"ACGT", b"A", b"GC", b"AATT", b"ACGTACGTTGCA"][int(rng.integers(0, 6))], dtype=np.uint8)
+        a = np.resize(unit, n).copy()
+        for _ in range(int(rng.integers(0, 6))):
+            at = int(rng.integers(0, n)); a[at:at + int(rng.integers(1, 40))] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4)]
+    else:              # long, sparse breaks
+        idx = rng.integers(0, n, max(1, n // 1500))
+        a[idx] = ord("N")
+    return a
+
+
+def stats_equal(a, b):
+    return all(int(a[x]) == int(b[x]) for x in ("n_total", "n_fwd", "n_rc", "sum", "xor")) and np.array_equal(a["hist"], b["hist"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    t_end = time.time() + args.seconds
+    counts = {"reduce": 0, "materialize": 0, "minimizers": 0, "quality": 0, "compat_batch": 0}
+    n_bytes = 0
+    it = 0
+    while time.time() < t_end:
+        it += 1
+        k = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 11, 15, 16, 17, 18, 20, 21, 22, 23, 24, 27, 30, 31, 32]))
+        path, pre, canon, tie, u = MODES[int(rng.integers(0, len(MODES)))]
+        a = make_input(rng, k)
+        n = len(a)
+        n_bytes += n
+        t = torch.full(((n + 1023) // 1024 * 1024 + 1024,), 0x41, dtype=torch.uint8, device="cuda")
+        if n:
+            t[:n] = torch.from_numpy(a).cuda()
+        buf = a.tobytes()
+        what = rng.integers(0, 10)
+        tag = f"it {it} seed {args.seed} k {k} path {path} pre {pre} n {n}"
+        if what < 5:
+            ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre)
+            if not stats_equal(ctx.accum_read(), O.reduce_fused(buf, k, canon, tie, u)):
+                print("MISMATCH reduce", tag); return 1
+            counts["reduce"] += 1
+        elif what < 6 and n <= 400000:
+            vals = torch.zeros((n + 15) // 16 * 16 + 16, dtype=torch.int64, device="cuda")
+            v16 = torch.zeros((n + 15) // 16 + 1, dtype=torch.int16, device="cuda"); r16 = torch.zeros_like(v16)
+            ctx.materialize_device(t, n, k, path, pre, vals, v16, r16)
+            hv = vals.cpu().numpy().view(np.uint64)
+            e = np.arange(n)   # position e (window end byte) = bit 15 - e % 16 of word e / 16
+            bits = ((v16.cpu().numpy().view(np.uint16)[e // 16] >> (15 - e % 16)) & 1).astype(bool)
+            rb = ((r16.cpu().numpy().view(np.uint16)[e // 16] >> (15 - e % 16)) & 1).astype(bool)
+            # the dense planes reduce to the oracle's result (position = window end byte)
+            want = O.reduce_fused(buf, k, canon, tie, u)
+            sel = hv[:n][bits]
+            got_sum = int(np.add.reduce(sel, dtype=np.uint64)) if len(sel) else 0
+            got_xor = int(np.bitwise_xor.reduce(sel)) if len(sel) else 0
+            if not (int(bits.sum()) == want["n_total"] and int((bits & rb).sum()) == want["n_rc"] and got_sum == int(want["sum"])
+                    and got_xor == int(want["xor"])):
+                print("MISMATCH materialize", tag); return 1
+            counts["materialize"] += 1
+        elif what < 8 and canon and path == nt.PATH_BYTES_CANONICAL and pre == nt.PRE_NORMALIZE:
+            w = int(rng.choice([1, 2, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
+            kk = k if rng.random() < 0.5 else int(rng.choice([17, 18, 19, 20, 21, 22]))
+            ctx.accum_reset(); ctx.reduce_device(t, n, kk, path, pre, w=w)
+            if not stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, kk, w, True, True)):
+                print("MISMATCH minimizers", tag, "w", w, "kk", kk); return 1
+            counts["minimizers"] += 1
+        elif what < 9:
+            q = rng.integers(33, 75, n, dtype=np.uint8)
+            if n and rng.random() < 0.5:
+                q[:] = 73; q[rng.integers(0, n, max(1, n // 50))] = 34
+            cutoff = int(rng.integers(33, 76))
+            tq = torch.full_like(t, 0x49)
+            if n:
+                tq[:n] = torch.from_numpy(q).cuda()
+            ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre, d_qual=tq, quality_cutoff=cutoff)
+            masked = O.quality_mask(buf, q.tobytes(), cutoff)
+            if not stats_equal(ctx.accum_read(), O.reduce_fused(masked, k, canon, tie, u)):
+                print("MISMATCH quality", tag, "cutoff", cutoff); return 1
+            counts["quality"] += 1
+        elif n <= 300000:
+            # batched compat face against the per-record oracle iterators
+            cuts = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, int(rng.integers(0, 30)))])).astype(np.int64)
+            recs = [buf[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+            if not recs:
+                continue
+            if rng.random() < 0.5:
+                cnt, pos, flg = nt.canonical_kmers_batch(recs, k, ctx=ctx)
+                wp, wf = [], []
+                for r in recs:
+                    p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), k)
+                    wp.append(np.asarray(p_, dtype=np.uint64)); wf.append(np.asarray(f_, dtype=np.uint8))
+                ok = [len(x) for x in wp] == list(map(int, cnt)) and np.array_equal(np.concatenate(wp) if wp else [], pos) and \
+                    np.array_equal(np.concatenate(wf) if wf else [], flg)
+            else:
+                c2 = bool(rng.integers(0, 2))
+                cnt, pos, val, flg = nt.bit_kmers_batch(recs, k, c2, ctx=ctx)
+                wp, wv, wf = [], [], []
+                for r in recs:
+                    p_, v_, f_ = O.bit_kmers_arrays(r, k, c2)
+                    wp.append(np.asarray(p_, dtype=np.uint64)); wv.append(np.asarray(v_, dtype=np.uint64)); wf.append(np.asarray(f_, dtype=np.uint8))
+                ok = [len(x) for x in wp] == list(map(int, cnt)) and np.array_equal(np.concatenate(wp), pos) and \
+                    np.array_equal(np.concatenate(wv), val) and np.array_equal(np.concatenate(wf), flg)
+            if not ok:
+                print("MISMATCH compat batch", tag); return 1
+            counts["compat_batch"] += 1
+    print(f"gpu_fuzz: seed {args.seed}, {args.seconds:.0f} s, {it} inputs, {n_bytes / 1e6:.1f} MB, all equal to the oracle: {counts}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
