@@ -178,6 +178,18 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     del cseq
     torch.cuda.empty_cache()
 
+    # forward-only bit path (BitNuclKmer with canonical = false, reference src/bitkmer.rs:80-108) on the config-2 batch: what the
+    # kernel reaches when the contract asks for no strand choice (no rc stream, no compare, no strand counter)
+    pre_r = 2000
+    ctx.accum_reset()
+    ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 21, nt.PATH_BITS, nt.PRE_NONE)
+    hs = k21_seq[: pre_r * (read_len + 1)].cpu().numpy().tobytes()
+    if not stats_equal(ctx.accum_read(), O.reduce_fused(hs, 21, False, False, False)):
+        raise SystemExit("secondary: forward-only prefix differs from the oracle")
+    ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BITS, nt.PRE_NONE)), 20)
+    out["bits_forward_k21"] = {"workload": "config-2 batch, k=21, BitNuclKmer canonical=false, reduce mode, resident", "kernel_ms": round(ms, 4),
+                               "GB_s": round(k21_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(k21_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
     # materialise mode (dense u64 per window + two flag planes), config-2 batch
     vals = torch.empty((k21_bytes + 15) // 16 * 16, dtype=torch.int64, device="cuda")
     v16 = torch.empty((k21_bytes + 15) // 16, dtype=torch.int16, device="cuda")

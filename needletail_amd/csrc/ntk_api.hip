@@ -21,6 +21,7 @@ using namespace ntk;
 // the sv2 builds (ntk_scan2.hip): nullptr when (k, flags) has none
 const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality);
 const void *ntk_pick_scan2_min(int k, int w, bool tie_rc, bool accept_u);
+const void *ntk_pick_scan2_fwd(int k, bool accept_u);
 
 namespace {
 
@@ -188,7 +189,7 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
-inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && m.canon && k >= 17 && (!qm || k == 21 || k == 31); }
+inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && k >= 17 && (m.canon ? (!qm || k == 21 || k == 31) : !qm); }
 
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
@@ -197,6 +198,8 @@ const void *pick_scan(const Mode &m, uint32_t k)
     // unit (ntk_scan2.hip, built with the ILP-driven iterative scheduler)
     if (REDUCE && m.kw == 2 && m.canon)
         if (const void *fn = ntk_pick_scan2((int)k, m.tie_rc, m.accept_u, QM)) return fn;
+    if (REDUCE && !QM && m.kw == 2 && !m.canon)
+        if (const void *fn = ntk_pick_scan2_fwd((int)k, m.accept_u)) return fn;
 #define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
 #define NTK_PICK_SV(KF, T, U)                                                                       \
     if (REDUCE && !QM && m.kw == 1 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \

@@ -469,6 +469,59 @@ struct DevMasks2 {
         return r;
     }
 
+    // byte offset of a position's histogram cell (see emit4): LIGHT packs two positions' prefixes into one T word
+    __device__ __forceinline__ uint32_t cell_offset(uint32_t T, int i) const
+    {
+        if (kLight && i >= 2) return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu);
+        if (HB == 14) {
+            uint32_t off;
+            const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "s"(kMask), "v"(T));
+            return off;
+        }
+        return (T >> 18) & 0x3FFCu;
+    }
+
+    // Forward-only builds (lane_tile_sv2_fwd): emit4 without the strand counter.
+    template <class S>
+    __device__ __forceinline__ void emit4_fwd(S &, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
+    {
+        uint64_t val[4];
+        uint32_t off[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { val[i] = ((uint64_t)hi[i] << 32) | lo[i]; off[i] = cell_offset(T[i], i); }
+        if constexpr (kLight) {
+#define NTK_EMITF(i)                                             \
+        "s_mov_b64 exec, %[V" #i "]\n"                          \
+        "ds_add_u32 %[o" #i "], %[one]\n"                       \
+        "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n"    \
+        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
+            asm volatile(NTK_EMITF(0) NTK_EMITF(1) NTK_EMITF(2) NTK_EMITF(3) "s_mov_b64 exec, -1\n"
+                         : [sum] "+v"(sum), [xlo] "+v"(xlo)
+                         : [o0] "v"(off[0]), [l0] "v"(lo[0]), [V0] "s"(V[pos[0]]), [o1] "v"(off[1]), [l1] "v"(lo[1]), [V1] "s"(V[pos[1]]),
+                           [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[pos[2]]), [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[pos[3]]),
+                           [one] "v"(one)
+                         : "memory", "vcc");
+#undef NTK_EMITF
+        } else {
+#define NTK_EMITF(i)                                             \
+        "s_mov_b64 exec, %[V" #i "]\n"                          \
+        "ds_add_u32 %[o" #i "], %[one]\n"                       \
+        "v_lshl_add_u64 %[sum], %[v" #i "], 0, %[sum]\n"        \
+        "v_xor_b32 %[xT], %[xT], %[T" #i "]\n"                  \
+        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
+            asm volatile(NTK_EMITF(0) NTK_EMITF(1) NTK_EMITF(2) NTK_EMITF(3) "s_mov_b64 exec, -1\n"
+                         : [sum] "+v"(sum), [xT] "+v"(xT), [xlo] "+v"(xlo)
+                         : [o0] "v"(off[0]), [v0] "v"(val[0]), [l0] "v"(lo[0]), [T0] "v"(T[0]), [V0] "s"(V[pos[0]]),
+                           [o1] "v"(off[1]), [v1] "v"(val[1]), [l1] "v"(lo[1]), [T1] "v"(T[1]), [V1] "s"(V[pos[1]]),
+                           [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[pos[2]]),
+                           [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[pos[3]]),
+                           [one] "v"(one)
+                         : "memory", "vcc");
+#undef NTK_EMITF
+        }
+    }
+
     // Side effects of four positions pos[0..3].  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
     // Per position, under the validity mask: histogram cell += 1 and the digests; under validity & strand mask: the
     // thread's own forward counter += 1 (non-returning LDS atomics: no VALU work for either count).
@@ -588,7 +641,7 @@ struct NoSink {};
 #define NTK_SV2_MINWAVES 1
 #endif
 // W > 0: windowed minimizers fused into the scan (lane_tile_sv2_min) instead of every k-mer
-template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12, int W = 0>
+template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12, int W = 0, bool FWD = false>
 __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs a)
 {
     static_assert(K >= 17 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 17 <= k <= 32");
@@ -663,7 +716,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #else
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
             mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-            if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
+            if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
+            else if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
             voff += kTileStride; tile_byte += kTileStride;
@@ -756,6 +810,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         }
         uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
         if constexpr (W > 0 && !TIE_RC) tf = tv - tf;   // the bits counted the reverse-complement choices
+        if constexpr (FWD) tf = tv;                     // forward-only builds keep no strand counter
         ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
     }
 }

@@ -1,5 +1,5 @@
-// ntk_scan2.hip - the instantiations of ntk::scan2_kernel (canonical reduce mode for 17 <= k <= 32, the quality-masked k = 21 / 31
-// builds and the fused windowed-minimizer builds) in their own translation unit: the tile loop is one long straight-line
+// ntk_scan2.hip - the instantiations of ntk::scan2_kernel (canonical and forward-only reduce mode for 17 <= k <= 32, the quality-masked
+// k = 21 / 31 builds and the fused windowed-minimizer builds) in their own translation unit: the tile loop is one long straight-line
 // block, and the ILP-driven iterative scheduler (-mllvm -amdgpu-sched-strategy=iterative-ilp, see the Makefile) orders it
 // 3.6 % faster than the default one - which in turn crashes the compiler on other kernels of the library, hence the split.
 #include <hip/hip_runtime.h>
@@ -28,6 +28,18 @@ const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality)
     NTK_PICK_SVQ(21, false, false) NTK_PICK_SVQ(21, false, true) NTK_PICK_SVQ(21, true, false) NTK_PICK_SVQ(21, true, true)
     NTK_PICK_SVQ(31, false, false) NTK_PICK_SVQ(31, false, true) NTK_PICK_SVQ(31, true, false) NTK_PICK_SVQ(31, true, true)
 #undef NTK_PICK_SVQ
+    return nullptr;
+}
+
+// Forward-only builds (BitNuclKmer with canonical = false; lane_tile_sv2_fwd), 17 <= k <= 32.
+const void *ntk_pick_scan2_fwd(int k, bool accept_u)
+{
+#define NTK_PICK_FWD(KF, U) if (k == KF && accept_u == U) return (const void *)&scan2_kernel<KF, false, U, false, kScan2HistBits, 0, true>;
+#define NTK_PICK_FWD2(KF) NTK_PICK_FWD(KF, false) NTK_PICK_FWD(KF, true)
+    NTK_PICK_FWD2(17) NTK_PICK_FWD2(18) NTK_PICK_FWD2(19) NTK_PICK_FWD2(20) NTK_PICK_FWD2(21) NTK_PICK_FWD2(22) NTK_PICK_FWD2(23) NTK_PICK_FWD2(24)
+    NTK_PICK_FWD2(25) NTK_PICK_FWD2(26) NTK_PICK_FWD2(27) NTK_PICK_FWD2(28) NTK_PICK_FWD2(29) NTK_PICK_FWD2(30) NTK_PICK_FWD2(31) NTK_PICK_FWD2(32)
+#undef NTK_PICK_FWD2
+#undef NTK_PICK_FWD
     return nullptr;
 }
 

@@ -622,6 +622,38 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
     }
 }
 
+// Forward-only sv2 (BitNuclKmer with canonical = false, reference src/bitkmer.rs:80-108 and Sequence::bit_kmers(k, false),
+// src/sequence.rs:250-252): no reverse-complement stream, no strand compare and no strand counter - the T word of position j is
+// fw[j - D], its lo word fw[j]; every k-mer counts as forward (n_fwd = n_total at block end).
+template <int K, class Sink, class XL, class MP>
+NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
+{
+    static_assert(K >= 17 && K <= 32, "sv2 is the 64-bit-value path");
+    constexpr int D = K - 16, S = 64 - 2 * K;
+    constexpr bool LIGHT = MP::kLight;
+    uint32_t fw[16 + D];   // index g + D
+    const uint32_t c1 = xl.prev(kSlotCode, code);
+    fw[D + 15] = code;
+    fw[D - 1] = c1;
+#pragma unroll
+    for (int j = 0; j < 15; j++) fw[D + j] = alignbit(c1, code, 30 - 2 * j);
+#pragma unroll
+    for (int g = 2; g <= D; g++) fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+#pragma unroll
+    for (int jp = 0; jp < 8; jp += 2) {
+        const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
+        uint32_t T[4], lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // LIGHT: fw[j - D] carries the histogram prefix of position j in bits 31:16 and that of position j + 8 in bits 15:0
+            T[i] = LIGHT ? fw[pos[i & 1]] : fw[pos[i]];
+            lo[i] = fw[D + pos[i]];
+            hi[i] = LIGHT ? 0u : (S ? T[i] >> S : T[i]);
+        }
+        mp.emit4_fwd(sink, pos, T, hi, lo);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // "sv2" windowed minimizers, fused into the scan (BASELINE.json configs[4]; SURVEY.md A.7: sequence::minimizer, reference
 // src/sequence.rs:139-152, applied to every window of W+K-1 good bases).  The window ending at byte e holds the W k-mers

@@ -176,6 +176,14 @@ struct EmuMP2 {
             n_fwd += fwd[i] ? 1 : 0;
         }
     }
+    bool fwd_only = false;
+    template <class S>
+    void emit4_fwd(S &s_, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
+    {
+        const bool all[4] = {true, true, true, true};
+        fwd_only = true;
+        emit4(s_, pos, all, T, hi, lo);
+    }
     uint64_t min64(uint64_t a, uint64_t b) const { return a < b ? a : b; }   // v_min_f64 on positive normal doubles
     uint64_t nf_bits = 0;
     bool min_mode = false, tie_rc = false;
@@ -210,13 +218,14 @@ struct EmuMP2 {
             xr = (xf << (2 * K - HB)) | (uint64_t)(xlo & low_mask);
         }
         if (min_mode) n_fwd = tie_rc ? nf_bits : nv - nf_bits;
+        if (fwd_only) n_fwd = nv;   // the forward-only kernel keeps no strand counter: n_fwd = n_total
         st->n_total += nv; st->n_fwd += n_fwd; st->sum += s; st->xr ^= xr;
     }
 };
 
 struct EmuNoSink {};
 
-template <bool TIE_RC, bool ACCEPT_U, int K, int HB, int W = 0>
+template <bool TIE_RC, bool ACCEPT_U, int K, int HB, int W = 0, bool FWD = false>
 void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
 {
     const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
@@ -241,7 +250,8 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
         for (int l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             mp.lane = l;
-            if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en[l].code, en[l].rcode);
+            if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en[l].code);
+            else if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en[l].code, en[l].rcode);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en[l].code, en[l].rcode);
         }
     }
@@ -271,10 +281,16 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     // bit 2 of tiles_per_wave: the second-generation scalar-validity variant (17 <= k <= 32); bit 3 picks its 14-bit histogram
     const bool sv2 = (tiles_per_wave & 4) && canon && !values && k >= 17;
     const bool hb14 = (tiles_per_wave & 8) != 0;
+    // the forward-only sv2 builds (BitNuclKmer, canonical = false)
+    const bool sv2f = (tiles_per_wave & 4) && !canon && !values && k >= 17;
 #define EMU_SV2(KF, T, U) if (sv2 && k == KF && !!tie_rc == T && !!accept_u == U) { if (hb14) run_sv2<T, U, KF, 14>(buf, n, n_padded, st); else run_sv2<T, U, KF, 12>(buf, n, n_padded, st); } else
 #define EMU_SV24(KF) EMU_SV2(KF, false, false) EMU_SV2(KF, false, true) EMU_SV2(KF, true, false) EMU_SV2(KF, true, true)
     EMU_SV24(17) EMU_SV24(18) EMU_SV24(19) EMU_SV24(20) EMU_SV24(21) EMU_SV24(22) EMU_SV24(23) EMU_SV24(24)
     EMU_SV24(25) EMU_SV24(26) EMU_SV24(27) EMU_SV24(28) EMU_SV24(29) EMU_SV24(30) EMU_SV24(31) EMU_SV24(32)
+#define EMU_SV2F(KF, U) if (sv2f && k == KF && !!accept_u == U) { if (hb14) run_sv2<false, U, KF, 14, 0, true>(buf, n, n_padded, st); else run_sv2<false, U, KF, 12, 0, true>(buf, n, n_padded, st); } else
+#define EMU_SV2F2(KF) EMU_SV2F(KF, false) EMU_SV2F(KF, true)
+    EMU_SV2F2(17) EMU_SV2F2(18) EMU_SV2F2(19) EMU_SV2F2(20) EMU_SV2F2(21) EMU_SV2F2(22) EMU_SV2F2(23) EMU_SV2F2(24)
+    EMU_SV2F2(25) EMU_SV2F2(26) EMU_SV2F2(27) EMU_SV2F2(28) EMU_SV2F2(29) EMU_SV2F2(30) EMU_SV2F2(31) EMU_SV2F2(32)
 #define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
 #define EMU_SV4(KF) EMU_SV(KF, false, false) EMU_SV(KF, false, true) EMU_SV(KF, true, false) EMU_SV(KF, true, true)
     EMU_SV4(1) EMU_SV4(2) EMU_SV4(3) EMU_SV4(4) EMU_SV4(5) EMU_SV4(6) EMU_SV4(7) EMU_SV4(8)

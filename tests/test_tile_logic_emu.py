@@ -120,6 +120,26 @@ def test_emu_random_alphabet_and_lengths(emu):
             assert_stats_equal(got, want, (trial, n, k, canon, tie_rc, accept_u))
 
 
+@pytest.mark.parametrize("k", list(range(17, 33)))
+def test_emu_sv2_forward_only(emu, k):
+    """lane_tile_sv2_fwd (BitNuclKmer with canonical = false, reference src/bitkmer.rs:80-108): several tiles, breaks at lane and
+    tile edges, both histogram sizes, with and without U."""
+    rng = np.random.default_rng(100 + k)
+    alphabet = np.frombuffer(b"ACGT" * 8 + b"acgtNUu\n", dtype=np.uint8)
+    n = int(rng.integers(3000, 7000))
+    a = alphabet[rng.integers(0, len(alphabet), n)].copy()
+    for at in (15, 16, 17, 991, 992, 993, 1007, 1008, 1984, 2 * 992 - k, 3 * 992 + k):
+        a[at] = ord("N")
+    a[2500:2500 + k - 1] = ord("A"); a[2499] = a[2500 + k - 1] = ord("N")   # k-1 good bases between two breaks: no window
+    a[2600:2600 + k] = ord("C"); a[2599] = a[2600 + k] = ord("N")           # exactly one window
+    buf = a.tobytes()
+    for accept_u in (0, 1):
+        want = O.reduce_fused(buf, k, False, False, bool(accept_u))
+        assert want["n_fwd"] == want["n_total"] and want["n_rc"] == 0
+        for tpw in (4, 12):
+            assert_stats_equal(emu_scan(emu, buf, k, 0, 0, accept_u, tpw), want, (k, accept_u, tpw))
+
+
 def test_emu_materialize_matches_bit_kmers(emu):
     rng = np.random.default_rng(5)
     alphabet = np.frombuffer(b"ACGTACGTACGTacgtN", dtype=np.uint8)
