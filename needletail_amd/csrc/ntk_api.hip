@@ -189,25 +189,17 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
-inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && k >= 17 && (m.canon ? (!qm || k == 21 || k == 31) : !qm); }
+inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && (!qm || (m.canon && (k == 21 || k == 31))); }
 
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
 {
-    // canonical reduce, 17 <= k <= 32 (and the quality-masked k = 21 / 31 builds): the sv2 kernel lives in its own translation
-    // unit (ntk_scan2.hip, built with the ILP-driven iterative scheduler)
-    if (REDUCE && m.kw == 2 && m.canon)
+    // reduce mode, canonical or forward-only, every k (and the quality-masked canonical k = 21 / 31 builds): the sv2 kernel lives
+    // in its own translation unit (ntk_scan2.hip, built with the ILP-driven iterative scheduler)
+    if (REDUCE && m.canon)
         if (const void *fn = ntk_pick_scan2((int)k, m.tie_rc, m.accept_u, QM)) return fn;
-    if (REDUCE && !QM && m.kw == 2 && !m.canon)
+    if (REDUCE && !QM && !m.canon)
         if (const void *fn = ntk_pick_scan2_fwd((int)k, m.accept_u)) return fn;
-#define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
-#define NTK_PICK_SV(KF, T, U)                                                                       \
-    if (REDUCE && !QM && m.kw == 1 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)       \
-        return (const void *)&scan_kernel<1, true, T, U, true, KF, true>;
-    NTK_PICK_SV4(1) NTK_PICK_SV4(2) NTK_PICK_SV4(3) NTK_PICK_SV4(4) NTK_PICK_SV4(5) NTK_PICK_SV4(6) NTK_PICK_SV4(7) NTK_PICK_SV4(8)
-    NTK_PICK_SV4(9) NTK_PICK_SV4(10) NTK_PICK_SV4(11) NTK_PICK_SV4(12) NTK_PICK_SV4(13) NTK_PICK_SV4(14) NTK_PICK_SV4(15) NTK_PICK_SV4(16)
-#undef NTK_PICK_SV4
-#undef NTK_PICK_SV
 #define NTK_PICK_FIX(KF, T, U)                                                                      \
     if (!REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)      \
         return (const void *)&scan_kernel<2, true, T, U, false, KF, false>;

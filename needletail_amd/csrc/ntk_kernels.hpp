@@ -391,6 +391,8 @@ struct DevMasks2 {
     uint64_t sum = 0;        // per-lane digests: sum of (hi:lo) (of the lo words when kLight); xor words of T and lo
     uint32_t xT = 0, xlo = 0;
     uint32_t cell = 0;       // LDS byte address of this thread's forward-strand counter
+    uint32_t rep = 0;        // word builds, K <= 6: this lane's histogram copy (see emit4w)
+    static constexpr int kWordCopies = K <= 6 ? (((1 << HB) >> (2 * (K <= 6 ? K : 0))) < 64 ? ((1 << HB) >> (2 * (K <= 6 ? K : 0))) : 64) : 1;
     uint32_t one = 1;
     uint32_t nf_s = 0;       // NTK_SV2_NFWD_SALU: forward-strand count of the wave, scalar
     uint32_t nf_v = 0;       // NTK_SV2_NFWD_VALU: forward-strand count of the lane
@@ -423,7 +425,7 @@ struct DevMasks2 {
 #pragma unroll
         for (int i = 0; i < 16; i++) V[i] = B[i];
 #else
-        window_masks<KM>(B, V);
+        if constexpr (KM >= 17) window_masks<KM>(B, V); else window_masks1<KM>(B, V);
 #endif
     }
 
@@ -520,6 +522,49 @@ struct DevMasks2 {
                          : "memory", "vcc");
 #undef NTK_EMITF
         }
+    }
+
+    // Word builds (K <= 16, lane_tile_sv2w): v = the chosen value, left-aligned; cell = its top HB bits.
+    template <bool FWD_ONLY, class S>
+    __device__ __forceinline__ void emit4w(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&v)[4])
+    {
+        uint32_t off[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // K <= 6: 4^K bins do not fill the cells: the lane's copy number (rep = lane mod kWordCopies) goes on top of the value, so
+            // that the lanes of a wave do not queue up on a handful of cells.  The left-aligned word has zeros below the value:
+            // one funnel shift yields (rep : value : 00), the 4-byte-aligned offset of cell rep * 4^K + value.
+            if constexpr (K <= 6) off[i] = alignbit(rep, v[i], 30 - 2 * K);
+            else off[i] = cell_offset(v[i], 0);
+        }
+#define NTK_EMITW(i)                                             \
+        "s_mov_b64 exec, %[V" #i "]\n"                          \
+        "ds_add_u32 %[o" #i "], %[one]\n"                       \
+        "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n"    \
+        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
+#define NTK_EMITWF(i) NTK_EMITW(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n" "ds_add_u32 %[cell], %[one]\n"
+        if constexpr (FWD_ONLY) {
+            asm volatile(NTK_EMITW(0) NTK_EMITW(1) NTK_EMITW(2) NTK_EMITW(3) "s_mov_b64 exec, -1\n"
+                         : [sum] "+v"(sum), [xlo] "+v"(xlo)
+                         : [o0] "v"(off[0]), [l0] "v"(v[0]), [V0] "s"(V[pos[0]]), [o1] "v"(off[1]), [l1] "v"(v[1]), [V1] "s"(V[pos[1]]),
+                           [o2] "v"(off[2]), [l2] "v"(v[2]), [V2] "s"(V[pos[2]]), [o3] "v"(off[3]), [l3] "v"(v[3]), [V3] "s"(V[pos[3]]),
+                           [one] "v"(one)
+                         : "memory", "vcc");
+        } else {
+            uint64_t F[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) F[i] = __builtin_amdgcn_ballot_w64(fwd[i]);   // the compare's own SGPR pair
+            asm volatile(NTK_EMITWF(0) NTK_EMITWF(1) NTK_EMITWF(2) NTK_EMITWF(3) "s_mov_b64 exec, -1\n"
+                         : [sum] "+v"(sum), [xlo] "+v"(xlo)
+                         : [o0] "v"(off[0]), [l0] "v"(v[0]), [V0] "s"(V[pos[0]]), [F0] "s"(F[0]),
+                           [o1] "v"(off[1]), [l1] "v"(v[1]), [V1] "s"(V[pos[1]]), [F1] "s"(F[1]),
+                           [o2] "v"(off[2]), [l2] "v"(v[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
+                           [o3] "v"(off[3]), [l3] "v"(v[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
+                           [cell] "v"(cell), [one] "v"(one)
+                         : "memory", "vcc", "scc");
+        }
+#undef NTK_EMITWF
+#undef NTK_EMITW
     }
 
     // Side effects of four positions pos[0..3].  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
@@ -644,9 +689,11 @@ struct NoSink {};
 template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12, int W = 0, bool FWD = false>
 __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs a)
 {
-    static_assert(K >= 17 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 17 <= k <= 32");
+    static_assert(K >= 1 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 1 <= k <= 32");
+    static_assert(K >= 17 || (W == 0 && !QM), "word builds (k <= 16): plain reduce only");
     static_assert(W == 0 || Sv2MinFused<K, W>::value, "fused minimizers: see ntk_tile.hpp");
-    constexpr bool LIGHT = Sv2Light<K>::value;
+    constexpr bool WORD = K <= 16;                        // one-word values (lane_tile_sv2w): digests kept left-aligned
+    constexpr bool LIGHT = Sv2Light<K>::value && !WORD;
     constexpr int kCells = 1 << HB;
     // One LDS object, histogram first: the masked regions address the histogram with the cell's byte offset alone, which
     // is only right while the histogram sits at LDS address 0 (checked below; the kernel has no other LDS object).
@@ -677,6 +724,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     DevMasks2<K, HB> mp;
     NoSink sink;
     mp.cell = (uint32_t)(uintptr_t)&s_nfwd[threadIdx.x];   // LDS byte address: the asm blocks address LDS directly
+    mp.rep = lane & (uint32_t)(DevMasks2<K, HB>::kWordCopies - 1);
 
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
@@ -716,7 +764,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #else
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
             mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-            if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
+            if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
+            else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
             else if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
@@ -759,8 +808,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #endif
     // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
-    constexpr int S = 64 - 2 * K;
-    uint64_t sum = mp.sum, xr = ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
+    constexpr int S = WORD ? 0 : 64 - 2 * K;
+    uint64_t sum = mp.sum, xr = WORD ? (uint64_t)mp.xlo : ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
     uint64_t shi = 0, xf = 0;   // LIGHT: high parts of the digests, from the histogram
     uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
 #ifdef NTK_SV2_XOR_LDS
@@ -777,6 +826,10 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     __syncthreads();
     for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
         uint32_t tot = 0;
+        if constexpr (K <= 6) {   // word builds up to 6 bases: cell = copy * 4^K + value, bin = value
+            if (c < (1 << (2 * K)))
+                for (int r = 0; r < DevMasks2<K, HB>::kWordCopies; r++) tot += s_hist[(r << (2 * K)) + c];
+        } else
 #pragma unroll
         for (int q = 0; q < kCells / kHistBins; q++) {
             const uint32_t f = c * (kCells / kHistBins) + q, h = s_hist[f];
@@ -811,6 +864,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
         if constexpr (W > 0 && !TIE_RC) tf = tv - tf;   // the bits counted the reverse-complement choices
         if constexpr (FWD) tf = tv;                     // forward-only builds keep no strand counter
+        if constexpr (WORD && K < 16) { ts >>= 32 - 2 * K; tx >>= 32 - 2 * K; }   // left-aligned digests (exact: < 2^32 words per block)
         ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
     }
 }

@@ -1,4 +1,4 @@
-// ntk_scan2.hip - the instantiations of ntk::scan2_kernel (canonical and forward-only reduce mode for 17 <= k <= 32, the quality-masked
+// ntk_scan2.hip - the instantiations of ntk::scan2_kernel (canonical and forward-only reduce mode for every k <= 32, the quality-masked
 // k = 21 / 31 builds and the fused windowed-minimizer builds) in their own translation unit: the tile loop is one long straight-line
 // block, and the ILP-driven iterative scheduler (-mllvm -amdgpu-sched-strategy=iterative-ilp, see the Makefile) orders it
 // 3.6 % faster than the default one - which in turn crashes the compiler on other kernels of the library, hence the split.
@@ -19,6 +19,8 @@ const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality)
 #define NTK_PICK_SV(KF, T, U)                                                                       \
     if (!quality && k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits>;
 #define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
+    NTK_PICK_SV4(1) NTK_PICK_SV4(2) NTK_PICK_SV4(3) NTK_PICK_SV4(4) NTK_PICK_SV4(5) NTK_PICK_SV4(6) NTK_PICK_SV4(7) NTK_PICK_SV4(8)
+    NTK_PICK_SV4(9) NTK_PICK_SV4(10) NTK_PICK_SV4(11) NTK_PICK_SV4(12) NTK_PICK_SV4(13) NTK_PICK_SV4(14) NTK_PICK_SV4(15) NTK_PICK_SV4(16)
     NTK_PICK_SV4(17) NTK_PICK_SV4(18) NTK_PICK_SV4(19) NTK_PICK_SV4(20) NTK_PICK_SV4(21) NTK_PICK_SV4(22) NTK_PICK_SV4(23) NTK_PICK_SV4(24)
     NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
 #undef NTK_PICK_SV4
@@ -31,11 +33,13 @@ const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality)
     return nullptr;
 }
 
-// Forward-only builds (BitNuclKmer with canonical = false; lane_tile_sv2_fwd), 17 <= k <= 32.
+// Forward-only builds (BitNuclKmer with canonical = false; lane_tile_sv2_fwd, lane_tile_sv2w), every k.
 const void *ntk_pick_scan2_fwd(int k, bool accept_u)
 {
 #define NTK_PICK_FWD(KF, U) if (k == KF && accept_u == U) return (const void *)&scan2_kernel<KF, false, U, false, kScan2HistBits, 0, true>;
 #define NTK_PICK_FWD2(KF) NTK_PICK_FWD(KF, false) NTK_PICK_FWD(KF, true)
+    NTK_PICK_FWD2(1) NTK_PICK_FWD2(2) NTK_PICK_FWD2(3) NTK_PICK_FWD2(4) NTK_PICK_FWD2(5) NTK_PICK_FWD2(6) NTK_PICK_FWD2(7) NTK_PICK_FWD2(8)
+    NTK_PICK_FWD2(9) NTK_PICK_FWD2(10) NTK_PICK_FWD2(11) NTK_PICK_FWD2(12) NTK_PICK_FWD2(13) NTK_PICK_FWD2(14) NTK_PICK_FWD2(15) NTK_PICK_FWD2(16)
     NTK_PICK_FWD2(17) NTK_PICK_FWD2(18) NTK_PICK_FWD2(19) NTK_PICK_FWD2(20) NTK_PICK_FWD2(21) NTK_PICK_FWD2(22) NTK_PICK_FWD2(23) NTK_PICK_FWD2(24)
     NTK_PICK_FWD2(25) NTK_PICK_FWD2(26) NTK_PICK_FWD2(27) NTK_PICK_FWD2(28) NTK_PICK_FWD2(29) NTK_PICK_FWD2(30) NTK_PICK_FWD2(31) NTK_PICK_FWD2(32)
 #undef NTK_PICK_FWD2

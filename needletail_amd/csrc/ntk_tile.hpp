@@ -622,6 +622,41 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
     }
 }
 
+// sv2 for k <= 16 ("word" builds: a value is one 32-bit word).  Values are kept LEFT-ALIGNED (the k-mer in the top 2K bits,
+// zeros below): forward = fw[j] << (32 - 2K), reverse complement = the top 2K bits of rw[j] (one AND); left-aligned words order
+// like the values, their top 14 bits are the histogram cell whatever K is (K < 7: the cell index is the value shifted up), and
+// the digests are accumulated left-aligned and shifted down once per block (sum of < 2^32 words of < 2^32: no overflow).
+// No cross-lane words beyond the two code words (a window never reaches past the previous lane).  FWD: forward-only builds.
+template <bool TIE_RC, int K, bool FWD, class Sink, class XL, class MP>
+NTK_HD void lane_tile_sv2w(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
+{
+    static_assert(K >= 1 && K <= 16, "word builds");
+    constexpr int S = 32 - 2 * K;
+    constexpr uint32_t hmask = K == 16 ? 0xFFFFFFFFu : ~((1u << (S & 31)) - 1u);
+    const uint32_t c1 = xl.prev(kSlotCode, code);
+    uint32_t r1 = 0;
+    if (!FWD) r1 = xl.prev(kSlotRcode, rcode);
+#pragma unroll
+    for (int jp = 0; jp < 8; jp += 2) {
+        const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
+        uint32_t v[4];
+        bool fwd[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = pos[i];
+            const uint32_t fwj = j == 15 ? code : alignbit(c1, code, 30 - 2 * j);
+            const uint32_t f = S ? fwj << S : fwj;
+            if (FWD) { v[i] = f; fwd[i] = true; }
+            else {
+                const uint32_t r = (j == 15 ? rcode : alignbit(rcode, r1, 2 * j + 2)) & hmask;
+                fwd[i] = TIE_RC ? (f < r) : (f <= r);
+                v[i] = f < r ? f : r;
+            }
+        }
+        mp.template emit4w<FWD>(sink, pos, fwd, v);
+    }
+}
+
 // Forward-only sv2 (BitNuclKmer with canonical = false, reference src/bitkmer.rs:80-108 and Sequence::bit_kmers(k, false),
 // src/sequence.rs:250-252): no reverse-complement stream, no strand compare and no strand counter - the T word of position j is
 // fw[j - D], its lo word fw[j]; every k-mer counts as forward (n_fwd = n_total at block end).

@@ -152,6 +152,7 @@ void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostS
 template <int K, int HB>
 struct EmuMP2 {
     static constexpr bool kLight = Sv2Light<K>::value;
+    static constexpr int kWordCopies = K <= 6 ? (((1 << HB) >> (2 * (K <= 6 ? K : 0))) < 64 ? ((1 << HB) >> (2 * (K <= 6 ? K : 0))) : 64) : 1;
     uint64_t V[16];
     int lane = 0;
     uint64_t sum = 0, n_fwd = 0;
@@ -177,6 +178,19 @@ struct EmuMP2 {
         }
     }
     bool fwd_only = false;
+    template <bool FWD_ONLY, class S>
+    void emit4w(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&v)[4])   // word builds (K <= 16): left-aligned values
+    {
+        if (FWD_ONLY) fwd_only = true;
+        for (int i = 0; i < 4; i++) {
+            if (!((V[pos[i]] >> lane) & 1)) continue;
+            const uint32_t rep = (uint32_t)lane & (uint32_t)(kWordCopies - 1);
+            const uint32_t off = K <= 6 ? ((v[i] >> ((30 - 2 * K) & 31)) | (rep << ((2 * K + 2) & 31))) : (HB == 14 ? ((v[i] >> 16) & 0xFFFCu) : ((v[i] >> 18) & 0x3FFCu));
+            cells[off >> 2]++;
+            sum += v[i]; xlo ^= v[i];
+            n_fwd += fwd[i] ? 1 : 0;
+        }
+    }
     template <class S>
     void emit4_fwd(S &s_, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
     {
@@ -200,23 +214,29 @@ struct EmuMP2 {
     }
     void finish(HostStats *st)   // the block-end arithmetic of scan2_kernel
     {
-        constexpr int S = 64 - 2 * K;
-        uint64_t s = sum, xr = ((uint64_t)(S ? xT >> S : xT) << 32) | xlo, shi = 0, xf = 0, nv = 0;
+        constexpr bool WORD = K <= 16, LIGHT = kLight && !WORD;
+        constexpr int S = WORD ? 0 : 64 - 2 * K;
+        uint64_t s = sum, xr = WORD ? (uint64_t)xlo : ((uint64_t)(S ? xT >> S : xT) << 32) | xlo, shi = 0, xf = 0, nv = 0;
         const uint32_t per = (1u << HB) / kHistBins;
         for (uint32_t c = 0; c < (uint32_t)kHistBins; c++) {
             uint32_t tot = 0;
-            for (uint32_t q = 0; q < per; q++) {
-                const uint32_t f = c * per + q, h = cells[f];
-                tot += h;
-                if (kLight) { shi += (uint64_t)(f >> (32 + HB - 2 * K)) * h; xf ^= (h & 1u) ? f : 0u; }
+            if (K <= 6) {
+                if (c < (1u << ((2 * K) & 31))) for (int r = 0; r < kWordCopies; r++) tot += cells[((uint32_t)r << ((2 * K) & 31)) + c];
+            } else {
+                for (uint32_t q = 0; q < per; q++) {
+                    const uint32_t f = c * per + q, h = cells[f];
+                    tot += h;
+                    if (LIGHT) { shi += (uint64_t)(f >> ((32 + HB - 2 * K) & 31)) * h; xf ^= (h & 1u) ? f : 0u; }
+                }
             }
             st->hist[c] += tot; nv += tot;
         }
-        if (kLight) {
+        if (LIGHT) {
             constexpr uint32_t low_mask = 2 * K - HB >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * K - HB) & 31)) - 1u);
             s += shi << 32;
-            xr = (xf << (2 * K - HB)) | (uint64_t)(xlo & low_mask);
+            xr = (xf << ((2 * K - HB) & 63)) | (uint64_t)(xlo & low_mask);
         }
+        if (WORD && K < 16) { s >>= (32 - 2 * K) & 31; xr >>= (32 - 2 * K) & 31; }
         if (min_mode) n_fwd = tie_rc ? nf_bits : nv - nf_bits;
         if (fwd_only) n_fwd = nv;   // the forward-only kernel keeps no strand counter: n_fwd = n_total
         st->n_total += nv; st->n_fwd += n_fwd; st->sum += s; st->xr ^= xr;
@@ -244,13 +264,14 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
                 if (good) G[i] |= 1ull << l;
             }
         }
-        window_masks<(W ? K + W - 1 : K)>(G, mp.V);
+        if constexpr (K >= 17) window_masks<(W ? K + W - 1 : K)>(G, mp.V); else window_masks1<K>(G, mp.V);
         mp.tie_rc = TIE_RC;
         EmuXL xl;
         for (int l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             mp.lane = l;
-            if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en[l].code);
+            if constexpr (K <= 16) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en[l].code, en[l].rcode);
+            else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en[l].code);
             else if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en[l].code, en[l].rcode);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en[l].code, en[l].rcode);
         }
@@ -283,6 +304,7 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     const bool hb14 = (tiles_per_wave & 8) != 0;
     // the forward-only sv2 builds (BitNuclKmer, canonical = false)
     const bool sv2f = (tiles_per_wave & 4) && !canon && !values && k >= 17;
+    const bool sv2w = (tiles_per_wave & 4) && !values && k <= 16;
 #define EMU_SV2(KF, T, U) if (sv2 && k == KF && !!tie_rc == T && !!accept_u == U) { if (hb14) run_sv2<T, U, KF, 14>(buf, n, n_padded, st); else run_sv2<T, U, KF, 12>(buf, n, n_padded, st); } else
 #define EMU_SV24(KF) EMU_SV2(KF, false, false) EMU_SV2(KF, false, true) EMU_SV2(KF, true, false) EMU_SV2(KF, true, true)
     EMU_SV24(17) EMU_SV24(18) EMU_SV24(19) EMU_SV24(20) EMU_SV24(21) EMU_SV24(22) EMU_SV24(23) EMU_SV24(24)
@@ -291,6 +313,12 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
 #define EMU_SV2F2(KF) EMU_SV2F(KF, false) EMU_SV2F(KF, true)
     EMU_SV2F2(17) EMU_SV2F2(18) EMU_SV2F2(19) EMU_SV2F2(20) EMU_SV2F2(21) EMU_SV2F2(22) EMU_SV2F2(23) EMU_SV2F2(24)
     EMU_SV2F2(25) EMU_SV2F2(26) EMU_SV2F2(27) EMU_SV2F2(28) EMU_SV2F2(29) EMU_SV2F2(30) EMU_SV2F2(31) EMU_SV2F2(32)
+    // the word builds (k <= 16) of sv2: canonical (both tie rules) and forward-only
+#define EMU_SV2W(KF, T, U) if (sv2w && canon && k == KF && !!tie_rc == T && !!accept_u == U) { if (hb14) run_sv2<T, U, KF, 14>(buf, n, n_padded, st); else run_sv2<T, U, KF, 12>(buf, n, n_padded, st); } else
+#define EMU_SV2WF(KF, U) if (sv2w && !canon && k == KF && !!accept_u == U) { if (hb14) run_sv2<false, U, KF, 14, 0, true>(buf, n, n_padded, st); else run_sv2<false, U, KF, 12, 0, true>(buf, n, n_padded, st); } else
+#define EMU_SV2W6(KF) EMU_SV2W(KF, false, false) EMU_SV2W(KF, false, true) EMU_SV2W(KF, true, false) EMU_SV2W(KF, true, true) EMU_SV2WF(KF, false) EMU_SV2WF(KF, true)
+    EMU_SV2W6(1) EMU_SV2W6(2) EMU_SV2W6(3) EMU_SV2W6(4) EMU_SV2W6(5) EMU_SV2W6(6) EMU_SV2W6(7) EMU_SV2W6(8)
+    EMU_SV2W6(9) EMU_SV2W6(10) EMU_SV2W6(11) EMU_SV2W6(12) EMU_SV2W6(13) EMU_SV2W6(14) EMU_SV2W6(15) EMU_SV2W6(16)
 #define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
 #define EMU_SV4(KF) EMU_SV(KF, false, false) EMU_SV(KF, false, true) EMU_SV(KF, true, false) EMU_SV(KF, true, true)
     EMU_SV4(1) EMU_SV4(2) EMU_SV4(3) EMU_SV4(4) EMU_SV4(5) EMU_SV4(6) EMU_SV4(7) EMU_SV4(8)

@@ -140,6 +140,27 @@ def test_emu_sv2_forward_only(emu, k):
             assert_stats_equal(emu_scan(emu, buf, k, 0, 0, accept_u, tpw), want, (k, accept_u, tpw))
 
 
+@pytest.mark.parametrize("k", list(range(1, 17)))
+def test_emu_sv2_word_builds(emu, k):
+    """lane_tile_sv2w (k <= 16: one-word values kept left-aligned; canonical with both tie rules, and forward-only): several
+    tiles, breaks at lane and tile edges, palindromic stretches (strand ties for even k), both histogram sizes."""
+    rng = np.random.default_rng(200 + k)
+    alphabet = np.frombuffer(b"ACGT" * 8 + b"acgtNUu\n", dtype=np.uint8)
+    n = int(rng.integers(3000, 7000))
+    a = alphabet[rng.integers(0, len(alphabet), n)].copy()
+    for at in (15, 16, 17, 991, 992, 993, 1007, 1008, 1984, 2 * 992 - k, 3 * 992 + k):
+        a[at] = ord("N")
+    a[1200:1400] = np.resize(np.frombuffer(b"ACGT", dtype=np.uint8), 200)      # ACGT repeats: every even-k window is a palindrome
+    a[1500:1600] = np.resize(np.frombuffer(b"AT", dtype=np.uint8), 100)
+    a[2500:2500 + k - 1] = ord("A"); a[2499] = a[2500 + k - 1] = ord("N")      # k-1 good bases between two breaks: no window
+    a[2600:2600 + k] = ord("C"); a[2599] = a[2600 + k] = ord("N")              # exactly one window
+    buf = a.tobytes()
+    for canon, tie_rc, accept_u in ((1, 1, 1), (1, 0, 0), (1, 0, 1), (1, 1, 0), (0, 0, 0), (0, 0, 1)):
+        want = O.reduce_fused(buf, k, bool(canon), bool(tie_rc), bool(accept_u))
+        for tpw in (4, 12):
+            assert_stats_equal(emu_scan(emu, buf, k, canon, tie_rc, accept_u, tpw), want, (k, canon, tie_rc, accept_u, tpw))
+
+
 def test_emu_materialize_matches_bit_kmers(emu):
     rng = np.random.default_rng(5)
     alphabet = np.frombuffer(b"ACGTACGTACGTacgtN", dtype=np.uint8)
