@@ -414,14 +414,39 @@ def main():
     # ---- the collective --------------------------------------------------------------------------------------------
     comm = None
     rccl = use_dist and args.backend == "nccl" and not args.single_device
+    collective_note = None
     if rccl:
-        ids = [nd.Communicator.unique_id() if rank == 0 else None]
+        # the product path: the library's own communicator (ntk_comm_*, RCCL through the C ABI).  Should it fail to come up on
+        # ANY rank (say a librccl the process cannot load), every rank falls back to torch.distributed's all-reduce of the same
+        # accumulator words - still RCCL, still on the scan stream - and the JSON line says so.
+        err = "NTK_BENCH_FORCE_COLLECTIVE_FALLBACK is set (test hook)" if os.environ.get("NTK_BENCH_FORCE_COLLECTIVE_FALLBACK") else None
+        try:
+            ids = [nd.Communicator.unique_id() if rank == 0 and not err else None]
+        except nt.NtkError as e:
+            ids, err = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
-        comm = nd.Communicator.for_rank(ctx, world, rank, ids[0])
+        if ids[0] is not None:
+            try:
+                comm = nd.Communicator.for_rank(ctx, world, rank, ids[0])
+            except nt.NtkError as e:
+                err = str(e)
+        else:
+            err = err or "rank 0 could not create a communicator id"
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            collective_note = "FALLBACK torch.distributed all_reduce (ntk_comm_* failed: %s)" % next(e for e in errs if e)
 
     def allreduce():
         if comm is not None:
             comm.allreduce_accumulators()          # ncclAllReduce(ncclUint64, ncclSum) on the scan stream + xor rebuild
+        elif rccl:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)   # fallback (see above): int64 sums of the same words, xor rebuilt on read
         elif use_dist:
             t = acc.cpu()                          # test mode (gloo): the same words, summed on the host
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -535,6 +560,7 @@ def main():
                 "parallelism": (f"records sharded over {world} GPUs (round-robin batches of 2^20), one ncclAllReduce(ncclUint64, ncclSum, "
                                 f"{ntl.ACC_WORDS} words) per step through ntk_allreduce_accumulators") if world > 1 else "single GPU",
                 "launch": {"blocks": args.blocks or "auto", "threads": args.threads or "auto"},
+                **({"collective": collective_note} if collective_note else {}),
                 **({"test_mode": f"{args.backend} backend, all ranks on cuda:0 - NOT a measurement"}
                    if (args.single_device or (use_dist and not rccl)) else {}),
             },
