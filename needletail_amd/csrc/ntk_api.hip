@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library is loaded at run time (load_rccl)
 #include <dlfcn.h>
+#include <time.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -700,7 +701,22 @@ int ntk_batch_submit(ntk_ctx *c, ntk_batch *b, const ntk_params *p)
 int ntk_batch_wait(ntk_ctx *c, ntk_batch *b)
 {
     if (!c || !b) return NTK_ERR_BAD_ARG;
-    if (b->in_flight) { HIPCHK(hipEventSynchronize(b->ev_done)); b->in_flight = false; }
+    if (b->in_flight) {
+        // query + sleep rather than hipEventSynchronize: with dozens of parser threads blocked inside the runtime at once, the
+        // submitting thread's enqueue calls slowed down 2 - 3 x (48+ threads: 16 instead of 39 Gbases/s, profiles/r02e/pipeline.txt).
+        // NTK_BATCH_WAIT_POLL_US = 0 restores the blocking wait.
+        static const long poll_us = [] { const char *e = getenv("NTK_BATCH_WAIT_POLL_US"); return e ? atol(e) : 50L; }();
+        if (poll_us > 0) {
+            for (;;) {
+                const hipError_t q = hipEventQuery(b->ev_done);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { g_last_hip = (int)q; return NTK_ERR_HIP; }
+                struct timespec ts = {0, poll_us * 1000L};
+                nanosleep(&ts, nullptr);
+            }
+        } else HIPCHK(hipEventSynchronize(b->ev_done));
+        b->in_flight = false;
+    }
     b->n_bytes = 0; b->n_records = 0; b->h_off[0] = 0; b->has_qual = false;
     return NTK_OK;
 }

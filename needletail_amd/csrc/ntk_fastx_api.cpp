@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <chrono>
 #include <thread>
 
 #include <new>
@@ -197,13 +198,18 @@ struct Shared {
     std::mutex mu;                       // the ctx is not thread-safe: submit / wait / acquire are serialised
     std::atomic<int> rc{NTK_OK};
     std::atomic<uint64_t> nrec{0}, nbases{0};
+    // the input is cut into several pieces per thread, handed out on demand: host threads do not run at one speed (SMT siblings,
+    // the far socket), and with one static range per thread the slowest one set the time (profiles/r02e/pipeline.txt)
+    const uint8_t *data = nullptr;
+    const uint64_t *cut = nullptr;
+    uint32_t n_pieces = 0;
+    std::atomic<uint32_t> next_piece{0};
 };
 
-void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
+void range_worker(Shared *sh)
 {
-    if (n == 0) return;
     ntk_reader *rd = nullptr;
-    int rc = ntk_reader_open_memory(d, n, &rd);
+    int rc = NTK_OK;
     ntk_batch *b[2] = {nullptr, nullptr};
     const uint64_t max_records = sh->batch_bytes / 32 + 16;
     // acquire / release take the ctx's own pool lock; they are not serialised with submit
@@ -211,24 +217,54 @@ void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
     uint64_t nrec = 0, nbases = 0;
     int cur = 0;
     ntk_record rec;
+    static const bool stats = getenv("NTK_PIPE_STATS") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_begin = now();
+    double t_lock = 0, t_submit = 0, t_wait = 0;
+    int n_sub = 0;
+    // Ramp-up: the first fills are cut short (1/8, 1/4, 1/2 of a batch) so that the first copies start after a fraction of a
+    // batch's parse time instead of a whole one; from then on full batches.
+    uint64_t filled = 0, soft = sh->batch_bytes / 8 < (256 << 10) ? (256 << 10) : sh->batch_bytes / 8;
+    auto flush = [&]() -> int {   // submit the batch in the making, continue in the other one (once its last use has completed)
+        const auto t0 = now();
+        int r;
+        {
+            std::lock_guard<std::mutex> g(sh->mu);
+            const auto t1 = now();
+            r = ntk_batch_submit(sh->ctx, b[cur], sh->p);
+            const auto t2 = now();
+            t_lock += secs(t0, t1); t_submit += secs(t1, t2); n_sub++;
+        }
+        if (r != NTK_OK) return r;
+        cur ^= 1;
+        const auto t3 = now();
+        r = ntk_batch_wait(sh->ctx, b[cur]);   // event wait only: no ctx state touched
+        t_wait += secs(t3, now());
+        filled = 0;
+        if (soft < sh->batch_bytes) soft *= 2;
+        return r;
+    };
     while (rc == NTK_OK && sh->rc.load() == NTK_OK) {
+        if (!rd) {   // next piece of the input (a batch in the making carries over: pieces are not flushed)
+            const uint32_t i = sh->next_piece.fetch_add(1);
+            if (i >= sh->n_pieces) break;
+            if (sh->cut[i + 1] <= sh->cut[i]) continue;
+            if ((rc = ntk_reader_open_memory(sh->data + sh->cut[i], sh->cut[i + 1] - sh->cut[i], &rd)) != NTK_OK) break;
+        }
         const int s = ntk_reader_next(rd, &rec);
-        if (s == NTK_EOF) break;
+        if (s == NTK_EOF) { ntk_reader_close(rd); rd = nullptr; continue; }
         if (s != NTK_OK) { rc = s; break; }
         int a = append_record(b[cur], rec, sh->p);
         if (a == NTK_ERR_CAPACITY) {
-            {
-                std::lock_guard<std::mutex> g(sh->mu);
-                rc = ntk_batch_submit(sh->ctx, b[cur], sh->p);
-            }
-            if (rc != NTK_OK) break;
-            cur ^= 1;
-            if ((rc = ntk_batch_wait(sh->ctx, b[cur])) != NTK_OK) break;  // event wait only: no ctx state touched
+            if ((rc = flush()) != NTK_OK) break;
             a = append_record(b[cur], rec, sh->p);
             if (a == NTK_ERR_CAPACITY) a = scan_oversized_record(sh->ctx, &sh->mu, rec, sh->p);
         }
         if (a != NTK_OK) { rc = a; break; }
         nrec++; nbases += rec.num_bases;
+        filled += rec.seq_len + 1;
+        if (filled >= soft && soft < sh->batch_bytes && (rc = flush()) != NTK_OK) break;
     }
     {
         std::lock_guard<std::mutex> g(sh->mu);
@@ -241,6 +277,8 @@ void range_worker(Shared *sh, const uint8_t *d, uint64_t n)
         ntk_batch_release(sh->ctx, b[i]);
     }
     if (rd) ntk_reader_close(rd);
+    if (stats) fprintf(stderr, "worker: total %.1f ms, lock %.1f, submit %.1f (%d), wait %.1f, parse+fill %.1f\n", secs(t_begin, now()) * 1e3, t_lock * 1e3,
+                       t_submit * 1e3, n_sub, t_wait * 1e3, (secs(t_begin, now()) - t_lock - t_submit - t_wait) * 1e3);
     if (rc != NTK_OK) { int ok = NTK_OK; sh->rc.compare_exchange_strong(ok, rc); }
     sh->nrec += nrec; sh->nbases += nbases;
 }
@@ -274,13 +312,19 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
     // a thread is only worth its two pinned batches if it has several batches of input to parse
     const uint64_t worth = n / (4 * batch_bytes) + 1;
     if (n_threads > worth) n_threads = (uint32_t)worth;
-    std::vector<uint64_t> cut(n_threads + 1, n);
-    if (ntk_fastx_split_points(data, n, n_threads, cut.data()) != NTK_OK) return NTK_ERR_PARSE;
+    if (n_threads > 64) n_threads = 64;   // more parser threads than that only queue up on the submit lock (profiles/r02e/pipeline.txt)
+    // pieces of >= 1 MiB, about eight per thread
+    uint64_t want_pieces = (uint64_t)n_threads * 8;
+    if (want_pieces > n / (1 << 20) + 1) want_pieces = n / (1 << 20) + 1;
+    if (want_pieces < n_threads) want_pieces = n_threads;
+    const uint32_t n_pieces = (uint32_t)want_pieces;
+    std::vector<uint64_t> cut(n_pieces + 1, n);
+    if (ntk_fastx_split_points(data, n, n_pieces, cut.data()) != NTK_OK) return NTK_ERR_PARSE;
     Shared sh;
     sh.ctx = ctx; sh.p = p; sh.batch_bytes = batch_bytes;
+    sh.data = data; sh.cut = cut.data(); sh.n_pieces = n_pieces;
     std::vector<std::thread> th;
-    for (uint32_t i = 0; i < n_threads; i++)
-        if (cut[i + 1] > cut[i]) th.emplace_back(range_worker, &sh, data + cut[i], cut[i + 1] - cut[i]);
+    for (uint32_t i = 0; i < n_threads; i++) th.emplace_back(range_worker, &sh);
     for (auto &t : th) t.join();
     if (n_records) *n_records = sh.nrec.load();
     if (n_bases) *n_bases = sh.nbases.load();
