@@ -20,7 +20,8 @@
 using namespace ntk;
 
 // the sv2 builds (ntk_scan2.hip): nullptr when (k, flags) has none
-const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality);
+const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u);
+const void *ntk_pick_scan2_q(int k, bool canonical, bool tie_rc, bool accept_u);
 const void *ntk_pick_scan2_min(int k, int w, bool tie_rc, bool accept_u);
 const void *ntk_pick_scan2_fwd(int k, bool accept_u);
 
@@ -190,25 +191,25 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
-inline bool is_scan2(const Mode &m, uint32_t k, bool reduce, bool qm) { return reduce && (!qm || (m.canon && (k == 21 || k == 31))); }
+inline bool is_scan2(const Mode &, uint32_t, bool reduce, bool) { return reduce; }   // every reduce-mode scan is a scan2 build
 
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
 {
-    // reduce mode, canonical or forward-only, every k (and the quality-masked canonical k = 21 / 31 builds): the sv2 kernel lives
-    // in its own translation unit (ntk_scan2.hip, built with the ILP-driven iterative scheduler)
-    if (REDUCE && m.canon)
-        if (const void *fn = ntk_pick_scan2((int)k, m.tie_rc, m.accept_u, QM)) return fn;
-    if (REDUCE && !QM && !m.canon)
-        if (const void *fn = ntk_pick_scan2_fwd((int)k, m.accept_u)) return fn;
+    // reduce mode: every (path, k, quality) has an sv2 build; the kernel lives in its own translation unit (ntk_scan2.hip, built
+    // with the ILP-driven iterative scheduler).  The round-1 kernel below serves materialise mode only.
+    if constexpr (REDUCE) {
+        if (QM) return ntk_pick_scan2_q((int)k, m.canon, m.tie_rc, m.accept_u);
+        return m.canon ? ntk_pick_scan2((int)k, m.tie_rc, m.accept_u) : ntk_pick_scan2_fwd((int)k, m.accept_u);
+    } else {
 #define NTK_PICK_FIX(KF, T, U)                                                                      \
-    if (!REDUCE && !QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)      \
+    if (!QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)                  \
         return (const void *)&scan_kernel<2, true, T, U, false, KF, false>;
     NTK_PICK_FIX(21, false, false) NTK_PICK_FIX(21, false, true) NTK_PICK_FIX(21, true, false) NTK_PICK_FIX(21, true, true)
 #undef NTK_PICK_FIX
 #define NTK_PICK(KW, C, T, U)                                                                       \
     if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U)                             \
-        return (const void *)&scan_kernel<KW, C, T, U, REDUCE, 0, false, QM>;
+        return (const void *)&scan_kernel<KW, C, T, U, false, 0, false, QM>;
     NTK_PICK(1, false, false, false) NTK_PICK(1, false, false, true)
     NTK_PICK(1, true, false, false) NTK_PICK(1, true, false, true)
     NTK_PICK(1, true, true, false) NTK_PICK(1, true, true, true)
@@ -217,6 +218,7 @@ const void *pick_scan(const Mode &m, uint32_t k)
     NTK_PICK(2, true, true, false) NTK_PICK(2, true, true, true)
 #undef NTK_PICK
     return nullptr;
+    }
 }
 
 // Fused windowed-minimizer builds of the sv2 kernel (ntk_tile.hpp lane_tile_sv2_min): w = 11 for 17 <= k <= 22 (configs[4] is

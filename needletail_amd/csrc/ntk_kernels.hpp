@@ -690,7 +690,7 @@ template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12, int W
 __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs a)
 {
     static_assert(K >= 1 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 1 <= k <= 32");
-    static_assert(K >= 17 || (W == 0 && !QM), "word builds (k <= 16): plain reduce only");
+    static_assert(K >= 17 || W == 0, "word builds (k <= 16): no fused minimizers");
     static_assert(W == 0 || Sv2MinFused<K, W>::value, "fused minimizers: see ntk_tile.hpp");
     constexpr bool WORD = K <= 16;                        // one-word values (lane_tile_sv2w): digests kept left-aligned
     constexpr bool LIGHT = Sv2Light<K>::value && !WORD;

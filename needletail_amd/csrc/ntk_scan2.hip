@@ -1,5 +1,5 @@
 // ntk_scan2.hip - the instantiations of ntk::scan2_kernel (canonical and forward-only reduce mode for every k <= 32, the quality-masked
-// k = 21 / 31 builds and the fused windowed-minimizer builds) in their own translation unit: the tile loop is one long straight-line
+// builds and the fused windowed-minimizer builds) in their own translation unit: the tile loop is one long straight-line
 // block, and the ILP-driven iterative scheduler (-mllvm -amdgpu-sched-strategy=iterative-ilp, see the Makefile) orders it
 // 3.6 % faster than the default one - which in turn crashes the compiler on other kernels of the library, hence the split.
 #include <hip/hip_runtime.h>
@@ -13,11 +13,11 @@ namespace {
 constexpr int kScan2HistBits = 14;   // LDS histogram of the sv2 builds: 64 KiB, two 768-thread blocks per CU
 }
 
-#ifndef NTK_SCAN2_MIN_BUILDS
-const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality)
+#if !defined(NTK_SCAN2_MIN_BUILDS) && !defined(NTK_SCAN2_Q_BUILDS)
+const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u)
 {
 #define NTK_PICK_SV(KF, T, U)                                                                       \
-    if (!quality && k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits>;
+    if (k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits>;
 #define NTK_PICK_SV4(KF) NTK_PICK_SV(KF, false, false) NTK_PICK_SV(KF, false, true) NTK_PICK_SV(KF, true, false) NTK_PICK_SV(KF, true, true)
     NTK_PICK_SV4(1) NTK_PICK_SV4(2) NTK_PICK_SV4(3) NTK_PICK_SV4(4) NTK_PICK_SV4(5) NTK_PICK_SV4(6) NTK_PICK_SV4(7) NTK_PICK_SV4(8)
     NTK_PICK_SV4(9) NTK_PICK_SV4(10) NTK_PICK_SV4(11) NTK_PICK_SV4(12) NTK_PICK_SV4(13) NTK_PICK_SV4(14) NTK_PICK_SV4(15) NTK_PICK_SV4(16)
@@ -25,11 +25,6 @@ const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u, bool quality)
     NTK_PICK_SV4(25) NTK_PICK_SV4(26) NTK_PICK_SV4(27) NTK_PICK_SV4(28) NTK_PICK_SV4(29) NTK_PICK_SV4(30) NTK_PICK_SV4(31) NTK_PICK_SV4(32)
 #undef NTK_PICK_SV4
 #undef NTK_PICK_SV
-#define NTK_PICK_SVQ(KF, T, U)                                                                      \
-    if (quality && k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, true, kScan2HistBits>;
-    NTK_PICK_SVQ(21, false, false) NTK_PICK_SVQ(21, false, true) NTK_PICK_SVQ(21, true, false) NTK_PICK_SVQ(21, true, true)
-    NTK_PICK_SVQ(31, false, false) NTK_PICK_SVQ(31, false, true) NTK_PICK_SVQ(31, true, false) NTK_PICK_SVQ(31, true, true)
-#undef NTK_PICK_SVQ
     return nullptr;
 }
 
@@ -44,6 +39,25 @@ const void *ntk_pick_scan2_fwd(int k, bool accept_u)
     NTK_PICK_FWD2(25) NTK_PICK_FWD2(26) NTK_PICK_FWD2(27) NTK_PICK_FWD2(28) NTK_PICK_FWD2(29) NTK_PICK_FWD2(30) NTK_PICK_FWD2(31) NTK_PICK_FWD2(32)
 #undef NTK_PICK_FWD2
 #undef NTK_PICK_FWD
+    return nullptr;
+}
+
+#elif defined(NTK_SCAN2_Q_BUILDS)
+// (compiled a third time with -DNTK_SCAN2_Q_BUILDS into ntk_scan2_q.o, same scheduler flag: the builds that read a quality stream)
+// Quality-masked builds (QualitySequence::quality_mask, reference src/sequence.rs:285-296, fused into the encode): every k,
+// canonical (both tie rules) and forward-only.
+const void *ntk_pick_scan2_q(int k, bool canonical, bool tie_rc, bool accept_u)
+{
+#define NTK_PICK_Q(KF, T, U) if (canonical && k == KF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, true, kScan2HistBits>;
+#define NTK_PICK_QF(KF, U) if (!canonical && k == KF && accept_u == U) return (const void *)&scan2_kernel<KF, false, U, true, kScan2HistBits, 0, true>;
+#define NTK_PICK_Q6(KF) NTK_PICK_Q(KF, false, false) NTK_PICK_Q(KF, false, true) NTK_PICK_Q(KF, true, false) NTK_PICK_Q(KF, true, true) NTK_PICK_QF(KF, false) NTK_PICK_QF(KF, true)
+    NTK_PICK_Q6(1) NTK_PICK_Q6(2) NTK_PICK_Q6(3) NTK_PICK_Q6(4) NTK_PICK_Q6(5) NTK_PICK_Q6(6) NTK_PICK_Q6(7) NTK_PICK_Q6(8)
+    NTK_PICK_Q6(9) NTK_PICK_Q6(10) NTK_PICK_Q6(11) NTK_PICK_Q6(12) NTK_PICK_Q6(13) NTK_PICK_Q6(14) NTK_PICK_Q6(15) NTK_PICK_Q6(16)
+    NTK_PICK_Q6(17) NTK_PICK_Q6(18) NTK_PICK_Q6(19) NTK_PICK_Q6(20) NTK_PICK_Q6(21) NTK_PICK_Q6(22) NTK_PICK_Q6(23) NTK_PICK_Q6(24)
+    NTK_PICK_Q6(25) NTK_PICK_Q6(26) NTK_PICK_Q6(27) NTK_PICK_Q6(28) NTK_PICK_Q6(29) NTK_PICK_Q6(30) NTK_PICK_Q6(31) NTK_PICK_Q6(32)
+#undef NTK_PICK_Q6
+#undef NTK_PICK_QF
+#undef NTK_PICK_Q
     return nullptr;
 }
 
