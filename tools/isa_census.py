@@ -17,7 +17,7 @@ with tempfile.TemporaryDirectory() as d:
                            "-DNTK_KB_HB=14", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "tools", "kbench.hip")],
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
-name = f"_ZN3ntk12scan2_kernelILi{K}ELb1ELb1ELb0ELi14ELi0EEEvNS_8ScanArgsE"
+name = f"_ZN3ntk12scan2_kernelILi{K}ELb1ELb1ELb0ELi14ELi0ELb0EEEvNS_8ScanArgsE"
 body = text[text.index(name + ":"):]
 body = body[:body.index(".end_amdhsa_kernel")]
 lines = body.splitlines()
