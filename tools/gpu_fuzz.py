@@ -111,6 +111,12 @@ def main():
             t[:n] = torch.from_numpy(a).cuda()
         buf = a.tobytes()
         what = rng.integers(0, 10)
+        # launch geometry: mostly the library's choice, sometimes forced (few / many blocks, small / large blocks: the shard, chunk
+        # and work-counter arithmetic of the scan must not depend on it)
+        if rng.random() < 0.3:
+            ctx.set_launch(int(rng.choice([1, 2, 7, 64, 300, 512, 1024, 2048])), int(rng.choice([0, 64, 128, 256, 512, 768, 1024])))
+        else:
+            ctx.set_launch(0, 0)
         tag = f"it {it} seed {args.seed} k {k} path {path} pre {pre} n {n}"
         if what < 5:
             ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre)
