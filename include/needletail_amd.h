@@ -234,9 +234,9 @@ void ntk_reader_close(ntk_reader *r);
 int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t batch_bytes, uint32_t n_batches,
                     uint64_t *n_records, uint64_t *n_bases);
 
-/* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into n_threads pieces,
- * each parsed by its own thread into its own pinned batches (record order across pieces is not preserved; the reduced
- * result does not depend on it).  A gzip stream is sequential: ntk_scan_buffer_parallel refuses it (NTK_ERR_UNSUPPORTED, use
+/* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into about eight pieces per
+ * thread, handed out on demand to n_threads parser threads (at most 64 are used; 32 reach the PCIe rate), each filling
+ * its own pinned batches (record order is not preserved; the reduced result does not depend on it).  A gzip stream is sequential: ntk_scan_buffer_parallel refuses it (NTK_ERR_UNSUPPORTED, use
  * ntk_scan_reader; the same for bzip2 / xz / zstd); ntk_scan_file_parallel inflates the whole file into memory first (all members) when libdeflate.so.0 can
  * be loaded and the output stays under 16 GiB (NTK_GZ_INMEM_LIMIT_BYTES), and is NTK_ERR_UNSUPPORTED otherwise.
  * Parse errors return NTK_ERR_PARSE without position detail. */
