@@ -469,9 +469,8 @@ def main():
             bad = [k for k in SCALARS if int(got[k]) != int(want_mine[k])]
             raise SystemExit(f"rank {rank}: parity check failed on the whole shard ({my_reads} reads): {bad or 'histogram'}")
 
-    def step():
-        ctx.accum_reset()
-        ctx.reduce_device(seq, n_bytes, args.k, path, pre)
+    def step():   # a new result every step: the accumulators are zeroed by the scan's own launch (NTK_FLAG_RESET), then scan + fold
+        ctx.reduce_device(seq, n_bytes, args.k, path, pre, reset=True)
         allreduce()
 
     # steady-state clocks before anything is timed (a fixed number of steps: every rank issues the same collectives)

@@ -76,9 +76,12 @@ typedef struct ntk_params {
                    /* bits 15:8 = quality cutoff (0 = none): bases whose quality byte is below it  */
                    /* are masked as QualitySequence::quality_mask does (src/sequence.rs:285-296)   */
                    /* on the *_quality entry points and on batches that carry qualities;           */
-                   /* other bits reserved, must be 0                                      */
+                   /* bit 16 = NTK_FLAG_RESET (reduce entry points: zero the accumulators first, as      */
+                   /* ntk_accum_reset would, but inside this call's own kernel launch - a pass that      */
+                   /* starts a new result saves the separate memset); other bits reserved, must be 0     */
 } ntk_params;
 #define NTK_FLAGS(window_w, quality_cutoff) (((uint32_t)(window_w) & 0xFFu) | (((uint32_t)(quality_cutoff) & 0xFFu) << 8))
+#define NTK_FLAG_RESET (1u << 16)
 
 /* Reduced result of a scan.  `value` is the emitted k-mer in the reference's
  * 2-bit encoding (A0 C1 G2 T3, first base most significant; src/bitkmer.rs:5-36). */

@@ -39,11 +39,14 @@ class Params(C.Structure):
     _fields_ = [("k", C.c_uint32), ("path", C.c_uint32), ("pre", C.c_uint32), ("flags", C.c_uint32)]
 
 
-def flags(w: int = 0, quality_cutoff: int = 0) -> int:
-    """ntk_params.flags (NTK_FLAGS): bits 7:0 minimizer window, bits 15:8 quality cutoff."""
+FLAG_RESET = 1 << 16   # NTK_FLAG_RESET: the reduce call zeroes the accumulators first, inside its own kernel launch
+
+
+def flags(w: int = 0, quality_cutoff: int = 0, reset: bool = False) -> int:
+    """ntk_params.flags (NTK_FLAGS): bits 7:0 minimizer window, bits 15:8 quality cutoff, bit 16 NTK_FLAG_RESET."""
     if not (0 <= w <= 255 and 0 <= quality_cutoff <= 255):
         raise ValueError("w and quality_cutoff must be 0..255")
-    return w | (quality_cutoff << 8)
+    return w | (quality_cutoff << 8) | (FLAG_RESET if reset else 0)
 
 
 class Result(C.Structure):

@@ -168,7 +168,7 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 {
     if (!p) return NTK_ERR_BAD_ARG;
     if (p->k < 1 || p->k > 32) return NTK_ERR_BAD_K;
-    if ((p->flags & ~0xFFFFu) != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
+    if ((p->flags & ~(0xFFFFu | NTK_FLAG_RESET)) != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
     m->kw = p->k > 16 ? 2 : 1;
     m->accept_u = p->pre >= NTK_PRE_NORMALIZE;
     switch (p->path) {
@@ -240,7 +240,11 @@ int get_event(ntk_ctx *c, hipEvent_t *e)
 int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
              uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16, const uint8_t *d_qual = nullptr, const void *fused_min_fn = nullptr)
 {
-    if (n == 0) return NTK_OK;
+    bool zero_first = reduce && (p->flags & NTK_FLAG_RESET);   // the first launch zeroes the accumulators in its prologue
+    if (n == 0) {
+        if (zero_first) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+        return NTK_OK;
+    }
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
@@ -294,6 +298,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         a.tiles_per_shard = (uint32_t)((tiles + a.n_shards - 1) / a.n_shards);
         a.chunk_tiles = (uint32_t)chunk;
         a.work_counters = c->d_work;
+        a.zero_acc = zero_first ? c->d_acc : nullptr; a.zero_words = NTK_ACC_WORDS;
+        zero_first = false;
         // the work counters are zero on entry: the fold kernel of the previous reduce scan re-armed them; anything else
         // (first use, a materialise scan, an error on the way) leaves work_dirty set and costs a memset here
         if (c->work_dirty) HIPCHK(hipMemsetAsync(c->d_work, 0, kMaxShards * 64, c->stream));
@@ -695,6 +701,7 @@ int ntk_batch_submit(ntk_ctx *c, ntk_batch *b, const ntk_params *p)
                                : run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr, d_qual);
         if (rc) return rc;
     }
+    else if (p->flags & NTK_FLAG_RESET) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
     HIPCHK(hipEventRecord(b->ev_done, c->stream));
     b->in_flight = true;
     return NTK_OK;
@@ -990,11 +997,12 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     int rc = resolve_mode(p, true, &m);
     if (rc) return rc;
     if (!m.canon) return NTK_ERR_BAD_ARG;
-    if (n == 0) return NTK_OK;
     HIPCHK(hipSetDevice(c->device));
     // fused build (one pass, nothing written to HBM) where one exists and no quality stream is involved
-    if (!(d_qual && quality_cutoff(p)) && !getenv("NTK_MINIMIZERS_TWO_PASS"))
+    if (n && !(d_qual && quality_cutoff(p)) && !getenv("NTK_MINIMIZERS_TWO_PASS"))
         if (const void *fn = pick_scan_min(m, p->k, w)) return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, nullptr, fn);
+    if (p->flags & NTK_FLAG_RESET) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    if (n == 0) return NTK_OK;
     // Long inputs are scanned in chunks so that the scratch planes stay bounded (8 B per position: 2 GiB for the default
     // 256 MiB chunk instead of 80 GB for a 10 GB batch).  A chunk is scanned together with the w+k-2 bytes of left context
     // before it (start rounded down to the 16-byte alignment of the scan); only windows ENDING inside the chunk are counted.

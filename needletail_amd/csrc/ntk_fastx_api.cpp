@@ -124,6 +124,9 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *h, const ntk_params *p, uint64_t b
     if (!ctx || !h || !p || batch_bytes < 1024 || n_batches < 2 || n_batches > 64) return NTK_ERR_BAD_ARG;
     std::vector<ntk_batch *> batches(n_batches, nullptr);
     int rc = NTK_OK;
+    ntk_params p_local = *p;   // NTK_FLAG_RESET means "this whole scan starts a new result": once, here, not per batch
+    if (p_local.flags & NTK_FLAG_RESET) { if ((rc = ntk_accum_reset(ctx)) != NTK_OK) return rc; p_local.flags &= ~NTK_FLAG_RESET; }
+    p = &p_local;
     const uint64_t max_records = batch_bytes / 32 + 16;  // offsets are bookkeeping only
     for (auto &b : batches)
         if ((rc = ntk_batch_acquire(ctx, batch_bytes, max_records, &b)) != NTK_OK) break;
@@ -309,6 +312,9 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
     // compressed streams (gzip, bzip2, xz, zstd) are sequential: use ntk_scan_reader
     if ((data[0] == 0x1F && data[1] == 0x8B) || (data[0] == 0x42 && data[1] == 0x5A) || (data[0] == 0xFD && data[1] == 0x37) ||
         (data[0] == 0x28 && data[1] == 0xB5)) return NTK_ERR_UNSUPPORTED;
+    ntk_params p_local = *p;   // NTK_FLAG_RESET: once for the whole scan, not per batch
+    if (p_local.flags & NTK_FLAG_RESET) { const int r = ntk_accum_reset(ctx); if (r != NTK_OK) return r; p_local.flags &= ~NTK_FLAG_RESET; }
+    p = &p_local;
     // a thread is only worth its two pinned batches if it has several batches of input to parse
     const uint64_t worth = n / (4 * batch_bytes) + 1;
     if (n_threads > worth) n_threads = (uint32_t)worth;

@@ -707,6 +707,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
     uint32_t dbg_tiles = 0;
 #endif
+    if (a.zero_acc && blockIdx.x == 0)   // NTK_FLAG_RESET: the accumulators start from zero (see ScanArgs)
+        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
     for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
     s_nfwd[threadIdx.x] = 0;
     __syncthreads();

@@ -42,6 +42,10 @@ struct ScanArgs {
     // quality masking (QM builds): one quality byte per sequence byte, same alignment and padding rules as seq
     const uint8_t *qual;
     uint32_t q_add, q_sel;  // quality_cut(cutoff)
+    // reduce scans started with NTK_FLAG_RESET: block 0 zeroes these words (the ctx accumulators) before anything else; the fold
+    // kernel that adds this scan's partials into them runs after the scan in stream order
+    uint64_t *zero_acc;
+    uint32_t zero_words;
 };
 
 // Fills the k-derived fields (host side).  k must be 1..32.

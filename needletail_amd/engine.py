@@ -71,10 +71,11 @@ class Context:
         L.check(L.lib().ntk_accum_reset(self._h), "ntk_accum_reset")
 
     def reduce_device(self, d_seq, n_bytes: int, k: int, path: int, pre: int, w: int = 0, d_qual=None,
-                      quality_cutoff: int = 0):
+                      quality_cutoff: int = 0, reset: bool = False):
         """w > 0: fold windowed minimizers (w k-mers per window) instead of every k-mer.  d_qual + quality_cutoff: mask
-        bases whose quality byte is below the cutoff first (QualitySequence::quality_mask, reference src/sequence.rs:285-296)."""
-        p = L.Params(k, path, pre, L.flags(w, quality_cutoff))
+        bases whose quality byte is below the cutoff first (QualitySequence::quality_mask, reference src/sequence.rs:285-296).
+        reset: start a new result (NTK_FLAG_RESET: accum_reset() folded into this call's kernel launch)."""
+        p = L.Params(k, path, pre, L.flags(w, quality_cutoff, reset))
         if d_qual is None:
             L.check(L.lib().ntk_reduce_device(self._h, C.c_void_p(_ptr(d_seq)), n_bytes, C.byref(p)), "ntk_reduce_device")
         else:
@@ -157,8 +158,8 @@ class Batch:
         o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(int(nr.value) + 1,))
         return s, o
 
-    def submit(self, k: int, path: int, pre: int, w: int = 0, quality_cutoff: int = 0):
-        p = L.Params(k, path, pre, L.flags(w, quality_cutoff))
+    def submit(self, k: int, path: int, pre: int, w: int = 0, quality_cutoff: int = 0, reset: bool = False):
+        p = L.Params(k, path, pre, L.flags(w, quality_cutoff, reset))
         L.check(L.lib().ntk_batch_submit(self.ctx._h, self._h, C.byref(p)), "ntk_batch_submit")
 
     def wait(self):

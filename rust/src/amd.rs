@@ -19,6 +19,8 @@ pub const NTK_PRE_STRIP_RETURNS: u32 = 1;
 pub const NTK_PRE_NORMALIZE: u32 = 2;
 pub const NTK_PRE_NORMALIZE_IUPAC: u32 = 3;
 pub const NTK_HIST_BINS: usize = 4096;
+/// ntk_params.flags bit 16: the reduce call zeroes the accumulators first, inside its own kernel launch.
+pub const NTK_FLAG_RESET: u32 = 1 << 16;
 pub const NTK_COMM_ID_BYTES: usize = 128;
 
 #[repr(C)] #[derive(Clone, Copy)]

@@ -1014,3 +1014,47 @@ def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatc
     ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); two = ctx.accum_read()
     assert_stats_equal(fused, two, "2 M reads")
     assert fused["n_total"] > 0
+
+
+def test_reset_flag_starts_a_new_result(ctx, monkeypatch):
+    """NTK_FLAG_RESET (ntk_params.flags bit 16): the reduce call zeroes the accumulators inside its own launch - same result as
+    ntk_accum_reset + the call, on every route that takes it (plain, quality-masked, fused and two-pass minimizers, empty input,
+    several launches, a pinned batch, a whole-reader scan)."""
+    a = O.synth_reads(0x5EED0011, 0, 3000, 150, 4).tobytes()
+    b = O.synth_reads(0x5EED0012, 5, 2000, 150, 2).tobytes()
+    ta, tb = to_dev(a), to_dev(b)
+    path, pre = nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE
+    for k in (4, 16, 21, 31):
+        ctx.accum_reset(); ctx.reduce_device(ta, len(a), k, path, pre)          # leave something in the accumulators
+        ctx.reduce_device(tb, len(b), k, path, pre, reset=True)
+        assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, k, True, True, True), ("reset", k))
+        ctx.reduce_device(ta, len(a), k, path, pre)                             # and without the flag it accumulates
+        both = ctx.accum_read()
+        assert both["n_total"] == O.reduce_fused(a, k, True, True, True)["n_total"] + O.reduce_fused(b, k, True, True, True)["n_total"]
+    # forward-only bit path
+    ctx.reduce_device(tb, len(b), 21, nt.PATH_BITS, nt.PRE_NONE, reset=True)
+    assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, 21, False, False, False), "reset fwd")
+    # quality-masked
+    q = np.full(len(b), 73, dtype=np.uint8); q[::5] = 34
+    tq = _qual_dev(q.tobytes())
+    ctx.reduce_device(tb, len(b), 21, path, pre, d_qual=tq, quality_cutoff=40, reset=True)
+    assert_stats_equal(ctx.accum_read(), O.reduce_fused(O.quality_mask(b, q.tobytes(), 40), 21, True, True, True), "reset quality")
+    # minimizers: fused build, then the two-pass path
+    want = O.minimizers_reduce(b, 21, 11, True, True)
+    ctx.reduce_device(tb, len(b), 21, path, pre, w=11, reset=True)
+    assert_stats_equal(ctx.accum_read(), want, "reset fused minimizers")
+    want2 = O.minimizers_reduce(b, 21, 33, True, True)
+    ctx.reduce_device(tb, len(b), 21, path, pre, w=33, reset=True)
+    assert_stats_equal(ctx.accum_read(), want2, "reset two-pass minimizers")
+    # empty input: only the reset happens
+    ctx.reduce_device(tb, 0, 21, path, pre, reset=True)
+    z = ctx.accum_read()
+    assert z["n_total"] == 0 and z["sum"] == 0 and z["xor"] == 0 and int(np.asarray(z["hist"]).sum()) == 0
+    # a pinned batch
+    ctx.reduce_device(ta, len(a), 21, path, pre)
+    bt = ctx.batch(1 << 20, 1 << 14)
+    recs = b.split(b"\n")[:-1]
+    for r in recs:
+        assert bt.append(r, pre)
+    bt.submit(21, path, pre, reset=True); bt.wait(); bt.release()
+    assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, 21, True, True, True), "reset batch")
