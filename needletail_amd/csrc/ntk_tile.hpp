@@ -585,7 +585,12 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
     // min-ed, so they are fetched once (DPP move).  Its reverse-complement words are only ever the lo candidate of one
     // position: they are fetched inside that position's select (select_prev: v_cndmask_b32_dpp on the device).
 #pragma unroll
-    for (int g = 2; g <= D; g++) fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+    for (int g = 2; g <= D; g++) {
+#ifdef NTK_ABL_HALFIMPORTS   // what-if (WRONG results): every other cross-lane move dropped - what 32 bytes per lane could save at most
+        if (g & 1) { fw[D - g] = fw[D + 16 - g]; continue; }
+#endif
+        fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+    }
     // Positions are taken in groups {jp, jp+1, jp+8, jp+9}: the T words of positions j and j+8 sit in ONE register on
     // either strand - fw[j-D] = (top half of T_fwd(j) : top half of T_fwd(j+8)), rw[j+8] = (top half of T_rc(j+8) : top half
     // of T_rc(j)) - so in the LIGHT build one packed 16-bit min with crossed halves yields both histogram prefixes.
@@ -601,6 +606,9 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
             fwd[i] = TIE_RC ? (ft < rt) : (ft <= rt);
             if (j - D >= -1) lo[i] = fwd[i] ? fw[D + j] : rw[j];  // rw[(j - D) + D]: own word, or r1
 #ifndef NTK_SV2_SELPREV   // (fusing the cross-lane move into the select - select_prev - measured slower: profiles/r02b)
+#ifdef NTK_ABL_HALFIMPORTS
+            else if (j & 1) lo[i] = fwd[i] ? fw[D + j] : rw[16 + j];
+#endif
             else { const uint32_t pw = xl.prev(kSlotRw + 16 + j - D, rw[16 + j]); lo[i] = fwd[i] ? fw[D + j] : pw; }
 #else
             else lo[i] = xl.select_prev(kSlotRw + 16 + j - D, fwd[i], fw[D + j], rw[16 + j]);   // previous lane's word 16 + (j - D)
