@@ -53,6 +53,9 @@ const char *ntk_strerror(int status);
 int ntk_last_hip_error(void);
 int ntk_last_rccl_error(void);   /* ncclResult_t of the last failed RCCL call on this thread; -1 = librccl not loadable */
 int ntk_abi_version(void);
+/* Usable gfx950 devices (0 and NTK_OK when there is none: a count, not an error); ntk_ctx_create accepts 0 .. n-1.
+ * Multi-GPU callers size ntk_comm_init_all / their rank-per-GPU launch with it. */
+int ntk_device_count(int *n);
 
 /* ---- parameters (mirror the arguments of the reference's trait methods) --------------------- */
 enum { /* which iterator: reference src/sequence.rs:237-252 */
@@ -116,7 +119,7 @@ int ntk_ctx_create_on_stream(int device, void *hip_stream, ntk_ctx **out);
 void ntk_ctx_destroy(ntk_ctx *ctx);
 int ntk_ctx_synchronize(ntk_ctx *ctx);
 /* Launch geometry of the scan kernel: blocks (0 = auto: the resident grid) x threads per block (a multiple of 64 up to
- * 1024; 0 = auto: 768 for the canonical 17 <= k <= 32 reduce builds, 512 otherwise). */
+ * 1024; 0 = auto: 768 for every reduce-mode scan; materialise mode always runs 256-thread blocks). */
 int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
 /* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */
@@ -197,6 +200,8 @@ int ntk_batch_append_quality(ntk_batch *b, const uint8_t *seq, const uint8_t *qu
                              uint32_t cutoff);
 int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t *n_bytes, uint64_t *n_records);
 int ntk_batch_submit(ntk_ctx *ctx, ntk_batch *b, const ntk_params *p);  /* async: H2D + reduce */
+/* Waits by polling the batch's event every NTK_BATCH_WAIT_POLL_US microseconds (environment, read once per process;
+ * default 50, clamped to 10 s; 0 = block in hipEventSynchronize; not a number = default). */
 int ntk_batch_wait(ntk_ctx *ctx, ntk_batch *b);
 void ntk_batch_release(ntk_ctx *ctx, ntk_batch *b);
 

@@ -19,7 +19,7 @@ ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 
 # every symbol include/needletail_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
-    "ntk_strerror", "ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version",
+    "ntk_strerror", "ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version", "ntk_device_count",
     "ntk_comm_init_all", "ntk_comm_unique_id", "ntk_comm_init_rank", "ntk_comm_size", "ntk_allreduce_accumulators", "ntk_comm_destroy",
     "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
     "ntk_ctx_set_launch", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
     L.ntk_last_hip_error.restype = i32
     L.ntk_abi_version.restype = i32
     L.ntk_last_rccl_error.restype = i32
+    L.ntk_device_count.argtypes = [C.POINTER(i32)]
     L.ntk_comm_init_all.argtypes = [C.POINTER(C.c_void_p), i32, pp]
     L.ntk_comm_unique_id.argtypes = [C.c_char_p]
     L.ntk_comm_init_rank.argtypes = [vp, i32, i32, C.c_char_p, pp]
@@ -156,6 +157,13 @@ def strerror(status: int) -> str:
 
 def last_hip_error() -> int:
     return lib().ntk_last_hip_error()
+
+
+def device_count() -> int:
+    """Usable gfx950 devices (ntk_device_count); 0 without a GPU."""
+    n = C.c_int(0)
+    check(lib().ntk_device_count(C.byref(n)), "ntk_device_count")
+    return n.value
 
 
 def check(status: int, what: str) -> None:

@@ -108,7 +108,7 @@ struct ntk_ctx {
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
-    Scratch scratch[6];
+    Scratch scratch[7];   // [6]: dense outputs of the batched compat face
     void *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned staging of the batched compat face
     void *h_pinned = nullptr;  // small pinned staging for scalar read-backs
     bool timing = false;
@@ -191,7 +191,6 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
 // build (-5 %; for larger k the generic build is as fast).
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
-inline bool is_scan2(const Mode &, uint32_t, bool reduce, bool) { return reduce; }   // every reduce-mode scan is a scan2 build
 
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
@@ -248,8 +247,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
-    const bool sv2 = fused_min_fn || is_scan2(m, p->k, reduce, cutoff != 0);
-    const int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : (sv2 ? 768 : 512));
+    // every reduce-mode scan (any path, any k, with or without a quality stream, fused minimizers) is a scan2 build: 768 threads
+    const int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : 768);
     const int waves_per_block = threads / 64;
     const void *fn = fused_min_fn ? fused_min_fn
                    : cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
@@ -416,6 +415,21 @@ int ntk_last_hip_error(void) { return g_last_hip; }
 int ntk_last_rccl_error(void) { return g_last_rccl; }
 int ntk_abi_version(void) { return NTK_ABI_VERSION; }
 
+int ntk_device_count(int *n)
+{
+    if (!n) return NTK_ERR_BAD_ARG;
+    *n = 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return NTK_OK; }
+    for (int d = 0; d < count; d++) {   // devices are usable as a prefix 0 .. n-1: stop at the first that is not gfx950
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) break;
+        *n = d + 1;
+    }
+    return NTK_OK;
+}
+
 int ntk_ctx_create(int device, ntk_ctx **out) { return create_ctx(device, nullptr, false, out); }
 int ntk_ctx_create_on_stream(int device, void *hip_stream, ntk_ctx **out) { return create_ctx(device, hip_stream, true, out); }
 
@@ -445,6 +459,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
 int ntk_ctx_synchronize(ntk_ctx *c)
 {
     if (!c) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));   // (a process may drive several devices: every entry point selects its ctx's own)
     HIPCHK(hipStreamSynchronize(c->copy_stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return NTK_OK;
@@ -467,6 +482,7 @@ int ntk_ctx_enable_timing(ntk_ctx *c, int on)
 int ntk_ctx_scan_time_ms(ntk_ctx *c, double *total_ms, uint64_t *launches)
 {
     if (!c || !total_ms) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     double t = 0;
     for (auto &p : c->ev_used) {
@@ -484,6 +500,7 @@ int ntk_ctx_scan_time_ms(ntk_ctx *c, double *total_ms, uint64_t *launches)
 int ntk_accum_reset(ntk_ctx *c)
 {
     if (!c) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
     return NTK_OK;
 }
@@ -510,6 +527,7 @@ int ntk_accum_read(ntk_ctx *c, ntk_result *out)
 {
     if (!c || !out) return NTK_ERR_BAD_ARG;
     uint64_t *h = (uint64_t *)c->h_pinned;
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(h, c->d_acc, NTK_ACC_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     out->n_total = h[NTK_ACC_N_TOTAL]; out->n_fwd = h[NTK_ACC_N_FWD]; out->n_rc = h[NTK_ACC_N_RC];
@@ -714,13 +732,21 @@ int ntk_batch_wait(ntk_ctx *c, ntk_batch *b)
         // query + sleep rather than hipEventSynchronize: with dozens of parser threads blocked inside the runtime at once, the
         // submitting thread's enqueue calls slowed down 2 - 3 x (48+ threads: 16 instead of 39 Gbases/s, profiles/r02e/pipeline.txt).
         // NTK_BATCH_WAIT_POLL_US = 0 restores the blocking wait.
-        static const long poll_us = [] { const char *e = getenv("NTK_BATCH_WAIT_POLL_US"); return e ? atol(e) : 50L; }();
+        // The variable is read once per process; a value that is not a number keeps the default 50, values are clamped to 10 s.
+        static const long poll_us = [] {
+            const char *e = getenv("NTK_BATCH_WAIT_POLL_US");
+            if (!e) return 50L;
+            char *end = nullptr;
+            const long v = strtol(e, &end, 10);
+            if (end == e) return 50L;
+            return v < 0 ? 0L : (v > 10000000L ? 10000000L : v);
+        }();
         if (poll_us > 0) {
             for (;;) {
                 const hipError_t q = hipEventQuery(b->ev_done);
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) { g_last_hip = (int)q; return NTK_ERR_HIP; }
-                struct timespec ts = {0, poll_us * 1000L};
+                struct timespec ts = {poll_us / 1000000L, (poll_us % 1000000L) * 1000L};   // tv_nsec stays below 1e9
                 nanosleep(&ts, nullptr);
             }
         } else HIPCHK(hipEventSynchronize(b->ev_done));
@@ -888,26 +914,25 @@ int compact_items(ntk_ctx *c, const uint16_t *d_v16, const uint16_t *d_r16, cons
     int rc;
     // one scratch slot holds: block_items u32[nblocks] | block_off u64[nblocks] | total u64 | counts u64[n_records]
     const size_t o_off = ((size_t)nblocks * 4 + 7) & ~(size_t)7, o_total = o_off + (size_t)nblocks * 8, o_counts = o_total + 8;
-    if ((rc = ensure_scratch(c, 4, o_counts + (size_t)n_records * 8))) return rc;
+    auto fail = [c](int status) { (void)hipStreamSynchronize(c->stream); return status; };   // (the upload may still be in flight)
+    if ((rc = ensure_scratch(c, 4, o_counts + (size_t)n_records * 8))) return fail(rc);
     uint8_t *base = (uint8_t *)c->scratch[4].p;
     uint32_t *d_items = (uint32_t *)base;
     uint64_t *d_off = (uint64_t *)(base + o_off), *d_total = (uint64_t *)(base + o_total), *d_counts = (uint64_t *)(base + o_counts);
     hipLaunchKernelGGL(cp_count_kernel, dim3((unsigned)nblocks), dim3(kCpThreads), 0, c->stream, d_v16, n_words, d_items);
     hipLaunchKernelGGL(cp_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_items, d_off, nblocks, d_total);
-    HIPCHK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { g_last_hip = (int)hipGetLastError(); return fail(NTK_ERR_HIP); }
     uint64_t *h = (uint64_t *)c->h_pinned;
-    HIPCHK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    if (hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); return fail(NTK_ERR_HIP); }
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint64_t m = h[0];
     *total = m;
     const uint64_t take = m < cap ? m : cap;
-    // dense outputs on the device: scratch[1] is free again for the byte path (flags8) but holds the values for the bit
-    // path, so the outputs get their own slots: pos -> scratch[2] / [3] hold the planes; use one fresh allocation per call
+    // dense outputs on the device: a growable slot of the ctx (no hipMalloc / hipFree per call: both synchronise the device)
     uint64_t *d_pos = nullptr, *d_val = nullptr; uint8_t *d_flag = nullptr;
-    void *d_out = nullptr;
     const size_t out_bytes = (size_t)take * (8 + (d_values ? 8 : 0) + 1) + 64;
-    HIPCHK(hipMalloc(&d_out, out_bytes));
-    d_pos = (uint64_t *)d_out;
+    if ((rc = ensure_scratch(c, 6, out_bytes))) return rc;   // (the stream is idle here: synchronised above)
+    d_pos = (uint64_t *)c->scratch[6].p;
     d_val = d_values ? d_pos + take : nullptr;
     d_flag = (uint8_t *)(d_pos + take + (d_values ? take : 0));
     int status = NTK_OK;
@@ -923,8 +948,10 @@ int compact_items(ntk_ctx *c, const uint16_t *d_v16, const uint16_t *d_r16, cons
         if (take && flag_out && hipMemcpyAsync(flag_out, d_flag, (size_t)take, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
         if (hipStreamSynchronize(c->stream) != hipSuccess) status = NTK_ERR_HIP;
     } while (0);
-    if (status == NTK_ERR_HIP) g_last_hip = (int)hipGetLastError();
-    (void)hipFree(d_out);
+    if (status == NTK_ERR_HIP) {
+        g_last_hip = (int)hipGetLastError();
+        (void)hipStreamSynchronize(c->stream);   // nothing of this call may still be reading the pinned staging or writing the caller's arrays
+    }
     if (status != NTK_OK) return status;
     return m > cap ? NTK_ERR_CAPACITY : NTK_OK;
 }
@@ -944,14 +971,17 @@ int ntk_bit_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets,
     int rc = resolve_mode(&p, true, &m);
     if (rc) return rc;
     uint64_t n = 0;
-    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return rc;
+    // from here on the pinned staging buffer is the source of an asynchronous copy: an early return waits for the stream, so
+    // that the next call cannot overwrite the buffer under a copy that is still in flight
+    auto fail = [c](int status) { (void)hipStreamSynchronize(c->stream); return status; };
+    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return fail(rc);
     const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 1, nt * 8))) return rc;
-    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return rc;
-    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return rc;
+    if ((rc = ensure_scratch(c, 1, nt * 8))) return fail(rc);
+    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return fail(rc);
+    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return fail(rc);
     uint64_t *d_val = (uint64_t *)c->scratch[1].p;
     uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
-    if ((rc = run_scan(c, (const uint8_t *)c->scratch[0].p, n, &p, m, false, d_val, d_v16, d_r16))) return rc;
+    if ((rc = run_scan(c, (const uint8_t *)c->scratch[0].p, n, &p, m, false, d_val, d_v16, d_r16))) return fail(rc);
     return compact_items(c, d_v16, d_r16, d_val, n, n_records, k - 1, counts, pos_out, val_out, was_rc_out, cap, total);
 }
 
@@ -966,18 +996,19 @@ int ntk_canonical_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *of
     HIPCHK(hipSetDevice(c->device));
     int rc;
     uint64_t n = 0;
-    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return rc;
+    auto fail = [c](int status) { (void)hipStreamSynchronize(c->stream); return status; };   // (see ntk_bit_kmers_batch)
+    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return fail(rc);
     const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 1, nt))) return rc;
-    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return rc;
-    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return rc;
+    if ((rc = ensure_scratch(c, 1, nt))) return fail(rc);
+    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return fail(rc);
+    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return fail(rc);
     uint8_t *d_flags = (uint8_t *)c->scratch[1].p;
     uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
     // raw-byte comparison exactly as the reference (src/kmer.rs:84-129): any k <= 255, mixed case compares as bytes
     hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
                        (const uint8_t *)c->scratch[0].p, n, k, (const uint16_t *)(c->d_lut + 768), d_flags);
     hipLaunchKernelGGL(pack_flags8_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, c->stream, (const uint8_t *)d_flags, n, d_v16, d_r16);
-    HIPCHK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { g_last_hip = (int)hipGetLastError(); return fail(NTK_ERR_HIP); }
     return compact_items(c, d_v16, d_r16, nullptr, n, n_records, 0, counts, pos_out, nullptr, is_rc_out, cap, total);
 }
 

@@ -329,6 +329,11 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
     Shared sh;
     sh.ctx = ctx; sh.p = p; sh.batch_bytes = batch_bytes;
     sh.data = data; sh.cut = cut.data(); sh.n_pieces = n_pieces;
+    // one worker per non-empty piece at most (on small or odd inputs many cuts collapse onto the end of the buffer, and a
+    // worker without a piece would still acquire its two pinned batches)
+    uint32_t live_pieces = 0;
+    for (uint32_t i = 0; i < n_pieces; i++) live_pieces += cut[i + 1] > cut[i];
+    if (n_threads > live_pieces) n_threads = live_pieces ? live_pieces : 1;
     std::vector<std::thread> th;
     for (uint32_t i = 0; i < n_threads; i++) th.emplace_back(range_worker, &sh);
     for (auto &t : th) t.join();

@@ -26,7 +26,10 @@ class NeedletailError(Exception):
         super().__init__(f"{msg} ({self.kind} at {where})")
 
 
-_WS = re.compile(r"\s")   # Python's \s on str == Rust's char::is_whitespace for the characters a header can hold
+# Rust's char::is_whitespace (the Unicode White_Space property; reference src/python.rs:148-163 splits and trims on it).
+# NOT Python's \s / str.strip(): those also treat U+001C..U+001F as whitespace, which Rust does not.
+_WS_CHARS = "\t\n\x0b\x0c\r \x85\xa0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u2028\u2029\u202f\u205f\u3000"
+_WS = re.compile("[" + _WS_CHARS + "]")
 
 
 class Record:
@@ -68,7 +71,7 @@ class Record:
     @property
     def description(self) -> Optional[str]:
         m = _WS.search(self.id)
-        return self.id[m.start():].lstrip() if m else None
+        return self.id[m.start():].lstrip(_WS_CHARS) if m else None
 
     def is_fasta(self) -> bool:
         return self.qual is None

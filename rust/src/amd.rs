@@ -2,7 +2,7 @@
 //! `cfg(feature = "amd")` build of needletail would use.
 //!
 //! NOT COMPILED IN THIS REPOSITORY: the build image has no rustc / cargo.  The declarations below
-//! are generated from the header (tests/test_abi.py checks names and arity against it); the adapters follow the reference's
+//! are generated from the header by tools/gen_rust_ffi.py (tests/test_abi.py diffs the block against the generator: types and constness); the adapters follow the reference's
 //! own types: `Sequence::canonical_kmers` / `bit_kmers` (src/sequence.rs:237-252), `CanonicalKmers::next`
 //! (src/kmer.rs:84-129), `BitNuclKmer::next` (src/bitkmer.rs:80-109), `FastxReader::next` (src/parser/utils.rs:119-130).
 #![allow(non_camel_case_types, dead_code)]
@@ -44,6 +44,7 @@ extern "C" {
     pub fn ntk_last_hip_error() -> c_int;
     pub fn ntk_last_rccl_error() -> c_int;
     pub fn ntk_abi_version() -> c_int;
+    pub fn ntk_device_count(n: *mut c_int) -> c_int;
     pub fn ntk_ctx_create(device: c_int, out: *mut *mut NtkCtx) -> c_int;
     pub fn ntk_ctx_create_on_stream(device: c_int, hip_stream: *mut c_void, out: *mut *mut NtkCtx) -> c_int;
     pub fn ntk_ctx_destroy(ctx: *mut NtkCtx);

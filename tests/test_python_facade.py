@@ -20,6 +20,11 @@ def test_record_fields_and_properties():
     assert (Record("solo", "A").name, Record("solo", "A").description) == ("solo", None)
     assert (Record("trail ", "A").name, Record("trail ", "A").description) == ("trail", "")
     assert (Record("", "A").name, Record("", "A").description) == ("", None)
+    # char::is_whitespace is the Unicode White_Space property: U+001C..U+001F (Python's \s / str.strip() treat them as
+    # whitespace) are NOT in it, U+0085 / U+00A0 / U+3000 are
+    assert (Record("a\x1cb c", "A").name, Record("a\x1cb c", "A").description) == ("a\x1cb", "c")
+    assert (Record("a \x1fb", "A").name, Record("a \x1fb", "A").description) == ("a", "\x1fb")
+    assert (Record("a\u3000\x85 b", "A").name, Record("a\u3000\x85 b", "A").description) == ("a", "b")
     assert r.is_fasta() and not r.is_fastq()
     q = Record("test description", "AGCTGATCGA", ";**9;;????")
     assert q.qual == ";**9;;????" and q.is_fastq() and not q.is_fasta()
