@@ -302,6 +302,36 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     return out
 
 
+class phase_deadline:
+    """Fail fast instead of hanging: a phase that may block inside C (process-group rendezvous, ncclCommInitRank, the first
+    collective) gets a deadline; when it passes, a watchdog thread prints the rank and the phase and ends the process with a
+    non-zero status (os._exit: the main thread may be stuck in a call that never returns).  `with phase_deadline(...)`."""
+
+    def __init__(self, phase: str, seconds: float, rank: int, fatal: bool = True):
+        import threading
+        self.phase, self.seconds, self.rank, self.fatal = phase, seconds, rank, fatal
+        self.done = threading.Event()
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+
+    def _watch(self):
+        if not self.done.wait(self.seconds):
+            sys.stderr.write(f"bench.py: rank {self.rank}: phase '{self.phase}' did not finish within {self.seconds:g} s - giving up "
+                             f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                             f"WORLD_SIZE={os.environ.get('WORLD_SIZE')})\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, etype, evalue, tb):
+        self.done.set()
+        if etype is not None and self.fatal and not issubclass(etype, (SystemExit, KeyboardInterrupt)):
+            raise SystemExit(f"bench.py: rank {self.rank}: phase '{self.phase}' failed: {etype.__name__}: {evalue}")
+        return False
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -336,11 +366,22 @@ def main():
                          "box with a torch.distributed all-reduce of the same accumulator words")
     ap.add_argument("--single-device", action="store_true",
                     help="test affordance: every rank uses cuda:0 (NOT a measurement: ranks share one GPU)")
+    ap.add_argument("--init-timeout-s", type=float, default=120.0,
+                    help="deadline for each start-up phase of an N > 1 run (process-group rendezvous, communicator init, first "
+                         "collective): past it the rank exits non-zero naming itself and the phase instead of hanging")
+    ap.add_argument("--allow-collective-fallback", action="store_true",
+                    help="if the library's own RCCL communicator (ntk_comm_*) cannot come up, reduce with torch.distributed's "
+                         "all_reduce instead (noted in config.collective); without this flag that is a fatal error")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
+        if not args.single_device:
+            from needletail_amd import _lib as ntl0
+            have = ntl0.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"--gpus {args.gpus} but {have} usable gfx950 device(s) are visible")
         # one process per GPU: re-launch under torch.distributed.run and pass its output through
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -370,18 +411,26 @@ def main():
     from needletail_amd import _lib as ntl
     from needletail_amd import distributed as nd
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     dev_index = 0 if args.single_device else local_rank
-    torch.cuda.set_device(dev_index)
     use_dist = "RANK" in os.environ
-    if use_dist:
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=max(1.0, args.init_timeout_s))
+    if use_dist and not (args.backend == "nccl" and not args.single_device):
+        # gloo (test mode) needs no device: rendezvous first, so that a wrong MASTER_ADDR / MASTER_PORT fails fast everywhere
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if args.backend == "nccl" and not args.single_device:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend="gloo")
+        with phase_deadline("process-group rendezvous (gloo)", args.init_timeout_s + 5, rank):
+            dist.init_process_group(backend="gloo", timeout=pg_timeout)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) are visible")
+    torch.cuda.set_device(dev_index)
+    if use_dist and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        with phase_deadline("process-group rendezvous (nccl)", args.init_timeout_s + 5, rank):
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=pg_timeout)
 
     # ---- workload ------------------------------------------------------------------------------------------------
     stride = args.read_len + 1
@@ -417,30 +466,46 @@ def main():
     collective_note = None
     if rccl:
         # the product path: the library's own communicator (ntk_comm_*, RCCL through the C ABI).  Should it fail to come up on
-        # ANY rank (say a librccl the process cannot load), every rank falls back to torch.distributed's all-reduce of the same
-        # accumulator words - still RCCL, still on the scan stream - and the JSON line says so.
+        # ANY rank (say a librccl the process cannot load) that is FATAL, on every rank, with the reason - unless
+        # --allow-collective-fallback was given: then every rank reduces the same accumulator words with torch.distributed's
+        # all-reduce (still RCCL, still on the scan stream) and the JSON line says so.  Every phase has a deadline.
         err = "NTK_BENCH_FORCE_COLLECTIVE_FALLBACK is set (test hook)" if os.environ.get("NTK_BENCH_FORCE_COLLECTIVE_FALLBACK") else None
         try:
             ids = [nd.Communicator.unique_id() if rank == 0 and not err else None]
         except nt.NtkError as e:
             ids, err = [None], str(e)
-        dist.broadcast_object_list(ids, src=0)
+        with phase_deadline("broadcast of the communicator id", args.init_timeout_s, rank):
+            dist.broadcast_object_list(ids, src=0)
         if ids[0] is not None:
             try:
-                comm = nd.Communicator.for_rank(ctx, world, rank, ids[0])
+                with phase_deadline("ntk_comm_init_rank (ncclCommInitRank)", args.init_timeout_s, rank, fatal=False):
+                    comm = nd.Communicator.for_rank(ctx, world, rank, ids[0])
             except nt.NtkError as e:
                 err = str(e)
         else:
             err = err or "rank 0 could not create a communicator id"
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 0:
+        with phase_deadline("agreement on the communicator (first torch collective)", args.init_timeout_s, rank):
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            all_ok = int(ok[0]) == 1
+        if not all_ok:
             if comm is not None:
                 comm.close()
             comm = None
             errs = [None] * world
             dist.all_gather_object(errs, err)
-            collective_note = "FALLBACK torch.distributed all_reduce (ntk_comm_* failed: %s)" % next(e for e in errs if e)
+            why = next(e for e in errs if e)
+            if not args.allow_collective_fallback:
+                raise SystemExit(f"rank {rank}: the library's RCCL communicator did not come up ({why}); "
+                                 "--allow-collective-fallback would reduce through torch.distributed instead")
+            collective_note = "FALLBACK torch.distributed all_reduce (ntk_comm_* failed: %s)" % why
+        else:
+            with phase_deadline("first ntk_allreduce_accumulators (ncclAllReduce)", args.init_timeout_s, rank):
+                ctx.accum_reset()
+                comm.allreduce_accumulators()
+                ctx.synchronize()
+            if comm.size != world:
+                raise SystemExit(f"rank {rank}: ntk_comm_size says {comm.size} ranks, WORLD_SIZE is {world}")
 
     def allreduce():
         if comm is not None:
@@ -559,6 +624,8 @@ def main():
                 "parallelism": (f"records sharded over {world} GPUs (round-robin batches of 2^20), one ncclAllReduce(ncclUint64, ncclSum, "
                                 f"{ntl.ACC_WORDS} words) per step through ntk_allreduce_accumulators") if world > 1 else "single GPU",
                 "launch": {"blocks": args.blocks or "auto", "threads": args.threads or "auto"},
+                "rccl_ranks": (comm.size if comm is not None else 0),   # ntk_comm_size: ranks the library's communicator spans (0 = none in use)
+                "devices_visible": torch.cuda.device_count(),
                 **({"collective": collective_note} if collective_note else {}),
                 **({"test_mode": f"{args.backend} backend, all ranks on cuda:0 - NOT a measurement"}
                    if (args.single_device or (use_dist and not rccl)) else {}),

@@ -386,9 +386,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 // ---------------------------------------------------------------------------------------------
 template <int K, int HB>
 struct DevMasks2 {
-    static constexpr bool kLight = Sv2Light<K>::value;
+    static constexpr bool kLight = Sv2Light<K, HB>::value;
     uint64_t V[16];          // lane masks: window ending at byte j is emitted
+#ifdef NTK_SV2_LAZYV
+    uint64_t VA[16], VB[16]; // ... as V[j] = VA[j] & VB[j], the AND done by the masked region straight into exec (emit4c)
+#endif
     uint64_t sum = 0;        // per-lane digests: sum of (hi:lo) (of the lo words when kLight); xor words of T and lo
+    uint64_t sum_b = 0;      // NTK_SV2_ACC2: second accumulator of the sum
     uint32_t xT = 0, xlo = 0;
     uint32_t cell = 0;       // LDS byte address of this thread's forward-strand counter
     uint32_t rep = 0;        // word builds, K <= 6: this lane's histogram copy (see emit4w)
@@ -396,6 +400,9 @@ struct DevMasks2 {
     uint32_t one = 1;
     uint32_t nf_s = 0;       // NTK_SV2_NFWD_SALU: forward-strand count of the wave, scalar
     uint32_t nf_v = 0;       // NTK_SV2_NFWD_VALU: forward-strand count of the lane
+    uint32_t app_m0 = 0;     // NTK_SV2_NFWD_APPEND: M0 for ds_append (LDS address of the wave's forward counter - 32768)
+    uint32_t app_sink = 0;   //   ... and the VGPR its (unused) return value lands in: owned for the whole kernel
+    uint32_t ptag = 0, pmask = 0;   // NTK_SV2_PRIV: (lane & 3) << 2, and 0xFFF0 held in a VGPR (an SGPR operand would make the op half-rate)
 
     template <int KM, class Enc>   // KM: good bases a window needs (K, or K + W - 1 for windowed minimizers)
     __device__ __forceinline__ void compute(const Enc &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
@@ -425,6 +432,9 @@ struct DevMasks2 {
 #pragma unroll
         for (int i = 0; i < 16; i++) V[i] = B[i];
 #else
+#if defined(NTK_SV2_LAZYV) && defined(NTK_SV2_CMPIN)
+        if constexpr (kLight && KM == K) window_masks_ab<KM>(B, VA, VB); else
+#endif
         if constexpr (KM >= 17) window_masks<KM>(B, V); else window_masks1<KM>(B, V);
 #endif
     }
@@ -567,6 +577,158 @@ struct DevMasks2 {
 #undef NTK_EMITW
     }
 
+    // NTK_SV2_CMPIN (LIGHT builds): emit4 with the strand compare and the lo select INSIDE the masked region.  Under exec = V the
+    // compare's mask is already F & V (inactive lanes compare as 0), so the forward count needs no s_and: it is either one more
+    // exec move + an LDS op (own cell, or ds_append with NTK_SV2_NFWD_APPEND), or two scalar ops and no LDS op at all
+    // (NTK_SV2_NFWD_SCNT: s_bcnt1 + s_add).  ft / rt: the T words, fl / rl: the lo candidates, off from the packed minimum as in emit4.
+    template <bool TIE_RC_, int N, class S>   // N = 4 or 8 positions per masked region (8: half as many exec restores and group sums)
+    __device__ __forceinline__ void emit4c(S &, const int (&pos)[N], const uint32_t (&ft)[N], const uint32_t (&rt)[N], const uint32_t (&fl)[N],
+                                           const uint32_t (&rl)[N], const uint32_t (&off)[N])
+    {
+        static_assert(N == 4 || N == 8, "4 or 8 positions per region");
+        uint32_t t0, t1, t2, t3;
+        uint64_t sd;
+#if defined(NTK_SV2_NFWD_SCNT)
+#define NTK_C_NFWD "s_bcnt1_i32_b64 %[cn], vcc\n s_add_u32 %[nf], %[nf], %[cn]\n"
+#define NTK_C_NFWD_FIRST "s_bcnt1_i32_b64 %[nf], vcc\n"   // (the group's first position starts the group's count)
+#define NTK_C_OUT , [nf] "=&s"(nf_grp), [cn] "=&s"(cn)
+#define NTK_C_IN [one] "v"(one)
+#define NTK_C_PRE ""
+        uint32_t cn, nf_grp;
+#elif defined(NTK_SV2_NFWD_APPEND)
+#define NTK_C_NFWD "s_mov_b64 exec, vcc\n ds_append %[apd] offset:32768\n"
+#define NTK_C_OUT , [apd] "+v"(app_sink)
+#define NTK_C_IN [one] "v"(one), [m0v] "s"(app_m0)
+#define NTK_C_PRE "s_mov_b32 m0, %[m0v]\n"
+#elif defined(NTK_SV2_NFWD_VADDC)
+        // per-lane forward count on the VALU without an exec change: nf_v += vcc (the carry-in of an add with 0)
+#define NTK_C_NFWD "v_addc_co_u32 %[nfv], %[sd], 0, %[nfv], vcc\n"
+#define NTK_C_OUT , [nfv] "+v"(nf_v)
+#define NTK_C_IN [one] "v"(one)
+#define NTK_C_PRE ""
+#else
+#define NTK_C_NFWD "s_mov_b64 exec, vcc\n ds_add_u32 %[cell], %[one]\n"
+#define NTK_C_OUT
+#define NTK_C_IN [one] "v"(one), [cell] "v"(cell)
+#define NTK_C_PRE ""
+#endif
+#define NTK_C_CMP(i) "v_cmp_lt_u32 vcc, %[ft" #i "], %[rt" #i "]\n"
+#define NTK_C_CMPE(i) "v_cmp_le_u32 vcc, %[ft" #i "], %[rt" #i "]\n"
+#ifdef NTK_SV2_LAZYV
+#define NTK_C_EXEC(i) "s_and_b64 exec, %[V" #i "], %[W" #i "]\n"
+#define NTK_C_VIN(i) [V##i] "s"(VA[pos[i]]), [W##i] "s"(VB[pos[i]])
+#else
+#define NTK_C_EXEC(i) "s_mov_b64 exec, %[V" #i "]\n"
+#define NTK_C_VIN(i) [V##i] "s"(V[pos[i]])
+#endif
+#ifndef NTK_C_NFWD_FIRST
+#define NTK_C_NFWD_FIRST NTK_C_NFWD
+#endif
+#ifdef NTK_SV2_CXOR_LDS   // the xor digest on the LDS pipe: the thread's own cell (free once the forward count is scalar)
+#define NTK_C_XOR(t) "ds_xor_b32 %[xcell], %[t" #t "]\n"
+#define NTK_C_XIN , [xcell] "v"(cell)
+#else
+#define NTK_C_XOR(t) "v_xor_b32 %[xlo], %[xlo], %[t" #t "]\n"
+#define NTK_C_XIN
+#endif
+#ifdef NTK_SV2_ACC2   // two accumulator pairs, alternating: no position waits for the previous position's 64-bit add
+#define NTK_C_SUM_0 "v_mad_u64_u32 %[sumA], %[sd], %[t0], 1, %[sumA]\n"
+#define NTK_C_SUM_1 "v_mad_u64_u32 %[sumB], %[sd], %[t1], 1, %[sumB]\n"
+#define NTK_C_SUM_2 "v_mad_u64_u32 %[sumA], %[sd], %[t2], 1, %[sumA]\n"
+#define NTK_C_SUM_3 "v_mad_u64_u32 %[sumB], %[sd], %[t3], 1, %[sumB]\n"
+#define NTK_C_SUM(t) NTK_C_SUM_##t
+#define NTK_C_SUMOPS [sumA] "+v"(sum), [sumB] "+v"(sum_b)
+#else
+#define NTK_C_SUM(t) "v_mad_u64_u32 %[sum], %[sd], %[t" #t "], 1, %[sum]\n"
+#define NTK_C_SUMOPS [sum] "+v"(sum)
+#endif
+#ifdef NTK_SV2_LDSLAST
+#define NTK_C_POS_(i, t, CMP, NF)                                           \
+        NTK_C_EXEC(i)                                                       \
+        CMP(i)                                                              \
+        "v_cndmask_b32 %[t" #t "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_C_SUM(t)                                                        \
+        NTK_C_XOR(t)                                                        \
+        "ds_add_u32 %[o" #i "], %[one]\n"                                   \
+        NF
+#else
+#define NTK_C_POS_(i, t, CMP, NF)                                           \
+        NTK_C_EXEC(i)                                                       \
+        CMP(i)                                                              \
+        "ds_add_u32 %[o" #i "], %[one]\n"                                   \
+        "v_cndmask_b32 %[t" #t "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_C_SUM(t)                                                        \
+        NTK_C_XOR(t)                                                        \
+        NF
+#endif
+#define NTK_C_POS(i, t, CMP) NTK_C_POS_(i, t, CMP, NTK_C_NFWD)
+#define NTK_C_POS0(i, t, CMP) NTK_C_POS_(i, t, CMP, NTK_C_NFWD_FIRST)
+#define NTK_C_PIN(i) [o##i] "v"(off[i]), [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_C_VIN(i)
+#define NTK_C_OUTS : NTK_C_SUMOPS, [xlo] "+v"(xlo), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sd] "=&s"(sd) NTK_C_OUT
+#define NTK_C_CLOB : "memory", "vcc", "scc"
+#define NTK_C_BODY4(CMP) NTK_C_PRE NTK_C_POS0(0, 0, CMP) NTK_C_POS(1, 1, CMP) NTK_C_POS(2, 2, CMP) NTK_C_POS(3, 3, CMP) "s_mov_b64 exec, -1\n"
+#define NTK_C_BODY8(CMP) NTK_C_PRE NTK_C_POS0(0, 0, CMP) NTK_C_POS(1, 1, CMP) NTK_C_POS(2, 2, CMP) NTK_C_POS(3, 3, CMP)            \
+                         NTK_C_POS(4, 0, CMP) NTK_C_POS(5, 1, CMP) NTK_C_POS(6, 2, CMP) NTK_C_POS(7, 3, CMP) "s_mov_b64 exec, -1\n"
+        if constexpr (N == 4) {
+            if constexpr (TIE_RC_)
+                asm volatile(NTK_C_BODY4(NTK_C_CMP) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
+            else
+                asm volatile(NTK_C_BODY4(NTK_C_CMPE) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
+        } else {
+            if constexpr (TIE_RC_)
+                asm volatile(NTK_C_BODY8(NTK_C_CMP) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_PIN(4), NTK_C_PIN(5),
+                             NTK_C_PIN(6), NTK_C_PIN(7), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
+            else
+                asm volatile(NTK_C_BODY8(NTK_C_CMPE) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_PIN(4), NTK_C_PIN(5),
+                             NTK_C_PIN(6), NTK_C_PIN(7), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
+        }
+#if defined(NTK_SV2_NFWD_SCNT)
+        nf_s += nf_grp;
+#endif
+#undef NTK_C_BODY8
+#undef NTK_C_BODY4
+#undef NTK_C_CLOB
+#undef NTK_C_OUTS
+#undef NTK_C_PIN
+#undef NTK_C_POS0
+#undef NTK_C_POS
+#undef NTK_C_POS_
+#undef NTK_C_NFWD_FIRST
+#undef NTK_C_SUM
+#undef NTK_C_SUM_0
+#undef NTK_C_SUM_1
+#undef NTK_C_SUM_2
+#undef NTK_C_SUM_3
+#undef NTK_C_SUMOPS
+#undef NTK_C_XOR
+#undef NTK_C_XIN
+#undef NTK_C_EXEC
+#undef NTK_C_VIN
+#undef NTK_C_CMPE
+#undef NTK_C_CMP
+#undef NTK_C_PRE
+#undef NTK_C_IN
+#undef NTK_C_OUT
+#undef NTK_C_NFWD
+    }
+    // histogram cell offsets of the two positions that share a packed minimum (hi half: position j, lo half: position j + 8)
+    __device__ __forceinline__ uint32_t cell_offset_hi(uint32_t T) const
+    {
+#ifdef NTK_SV2_PRIV
+        return and_or(T >> 16, pmask, ptag);
+#else
+        return cell_offset(T, 0);
+#endif
+    }
+    __device__ __forceinline__ uint32_t cell_offset_lo(uint32_t T) const
+    {
+#ifdef NTK_SV2_PRIV
+        return and_or(T, pmask, ptag);
+#else
+        return cell_offset(T, 2);
+#endif
+    }
+
     // Side effects of four positions pos[0..3].  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
     // Per position, under the validity mask: histogram cell += 1 and the digests; under validity & strand mask: the
     // thread's own forward counter += 1 (non-returning LDS atomics: no VALU work for either count).
@@ -584,11 +746,17 @@ struct DevMasks2 {
             // byte offset of the histogram cell: the value's top HB bits, * 4
             // (LDS atomics at an address that is not 4-byte aligned raise a memory violation on gfx950 - measured - so the low
             //  two bits have to be cleared)
+#ifdef NTK_SV2_PRIV
+            // cell = (the value's top 12 bits : lane & 3): the 32 lanes of an LDS lane group spread over four disjoint bank sets
+            if (kLight && i >= 2) off[i] = and_or(T[i], pmask, ptag);
+            else off[i] = and_or(T[i] >> 16, pmask, ptag);
+#else
             if (kLight && i >= 2) off[i] = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
             else if (HB == 14) {
                 const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
                 asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off[i]) : "s"(kMask), "v"(T[i]));
             } else off[i] = (T[i] >> 18) & 0x3FFCu;
+#endif
         }
 #ifdef NTK_ABL_NOLDS
 #define NTK_DS_HIST(i) ""
@@ -611,6 +779,11 @@ struct DevMasks2 {
 #define NTK_DIGEST_L(i) "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n" "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
 #endif
 #endif
+#ifdef NTK_SV2_NFWD_APPEND
+#define NTK_M0_CLOB   /* (m0 is a reserved register: the compiler does not track it and does not use it in this kernel) */
+#else
+#define NTK_M0_CLOB
+#endif
 #if defined(NTK_ABL_NOEXEC)
 #define NTK_NFWD(i) NTK_DS_CELL
 #define NTK_NF_OUT
@@ -621,6 +794,12 @@ struct DevMasks2 {
 #define NTK_NF_OUT , [nfv] "+v"(nf_v)
 #define NTK_CELL_IN [one] "v"(one)
 #define NTK_NF_ZERO
+#elif defined(NTK_SV2_NFWD_APPEND)
+        // the forward-strand count on ds_append: LDS[M0 + offset] += popcount(exec), no address / data VGPRs to move
+#define NTK_NFWD(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n ds_append %[apd] offset:32768\n"
+#define NTK_NF_OUT , [apd] "+v"(app_sink)
+#define NTK_CELL_IN [one] "v"(one), [m0v] "s"(app_m0)
+#define NTK_NF_ZERO "s_mov_b32 m0, %[m0v]\n"
 #elif defined(NTK_SV2_NFWD_SALU)
 #define NTK_NFWD(i) "s_and_b64 vcc, %[V" #i "], %[F" #i "]\n s_bcnt1_i32_b64 vcc_lo, vcc\n s_add_u32 %[nf], %[nf], vcc_lo\n"
 #define NTK_NF_OUT , [nf] "=&s"(nf_grp)
@@ -646,7 +825,7 @@ struct DevMasks2 {
                            [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
                            [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
                            NTK_CELL_IN
-                         : "memory", "vcc", "scc");
+                         : "memory", "vcc", "scc" NTK_M0_CLOB);
 #undef NTK_EMIT1
         } else {
 #define NTK_EMIT1(i)                                             \
@@ -663,7 +842,7 @@ struct DevMasks2 {
                            [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
                            [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
                            NTK_CELL_IN
-                         : "memory", "vcc", "scc");
+                         : "memory", "vcc", "scc" NTK_M0_CLOB);
 #undef NTK_EMIT1
         }
 #undef NTK_DS_HIST
@@ -672,6 +851,7 @@ struct DevMasks2 {
 #undef NTK_NF_OUT
 #undef NTK_CELL_IN
 #undef NTK_NF_ZERO
+#undef NTK_M0_CLOB
 #undef NTK_SETEXEC
 #undef NTK_DIGEST_L
 #ifdef NTK_SV2_NFWD_SALU
@@ -690,14 +870,13 @@ template <int K, bool TIE_RC, bool ACCEPT_U, bool QM = false, int HB = 12, int W
 __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs a)
 {
     static_assert(K >= 1 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 1 <= k <= 32");
-    static_assert(K >= 17 || W == 0, "word builds (k <= 16): no fused minimizers");
     static_assert(W == 0 || Sv2MinFused<K, W>::value, "fused minimizers: see ntk_tile.hpp");
     constexpr bool WORD = K <= 16;                        // one-word values (lane_tile_sv2w): digests kept left-aligned
-    constexpr bool LIGHT = Sv2Light<K>::value && !WORD;
+    constexpr bool LIGHT = Sv2Light<K, HB>::value && !WORD;
     constexpr int kCells = 1 << HB;
     // One LDS object, histogram first: the masked regions address the histogram with the cell's byte offset alone, which
     // is only right while the histogram sits at LDS address 0 (checked below; the kernel has no other LDS object).
-    struct Lds { uint32_t hist[kCells]; uint32_t nfwd[1024]; uint64_t red[16 * 6]; };
+    struct Lds { uint32_t hist[kCells]; uint32_t nfwd[1024]; uint64_t red[16 * 6]; uint32_t nfw[16]; };   // nfw: per-wave forward counters (ds_append)
     __shared__ Lds L;
     uint32_t *const s_hist = L.hist, *const s_nfwd = L.nfwd;  // nfwd: per-thread forward-strand counters
     uint64_t *const s_red = L.red;
@@ -711,6 +890,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
     for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
     s_nfwd[threadIdx.x] = 0;
+    if (threadIdx.x < 16) L.nfw[threadIdx.x] = 0;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -727,6 +907,13 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     NoSink sink;
     mp.cell = (uint32_t)(uintptr_t)&s_nfwd[threadIdx.x];   // LDS byte address: the asm blocks address LDS directly
     mp.rep = lane & (uint32_t)(DevMasks2<K, HB>::kWordCopies - 1);
+#ifdef NTK_SV2_NFWD_APPEND
+    mp.app_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&L.nfw[wave] - 32768u);   // ds_append: M0[15:0] + offset:32768
+#endif
+#ifdef NTK_SV2_PRIV
+    mp.ptag = (lane & 3u) << 2; mp.pmask = 0xFFF0u;
+    asm volatile("" : "+v"(mp.pmask));   // keep the constant in a VGPR (v_bitop3 with an SGPR operand is half-rate)
+#endif
 
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
@@ -755,20 +942,41 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         }
         uint32_t voff = lane * 16u - (32u - halo);
         uint64_t tile_byte = run_byte;
+#ifdef NTK_ABL_FLOOR
+        auto load_tile = [&](uint32_t off) { (void)rs; return u32x4{off, off, off, off}; };
+#else
         auto load_tile = [&](uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); };
+#endif
         auto load_qual = [&](uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0); };
+#ifdef NTK_ABL_FLOOR
+        uint32_t fl_code = lane * 0x9E3779B9u + r0, fl_rcode = ~fl_code, fl_step = 0x85EBCA6Bu + lane;
+        asm volatile("" : "+v"(fl_step));
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            mp.V[i] = ~3ull;
+#ifdef NTK_SV2_LAZYV
+            mp.VA[i] = ~3ull; mp.VB[i] = ~0ull;
+#endif
+        }
+#endif
         auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r) {
             const bool tail = r >= a.tail_tile_rel;
             Raw16 raw{t.x, t.y, t.z, t.w};
             if constexpr (QM) raw = quality_break16(raw, Raw16{q.x, q.y, q.z, q.w}, a.q_add, a.q_sel);
 #ifdef NTK_ABL_LOADSONLY
             mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
+#elif defined(NTK_ABL_FLOOR)
+            // floor kernel (tools/kbench.hip, profiles/r03*/floor.txt): no load, no encode, no validity - only the window words and
+            // the per-position work, on synthetic register-resident stream words (two adds keep them changing from tile to tile)
+            (void)tail; (void)raw;
+            fl_code += fl_step; fl_rcode += fl_code;
+            lane_tile_sv2<TIE_RC, K>(sink, xl, mp, fl_code, fl_rcode);
 #else
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
             mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-            if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
+            if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
+            else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
-            else if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
             voff += kTileStride; tile_byte += kTileStride;
@@ -811,21 +1019,32 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
     constexpr int S = WORD ? 0 : 64 - 2 * K;
-    uint64_t sum = mp.sum, xr = WORD ? (uint64_t)mp.xlo : ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
+    uint64_t sum = mp.sum + mp.sum_b, xr = WORD ? (uint64_t)mp.xlo : ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
     uint64_t shi = 0, xf = 0;   // LIGHT: high parts of the digests, from the histogram
     uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
-#ifdef NTK_SV2_XOR_LDS
+#if defined(NTK_SV2_XOR_LDS) || defined(NTK_SV2_CXOR_LDS)
     mp.xlo = s_nfwd[threadIdx.x];   // the cell holds the lane's xor of lo words
 #endif
-#if defined(NTK_SV2_NFWD_VALU)
+#if defined(NTK_SV2_NFWD_APPEND)
+    asm volatile("" : : "v"(mp.app_sink));   // the ds_append return register stayed reserved up to here
+    nf = 0;   // (read after the barrier below: the wave's LDS counter)
+#elif defined(NTK_SV2_NFWD_VALU) || defined(NTK_SV2_NFWD_VADDC)
     nf = mp.nf_v;
-#elif defined(NTK_SV2_NFWD_SALU)
+#elif defined(NTK_SV2_NFWD_SALU) || defined(NTK_SV2_NFWD_SCNT)
     nf = lane == 0 ? mp.nf_s : 0u;
 #else
     nf = s_nfwd[threadIdx.x];
 #endif
     if constexpr (W > 0) nf = mp.nf_bits;   // strand bits of the chosen keys: forward count (TIE_RC) or rc count
     __syncthreads();
+#if defined(NTK_SV2_NFWD_APPEND)
+    if constexpr (W == 0 && !FWD && !WORD) nf = lane == 0 ? L.nfw[wave] : 0u;
+#endif
+#ifdef NTK_SV2_PRIV
+    constexpr int HBE = (LIGHT && W == 0 && !FWD) ? 12 : HB;   // bits of the value's prefix in a cell index (the rest: lane copies)
+#else
+    constexpr int HBE = HB;
+#endif
     for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
         uint32_t tot = 0;
         if constexpr (K <= 6) {   // word builds up to 6 bases: cell = copy * 4^K + value, bin = value
@@ -836,18 +1055,19 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         for (int q = 0; q < kCells / kHistBins; q++) {
             const uint32_t f = c * (kCells / kHistBins) + q, h = s_hist[f];
             tot += h;
-            if constexpr (LIGHT) {   // cell f = the value's top HB bits: hi word = f >> (32 + HB - 2K), xor bits 2K-HB and up = f
-                shi += (uint64_t)(f >> (32 + HB - 2 * K)) * h;
-                xf ^= (h & 1u) ? f : 0u;
+            if constexpr (LIGHT) {   // cell f >> (HB - HBE) = the value's top HBE bits p: hi word = p >> (32 + HBE - 2K), xor bits 2K-HBE and up = p
+                const uint32_t pfx = f >> (HB - HBE);
+                shi += (uint64_t)(pfx >> (32 + HBE - 2 * K)) * h;
+                xf ^= (h & 1u) ? pfx : 0u;
             }
         }
         ph[c] = tot; nv += tot;
     }
     if constexpr (LIGHT) {
         // the lo words and the histogram cells overlap in bits [2K-HB, 32) of the value: those bits are taken from the cells
-        constexpr uint32_t low_mask = 2 * K - HB >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * K - HB) & 31)) - 1u);
+        constexpr uint32_t low_mask = 2 * K - HBE >= 32 ? 0xFFFFFFFFu : ((1u << ((2 * K - HBE) & 31)) - 1u);
         sum += shi << 32;
-        xr = (xf << (2 * K - HB)) | (uint64_t)(mp.xlo & low_mask);
+        xr = (xf << (2 * K - HBE)) | (uint64_t)(mp.xlo & low_mask);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -866,7 +1086,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
         if constexpr (W > 0 && !TIE_RC) tf = tv - tf;   // the bits counted the reverse-complement choices
         if constexpr (FWD) tf = tv;                     // forward-only builds keep no strand counter
-        if constexpr (WORD && K < 16) { ts >>= 32 - 2 * K; tx >>= 32 - 2 * K; }   // left-aligned digests (exact: < 2^32 words per block)
+        if constexpr (WORD && K < 16 && W == 0) { ts >>= 32 - 2 * K; tx >>= 32 - 2 * K; }   // left-aligned digests (exact: < 2^32 words per block; the fused minimizers keep plain values)
         ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
     }
 }

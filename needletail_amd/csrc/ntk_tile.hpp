@@ -414,6 +414,28 @@ NTK_HD void window_masks(const uint64_t (&G)[16], uint64_t (&OK)[16])
     }
 }
 
+// The same masks with their last AND left open: OK[j] = A[j] & B[j] (A = the lane's own prefix, B = what the previous lanes
+// contribute).  The masked region forms exec with that AND itself (s_and_b64 exec, A, B): one scalar op instead of AND + move.
+template <int K>
+NTK_HD void window_masks_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
+{
+    static_assert(K >= 17 && K <= 32, "sv path is built for 17 <= k <= 32");
+    uint64_t S[16];
+    S[15] = G[15];
+#pragma unroll
+    for (int i = 14; i >= 0; i--) S[i] = S[i + 1] & G[i];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int c = 17 + j - K, a_ = c > 0 ? c : 0;
+        uint64_t v = S[a_] << 1;
+        if (c < 0) v &= S[(33 + j - K) & 15] << 2;
+        B[j] = v;
+    }
+    A[0] = G[0] & ~3ull;  // halo lanes 0/1: cleared once here, inherited by every prefix
+#pragma unroll
+    for (int j = 1; j < 16; j++) A[j] = A[j - 1] & G[j];
+}
+
 template <bool CANON, bool TIE_RC, int KFIX, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv(Sink &sink, XL &xl, MP &mp, const EncSV &en)
 {
@@ -590,12 +612,13 @@ NTK_HD bool sv2_base_is_break(const EncSV2 &e, int i)  // host side of the SDWA 
     return ((e.ex[i >> 2] >> sh) & 0xFFu) != ((e.uu[i >> 2] >> sh) & 0xFFu);
 }
 
-// LIGHT (K <= 22): the top 12 bits of a value (its histogram bin) reach down to bit 2K-12 <= 32, so bin and lo word
-// together cover every bit of the value.  The per-position work then only touches the lo word (sum of lo words in 64
-// bits, xor of lo words); the high part of both digests follows from the block's histogram when it is written out:
-//     sum of hi words = sum_b (b >> (44 - 2K)) * H[b]          xor, bits 2K-12 and up = xor_b (H[b] odd ? b : 0)
-// and the histogram address only needs the top 16 bits of the chosen T word = min of the two top halves (one SDWA min).
-template <int K> struct Sv2Light { static constexpr bool value = K <= 22; };
+// LIGHT (2K - HB <= 32: K <= 22 with a 12-bit histogram, K <= 23 with the shipped 14-bit one): the top HB bits of a value (its
+// histogram cell) reach down to bit 2K-HB <= 32, so cell and lo word together cover every bit of the value.  The per-position
+// work then only touches the lo word (sum of lo words in 64 bits, xor of lo words); the high part of both digests follows from
+// the block's histogram when it is written out:
+//     sum of hi words = sum_b (b >> (32 + HB - 2K)) * H[b]          xor, bits 2K-HB and up = xor_b (H[b] odd ? b : 0)
+// and the histogram address only needs the top 16 bits of the chosen T word = min of the two top halves (one packed min).
+template <int K, int HB> struct Sv2Light { static constexpr bool value = K >= 17 && 2 * K - HB <= 32; };
 
 template <bool TIE_RC, int K, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
@@ -630,6 +653,32 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
         const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
         uint32_t T[4], lo[4], hi[4];
         bool fwd[4];
+#if defined(NTK_SV2_CMPIN) && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (LIGHT) {   // compare + select inside the masked region (DevMasks2::emit4c)
+#ifdef NTK_SV2_G8
+            constexpr int N = 8;
+            if (jp & 2) continue;   // positions {jp .. jp+3, jp+8 .. jp+11}, jp = 0, 4
+            const int ps[N] = {jp, jp + 1, jp + 2, jp + 3, jp + 8, jp + 9, jp + 10, jp + 11};
+#else
+            constexpr int N = 4;
+            const int ps[N] = {jp, jp + 1, jp + 8, jp + 9};
+#endif
+            uint32_t ftw[N], rtw[N], flw[N], rlw[N], off[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = ps[i];
+                ftw[i] = fw[j]; rtw[i] = rw[D + j]; flw[i] = fw[D + j];
+                rlw[i] = j - D >= -1 ? rw[j] : xl.prev(kSlotRw + 16 + j - D, rw[16 + j]);
+            }
+#pragma unroll
+            for (int i = 0; i < N / 2; i++) {   // positions ps[i] and ps[i] + 8 share one packed minimum
+                const uint32_t Tm = mp.pk_min16_crossed(fw[ps[i]], rw[D + ps[i] + 8]);
+                off[i] = mp.cell_offset_hi(Tm); off[i + N / 2] = mp.cell_offset_lo(Tm);
+            }
+            mp.template emit4c<TIE_RC, N>(sink, ps, ftw, rtw, flw, rlw, off);
+            continue;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int j = pos[i];
@@ -749,20 +798,21 @@ NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 // The digests follow the LIGHT scheme of lane_tile_sv2 (K <= 22): lo word per position, high parts from the histogram.
 // ---------------------------------------------------------------------------------------------
 template <int K, int W> struct Sv2MinFused {
-    static constexpr bool value = K >= 17 && K <= 22 && W >= 9 && K + W - 1 <= 32;
+    static constexpr bool value = K >= 15 && K <= 22 && W >= 9 && K + W - 1 <= 32;
 };
 
 template <bool TIE_RC, int K, int W, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
 {
-    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 17 <= K <= 22, 9 <= W, K + W - 1 <= 32");
-    constexpr int D = K - 16, HS = 58 - 2 * K;            // key hi word = T >> HS (| bit 30)
+    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 22, 9 <= W, K + W - 1 <= 32");
+    constexpr int D = K > 16 ? K - 16 : 0;
+    constexpr int HS = K > 16 ? 58 - 2 * K : 26;           // key hi word = T >> HS (| bit 30); K <= 16: the value is one word, T = value
     constexpr uint32_t kBit62 = 1u << (HS - 2);            // alignbit(kBit62, T, HS) == (T >> HS) | 0x40000000
     constexpr uint32_t fbitF = TIE_RC ? 1u : 0u, fbitR = TIE_RC ? 0u : 1u;
-    uint32_t fw[16 + D], rw[16 + D];   // index g + D
+    uint32_t fw[16 + D + 1], rw[16 + D + 1];   // index g + D  (+ 1: never a zero-length array)
     const uint32_t c1 = xl.prev(kSlotCode, code), r1 = xl.prev(kSlotRcode, rcode);
     fw[D + 15] = code; rw[D + 15] = rcode;
-    fw[D - 1] = c1;    rw[D - 1] = r1;
+    if constexpr (D > 0) { fw[D - 1] = c1; rw[D - 1] = r1; }
 #pragma unroll
     for (int j = 0; j < 15; j++) {
         fw[D + j] = alignbit(c1, code, 30 - 2 * j);
@@ -778,9 +828,19 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t idx2 = (uint32_t)(16 + j) << 1;
-        const uint64_t kf = ((uint64_t)alignbit(kBit62, fw[j], HS) << 32) | ((fw[D + j] << 6) | (idx2 | fbitF));
-        const uint64_t kr = ((uint64_t)alignbit(kBit62, rw[D + j], HS) << 32) | ((rw[j] << 6) | (idx2 | fbitR));
-        key[j] = mp.min64(kf, kr);
+        if constexpr (K > 16) {
+            const uint64_t kf = ((uint64_t)alignbit(kBit62, fw[j], HS) << 32) | ((fw[D + j] << 6) | (idx2 | fbitF));
+            const uint64_t kr = ((uint64_t)alignbit(kBit62, rw[D + j], HS) << 32) | ((rw[j] << 6) | (idx2 | fbitR));
+            key[j] = mp.min64(kf, kr);
+        } else {
+            // K <= 16 (the common (15, 10) sketch): the value is the low 2K bits of the forward word ending at base j / the top 2K
+            // bits of the reverse-complement word starting there; the key is built from that one word
+            constexpr uint32_t vmask = K == 16 ? 0xFFFFFFFFu : ((1u << ((2 * K) & 31)) - 1u);
+            const uint32_t vf = K == 16 ? fw[j] : (fw[j] & vmask), vr = K == 16 ? rw[j] : (rw[j] >> ((32 - 2 * K) & 31));
+            const uint64_t kf = ((uint64_t)alignbit(kBit62, vf, HS) << 32) | ((vf << 6) | (idx2 | fbitF));
+            const uint64_t kr = ((uint64_t)alignbit(kBit62, vr, HS) << 32) | ((vr << 6) | (idx2 | fbitR));
+            key[j] = mp.min64(kf, kr);
+        }
     }
     // suffix minima of the own keys, handed to the next lane; the previous lane's arrive with 16 taken off their index
     constexpr int A0 = 17 - W;                             // the previous lane's positions A0 .. 15 can be in a window of ours

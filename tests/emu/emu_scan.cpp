@@ -151,7 +151,7 @@ void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostS
 // which the high parts are rebuilt - so that the reconstruction arithmetic of scan2_kernel is what gets checked.
 template <int K, int HB>
 struct EmuMP2 {
-    static constexpr bool kLight = Sv2Light<K>::value;
+    static constexpr bool kLight = Sv2Light<K, HB>::value;
     static constexpr int kWordCopies = K <= 6 ? (((1 << HB) >> (2 * (K <= 6 ? K : 0))) < 64 ? ((1 << HB) >> (2 * (K <= 6 ? K : 0))) : 64) : 1;
     uint64_t V[16];
     int lane = 0;

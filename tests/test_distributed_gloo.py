@@ -96,3 +96,32 @@ def test_round_robin_batches_partition_the_records():
         D.round_robin_batches(10, 2, 2)
     b, e = D.shard_range(10, 1, 3)
     assert (b, e) == (4, 7)
+
+
+def test_bench_fails_fast_when_the_rendezvous_cannot_happen():
+    """bench.py N > 1 start-up has deadlines: a rank whose MASTER_PORT nobody listens on must exit
+    non-zero within seconds, naming itself and the phase - not sit in the rendezvous until the driver's lease runs out.
+    (gloo, no GPU needed: the process group is joined before any device is touched.)"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                        "--init-timeout-s", "4", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=170)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 120, (r.returncode, took)
+    assert "rank 1" in r.stderr and "phase 'process-group rendezvous (gloo)'" in r.stderr, r.stderr[-1500:]
+    assert r.stdout.strip() == ""   # no JSON line from a run that did not happen
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """`python bench.py --gpus N` with fewer than N usable devices is an immediate, named error (no launcher, no hang)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 64 but" in r.stderr and "usable gfx950 device(s) are visible" in r.stderr, r.stderr[-800:]

@@ -930,6 +930,107 @@ def test_rccl_allreduce_through_the_c_abi_single_rank(ctx):
         D.Communicator.for_rank(ctx, 2, 5, b"\0" * 128)   # rank out of range: an argument error, not a hang
 
 
+def test_rccl_all_visible_devices():
+    """configs[3] over EVERY device this process can see (1 on the builder's box, 8 on a node - the test scales with
+    torch.cuda.device_count()): ONE process, one ctx and one host thread per device, one ntk_comm_init_all communicator; each
+    device generates and scans its round-robin share (record batches of 2^20 reads) of a 4 M-read
+    seed-0x5EED0004 set, ONE ntk_allreduce_accumulators, and every device must then hold the oracle's result of the WHOLE set."""
+    import threading
+    from needletail_amd import _lib as NL
+    from needletail_amd import distributed as D
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1 and NL.device_count() == n_dev
+    total_reads, L, k = 4_000_000, 150, 21
+    stride = L + 1
+    want = O.reduce_fused_parallel(O.synth_reads(0x5EED0004, 0, total_reads, L, 1), stride, k, True, True, True,
+                                   max(1, os.cpu_count() or 1))
+    ctxs = [nt.Context(d) for d in range(n_dev)]      # own streams: nothing here goes through torch's current stream
+    shards, seqs, errors = [], [], []
+    try:
+        for d in range(n_dev):
+            batches = D.round_robin_batches(total_reads, d, n_dev)
+            shards.append(batches)
+            seqs.append(torch.empty(sum(n for _, n in batches) * stride + 2048, dtype=torch.uint8, device=f"cuda:{d}"))
+        assert sum(n for b in shards for _, n in b) == total_reads
+        torch.cuda.synchronize()
+
+        def work(d):
+            try:
+                c, pos = ctxs[d], 0
+                for first, n in shards[d]:
+                    c.synth_reads_device(0x5EED0004, first, n, L, 1, seqs[d][pos:])
+                    pos += n * stride
+                c.accum_reset()
+                c.reduce_device(seqs[d], pos, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+                c.synchronize()
+            except Exception as e:   # noqa: BLE001 - reported below, from the main thread
+                errors.append((d, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(d,)) for d in range(n_dev)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors and not any(t.is_alive() for t in threads), errors
+        mine = [c.accum_read() for c in ctxs]
+        assert sum(m["n_total"] for m in mine) == want["n_total"]
+        with D.Communicator.all_local(ctxs) as comm:
+            assert comm.size == n_dev
+            comm.allreduce_accumulators()
+            for d, c in enumerate(ctxs):
+                assert_stats_equal(c.accum_read(), want, f"device {d} of {n_dev} after the all-reduce")
+    finally:
+        for c in ctxs:
+            c.close()
+        del seqs
+        torch.cuda.empty_cache()
+
+
+def test_bench_self_launch_all_devices():
+    """`python bench.py --gpus <all visible devices>` end to end as the driver runs it: with more than one device it
+    re-launches itself under torch.distributed.run (one process per GPU, the library's own RCCL communicator); with one
+    device the same configs[3] path runs as a one-rank RCCL job.  Either way: the whole read set verified against the oracle,
+    the library's communicator in use (rccl_ranks == devices, no fallback note)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_dev = torch.cuda.device_count()
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_dev), "--reads", "8000000", "--steps", "3", "--warmup", "1",
+           "--preheat-ms", "20", "--no-cpu-baseline", "--no-secondary", "--init-timeout-s", "120"]
+    if n_dev == 1:   # one rank: the RCCL path needs the rank environment (--gpus 1 alone is the single-GPU configs[1] run)
+        env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        cmd += ["--workload", "c4"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == n_dev and cfg["rccl_ranks"] == n_dev and cfg["devices_visible"] == n_dev
+    assert "collective" not in cfg and "test_mode" not in cfg, cfg
+    assert cfg["reads_total"] == 8_000_000 and cfg["seed"] == "0x5eed0004"
+    assert line["result"]["verified"] and "bit-exact" in line["result"]["verified"]
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_bench_collective_fallback_is_opt_in():
+    """A communicator that cannot come up is fatal unless --allow-collective-fallback is given (then the line says so)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", NTK_BENCH_FORCE_COLLECTIVE_FALLBACK="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "c4", "--reads", "1000000", "--steps", "2", "--warmup", "1",
+           "--preheat-ms", "10", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "did not come up" in r.stderr and r.stdout.strip() == "", r.stderr[-2000:]
+    r = subprocess.run(cmd + ["--allow-collective-fallback"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cfg = json.loads(r.stdout.strip().splitlines()[-1])["config"]
+    assert cfg["rccl_ranks"] == 0 and cfg["collective"].startswith("FALLBACK")
+
+
 def test_batched_compat_face_matches_the_iterators_per_record(ctx):
     """ntk_bit_kmers_batch / ntk_canonical_kmers_batch: one call for a whole batch of records, element-wise against the
     oracle's literal iterators (reference src/sequence.rs:237-252) record by record; ragged, empty and all-N records,

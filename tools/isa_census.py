@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Instruction census of the scan2 tile loop (k = 21 headline build) straight from the compiler's ISA listing:
 hipcc -S of tools/kbench.hip, the kernel's innermost loop (the basic blocks between the tile loop's header and its back
-edge), instructions counted by mnemonic and by class.  Usage: python tools/isa_census.py [K] > profiles/<round>/isa_census.txt"""
+edge), instructions counted by mnemonic and by class.  Usage: python tools/isa_census.py [K] > profiles/<round>/isa_census.txt
+NTK_CENSUS_FLAGS="-DNTK_SV2_PRIV ..." adds build flags (A/B variants of the kernel)."""
 import collections
 import os
 import re
@@ -14,7 +15,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DNTK_KB_FIX", "-DNTK_KB_SV", "-DNTK_KB_SV2",
-                           "-DNTK_KB_HB=14", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "tools", "kbench.hip")],
+                           "-DNTK_KB_HB=14", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", out, os.path.join(root, "tools", "kbench.hip")] + os.environ.get("NTK_CENSUS_FLAGS", "").split(),
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
 name = f"_ZN3ntk12scan2_kernelILi{K}ELb1ELb1ELb0ELi14ELi0ELb0EEEvNS_8ScanArgsE"
@@ -24,6 +25,8 @@ lines = body.splitlines()
 # the tile loop: the Depth=2 loop (blocks whose label comment says "Depth=2"), i.e. from the first such label to the last
 # branch back into it
 idx = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:.*Depth=2", l)]
+if not idx:   # (builds without the prefetch branch inside the loop have a single-block tile loop)
+    idx = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:.*Parent Loop", l)]
 first, last = idx[0], idx[-1]
 end = last
 for i in range(last, len(lines)):
@@ -43,7 +46,7 @@ for b in blocks:
     if any("v_cmp_gt_i64" in l for l in b):
         continue
     loop += [l.split()[0] for l in b if l.startswith("\t") and not l.strip().startswith((";", "."))]
-    loop += [l.split()[0] for l in b if re.match(r"^(v_|s_|ds_|buffer_)", l)]   # inline-asm lines are not indented
+    loop += [l.split()[0] for l in b if re.match(r"^ *(v_|s_|ds_|buffer_)", l)]   # inline-asm lines are not tab-indented
 cnt = collections.Counter(loop)
 cls = collections.Counter()
 for m, c in cnt.items():
@@ -55,7 +58,7 @@ for m, c in cnt.items():
         cls["VMEM"] += c
     elif m.startswith("s_"):
         cls["SALU (incl. branches, waitcnt, nop)"] += c
-print(f"scan2_kernel<{K}, true, true, false, 14, 0>: tile loop, instructions per 992-base tile (steady state)")
+print(f"scan2_kernel<{K}, true, true, false, 14, 0> {os.environ.get('NTK_CENSUS_FLAGS', '')}: tile loop, instructions per 992-base tile (steady state)")
 for k_, v in sorted(cls.items()):
     print(f"  {k_:40s} {v}")
 for m, c in cnt.most_common():
