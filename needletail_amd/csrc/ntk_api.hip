@@ -22,7 +22,8 @@ using namespace ntk;
 // the sv2 builds (ntk_scan2.hip): nullptr when (k, flags) has none
 const void *ntk_pick_scan2(int k, bool tie_rc, bool accept_u);
 const void *ntk_pick_scan2_q(int k, bool canonical, bool tie_rc, bool accept_u);
-const void *ntk_pick_scan2_min(int k, int w, bool tie_rc, bool accept_u);
+const void *ntk_pick_scan2_min_a(int k, int w, bool tie_rc, bool accept_u, bool quality);   // ntk_scan2_min.o: k = 15..18
+const void *ntk_pick_scan2_min_b(int k, int w, bool tie_rc, bool accept_u, bool quality);   // ntk_scan2_min2.o: k = 19..22
 const void *ntk_pick_scan2_fwd(int k, bool accept_u);
 
 namespace {
@@ -115,6 +116,7 @@ struct ntk_ctx {
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
     std::map<std::pair<const void *, int>, int> occupancy;  // resident blocks per CU of a scan build at a block size
+    std::map<const void *, int> auto_threads;               // block size chosen for a reduce build (run_scan)
     // released batches are kept for re-use: pinned + device allocations cost milliseconds each, a parser thread's two
     // batches more than its share of a multi-GB input (tools/pipeline_bench.py).  Guarded: producer threads acquire and
     // release concurrently.
@@ -220,11 +222,14 @@ const void *pick_scan(const Mode &m, uint32_t k)
     }
 }
 
-// Fused windowed-minimizer builds of the sv2 kernel (ntk_tile.hpp lane_tile_sv2_min): w = 11 for 17 <= k <= 22 (configs[4] is
-// w = 11, k = 21), plus a few neighbours of that point; every other (k, w) takes the two-pass path (materialise + window-min).
-const void *pick_scan_min(const Mode &m, uint32_t k, uint32_t w)
+// Fused windowed-minimizer builds of the sv2 kernel (ntk_tile.hpp lane_tile_sv2_min): k = 15..22 x w = 9..12 with k + w - 1 <= 32,
+// and quality-masked builds of (21, 11) and (15, 10) (ntk_scan2.hip); every other (k, w) takes the two-pass path (materialise +
+// window-min).
+const void *pick_scan_min(const Mode &m, uint32_t k, uint32_t w, bool quality)
 {
-    return m.canon ? ntk_pick_scan2_min((int)k, (int)w, m.tie_rc, m.accept_u) : nullptr;
+    if (!m.canon) return nullptr;
+    if (const void *fn = ntk_pick_scan2_min_a((int)k, (int)w, m.tie_rc, m.accept_u, quality)) return fn;
+    return ntk_pick_scan2_min_b((int)k, (int)w, m.tie_rc, m.accept_u, quality);
 }
 
 int get_event(ntk_ctx *c, hipEvent_t *e)
@@ -247,13 +252,29 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
-    // every reduce-mode scan (any path, any k, with or without a quality stream, fused minimizers) is a scan2 build: 768 threads
-    const int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : 768);
-    const int waves_per_block = threads / 64;
     const void *fn = fused_min_fn ? fused_min_fn
                    : cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
                             : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));
     if (!fn) return NTK_ERR_BAD_ARG;
+    // every reduce-mode scan (any path, any k, with or without a quality stream, fused minimizers) is a scan2 build: 768 threads, two
+    // blocks per CU = 6 waves per SIMD, which needs <= 80 VGPRs.  A build above that (the quality-masked k = 28..30 builds: 82-84)
+    // would get ONE 768-thread block per CU; it runs 640-thread blocks instead (two per CU: 5 waves per SIMD).
+    int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : 768);
+    if (reduce && !c->launch_threads) {
+        auto it = c->auto_threads.find(fn);
+        if (it != c->auto_threads.end()) threads = it->second;
+        else {
+            int best_waves = 0;
+            for (int t : {768, 640, 512}) {
+                int blocks_cu = 0;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_cu, fn, t, 0));
+                if (blocks_cu > 2) blocks_cu = 2;
+                if (blocks_cu * t > best_waves) { best_waves = blocks_cu * t; threads = t; }
+            }
+            c->auto_threads[fn] = threads;
+        }
+    }
+    const int waves_per_block = threads / 64;
     const size_t lds = reduce ? 0 : (size_t)waves_per_block * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
     // auto grid: exactly the blocks that are resident at once (work is pulled, so a second round of blocks would only
     // zero and write out empty histograms: measured +1.5 % at config 2).  Reduce builds, 512-thread blocks (default): 4 per
@@ -1029,9 +1050,12 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     if (rc) return rc;
     if (!m.canon) return NTK_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
-    // fused build (one pass, nothing written to HBM) where one exists and no quality stream is involved
-    if (n && !(d_qual && quality_cutoff(p)) && !getenv("NTK_MINIMIZERS_TWO_PASS"))
-        if (const void *fn = pick_scan_min(m, p->k, w)) return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, nullptr, fn);
+    // fused build (one pass, nothing written to HBM) where one exists - with a quality stream: the quality-masked builds
+    if (n && !getenv("NTK_MINIMIZERS_TWO_PASS")) {
+        const bool masked = d_qual && quality_cutoff(p);
+        if (const void *fn = pick_scan_min(m, p->k, w, masked))
+            return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, masked ? d_qual : nullptr, fn);
+    }
     if (p->flags & NTK_FLAG_RESET) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
     if (n == 0) return NTK_OK;
     // Long inputs are scanned in chunks so that the scratch planes stay bounded (8 B per position: 2 GiB for the default

@@ -387,22 +387,17 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 template <int K, int HB>
 struct DevMasks2 {
     static constexpr bool kLight = Sv2Light<K, HB>::value;
-    uint64_t V[16];          // lane masks: window ending at byte j is emitted
-#ifdef NTK_SV2_LAZYV
-    uint64_t VA[16], VB[16]; // ... as V[j] = VA[j] & VB[j], the AND done by the masked region straight into exec (emit4c)
-#endif
-    uint64_t sum = 0;        // per-lane digests: sum of (hi:lo) (of the lo words when kLight); xor words of T and lo
-    uint64_t sum_b = 0;      // NTK_SV2_ACC2: second accumulator of the sum
-    uint32_t xT = 0, xlo = 0;
-    uint32_t cell = 0;       // LDS byte address of this thread's forward-strand counter
-    uint32_t rep = 0;        // word builds, K <= 6: this lane's histogram copy (see emit4w)
+    // Lane masks: the window ending at byte j is emitted where VA[j] & VB[j] is set.  The last AND of the mask algebra is left
+    // to the masked region, which forms exec with it (s_and_b64 exec, VA, VB): one scalar op instead of an AND and a move.
+    uint64_t VA[16], VB[16];
+    uint64_t sum = 0, sum2 = 0;   // per-lane sum of the lo words (of the whole word in the word builds): two accumulators, used alternately
+    uint32_t sumh = 0;            // builds that are not kLight (K >= 24): sum of the hi words mod 2^32 (all that 2^32 * sum needs mod 2^64: a full-rate add)
+    uint32_t xh = 0, xlo = 0;     // xor of the lo words; not kLight: xor of the hi words
+    uint32_t rep = 0;             // word builds, K <= 6: this lane's histogram copy (see emit_word)
     static constexpr int kWordCopies = K <= 6 ? (((1 << HB) >> (2 * (K <= 6 ? K : 0))) < 64 ? ((1 << HB) >> (2 * (K <= 6 ? K : 0))) : 64) : 1;
     uint32_t one = 1;
-    uint32_t nf_s = 0;       // NTK_SV2_NFWD_SALU: forward-strand count of the wave, scalar
-    uint32_t nf_v = 0;       // NTK_SV2_NFWD_VALU: forward-strand count of the lane
-    uint32_t app_m0 = 0;     // NTK_SV2_NFWD_APPEND: M0 for ds_append (LDS address of the wave's forward counter - 32768)
-    uint32_t app_sink = 0;   //   ... and the VGPR its (unused) return value lands in: owned for the whole kernel
-    uint32_t ptag = 0, pmask = 0;   // NTK_SV2_PRIV: (lane & 3) << 2, and 0xFFF0 held in a VGPR (an SGPR operand would make the op half-rate)
+    uint32_t nf_s = 0;            // forward-strand count of the WAVE (scalar: s_bcnt1 of the compare mask, no LDS op, no VALU op)
+    uint32_t nf_bits = 0;         // fused minimizers: per-lane sum of the chosen keys' strand bits
 
     template <int KM, class Enc>   // KM: good bases a window needs (K, or K + W - 1 for windowed minimizers)
     __device__ __forceinline__ void compute(const Enc &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
@@ -430,12 +425,9 @@ struct DevMasks2 {
         }
 #ifdef NTK_ABL_NOMASKALG
 #pragma unroll
-        for (int i = 0; i < 16; i++) V[i] = B[i];
+        for (int i = 0; i < 16; i++) { VA[i] = B[i]; VB[i] = ~0ull; }
 #else
-#if defined(NTK_SV2_LAZYV) && defined(NTK_SV2_CMPIN)
-        if constexpr (kLight && KM == K) window_masks_ab<KM>(B, VA, VB); else
-#endif
-        if constexpr (KM >= 17) window_masks<KM>(B, V); else window_masks1<KM>(B, V);
+        window_masks_ab_any<KM>(B, VA, VB);
 #endif
     }
 
@@ -446,33 +438,6 @@ struct DevMasks2 {
         asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
         return r;
     }
-    uint32_t nf_bits = 0;    // fused minimizers: sum of the chosen keys' strand bits
-
-    // fused minimizers: side effects of four window positions (prefix = the value's top 14 bits, lo = its low word, fb = strand bit)
-    template <class S>
-    __device__ __forceinline__ void emit_min4(S &, const int (&pos)[4], const uint32_t (&prefix)[4], const uint32_t (&lo)[4],
-                                              const uint32_t (&fb)[4])
-    {
-        uint32_t off[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) off[i] = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
-#define NTK_EMIN1(i)                                             \
-        "s_mov_b64 exec, %[V" #i "]\n"                          \
-        "ds_add_u32 %[o" #i "], %[one]\n"                       \
-        "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n"    \
-        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"                \
-        "v_add_u32 %[nf], %[nf], %[f" #i "]\n"
-        asm volatile(NTK_EMIN1(0) NTK_EMIN1(1) NTK_EMIN1(2) NTK_EMIN1(3) "s_mov_b64 exec, -1\n"
-                     : [sum] "+v"(sum), [xlo] "+v"(xlo), [nf] "+v"(nf_bits)
-                     : [o0] "v"(off[0]), [l0] "v"(lo[0]), [f0] "v"(fb[0]), [V0] "s"(V[pos[0]]),
-                       [o1] "v"(off[1]), [l1] "v"(lo[1]), [f1] "v"(fb[1]), [V1] "s"(V[pos[1]]),
-                       [o2] "v"(off[2]), [l2] "v"(lo[2]), [f2] "v"(fb[2]), [V2] "s"(V[pos[2]]),
-                       [o3] "v"(off[3]), [l3] "v"(lo[3]), [f3] "v"(fb[3]), [V3] "s"(V[pos[3]]),
-                       [one] "v"(one)
-                     : "memory", "vcc");
-#undef NTK_EMIN1
-    }
-
     // (min(a.hi16, b.lo16) : min(a.lo16, b.hi16)): the T words of positions j and j+8 share registers with crossed halves
     __device__ __forceinline__ uint32_t pk_min16_crossed(uint32_t a, uint32_t b) const
     {
@@ -480,11 +445,11 @@ struct DevMasks2 {
         asm("v_pk_min_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
         return r;
     }
-
-    // byte offset of a position's histogram cell (see emit4): LIGHT packs two positions' prefixes into one T word
-    __device__ __forceinline__ uint32_t cell_offset(uint32_t T, int i) const
+    // Byte offset of a histogram cell = the value's top HB bits, * 4.  (LDS atomics at an address that is not 4-byte aligned raise a
+    // memory violation on gfx950 - measured - so the low two bits have to be cleared.)  _hi: the prefix sits in bits 31:16 of T,
+    // _lo: in bits 15:0 (the second position of a packed minimum).
+    __device__ __forceinline__ uint32_t cell_offset_hi(uint32_t T) const
     {
-        if (kLight && i >= 2) return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu);
         if (HB == 14) {
             uint32_t off;
             const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
@@ -493,371 +458,246 @@ struct DevMasks2 {
         }
         return (T >> 18) & 0x3FFCu;
     }
+    __device__ __forceinline__ uint32_t cell_offset_lo(uint32_t T) const { return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu); }
 
-    // Forward-only builds (lane_tile_sv2_fwd): emit4 without the strand counter.
-    template <class S>
-    __device__ __forceinline__ void emit4_fwd(S &, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
-    {
-        uint64_t val[4];
-        uint32_t off[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) { val[i] = ((uint64_t)hi[i] << 32) | lo[i]; off[i] = cell_offset(T[i], i); }
-        if constexpr (kLight) {
-#define NTK_EMITF(i)                                             \
-        "s_mov_b64 exec, %[V" #i "]\n"                          \
-        "ds_add_u32 %[o" #i "], %[one]\n"                       \
-        "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n"    \
-        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
-            asm volatile(NTK_EMITF(0) NTK_EMITF(1) NTK_EMITF(2) NTK_EMITF(3) "s_mov_b64 exec, -1\n"
-                         : [sum] "+v"(sum), [xlo] "+v"(xlo)
-                         : [o0] "v"(off[0]), [l0] "v"(lo[0]), [V0] "s"(V[pos[0]]), [o1] "v"(off[1]), [l1] "v"(lo[1]), [V1] "s"(V[pos[1]]),
-                           [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[pos[2]]), [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[pos[3]]),
-                           [one] "v"(one)
-                         : "memory", "vcc");
-#undef NTK_EMITF
-        } else {
-#define NTK_EMITF(i)                                             \
-        "s_mov_b64 exec, %[V" #i "]\n"                          \
-        "ds_add_u32 %[o" #i "], %[one]\n"                       \
-        "v_lshl_add_u64 %[sum], %[v" #i "], 0, %[sum]\n"        \
-        "v_xor_b32 %[xT], %[xT], %[T" #i "]\n"                  \
-        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
-            asm volatile(NTK_EMITF(0) NTK_EMITF(1) NTK_EMITF(2) NTK_EMITF(3) "s_mov_b64 exec, -1\n"
-                         : [sum] "+v"(sum), [xT] "+v"(xT), [xlo] "+v"(xlo)
-                         : [o0] "v"(off[0]), [v0] "v"(val[0]), [l0] "v"(lo[0]), [T0] "v"(T[0]), [V0] "s"(V[pos[0]]),
-                           [o1] "v"(off[1]), [v1] "v"(val[1]), [l1] "v"(lo[1]), [T1] "v"(T[1]), [V1] "s"(V[pos[1]]),
-                           [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[pos[2]]),
-                           [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[pos[3]]),
-                           [one] "v"(one)
-                         : "memory", "vcc");
-#undef NTK_EMITF
-        }
-    }
-
-    // Word builds (K <= 16, lane_tile_sv2w): v = the chosen value, left-aligned; cell = its top HB bits.
-    template <bool FWD_ONLY, class S>
-    __device__ __forceinline__ void emit4w(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&v)[4])
-    {
-        uint32_t off[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            // K <= 6: 4^K bins do not fill the cells: the lane's copy number (rep = lane mod kWordCopies) goes on top of the value, so
-            // that the lanes of a wave do not queue up on a handful of cells.  The left-aligned word has zeros below the value:
-            // one funnel shift yields (rep : value : 00), the 4-byte-aligned offset of cell rep * 4^K + value.
-            if constexpr (K <= 6) off[i] = alignbit(rep, v[i], 30 - 2 * K);
-            else off[i] = cell_offset(v[i], 0);
-        }
-#define NTK_EMITW(i)                                             \
-        "s_mov_b64 exec, %[V" #i "]\n"                          \
-        "ds_add_u32 %[o" #i "], %[one]\n"                       \
-        "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n"    \
-        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
-#define NTK_EMITWF(i) NTK_EMITW(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n" "ds_add_u32 %[cell], %[one]\n"
-        if constexpr (FWD_ONLY) {
-            asm volatile(NTK_EMITW(0) NTK_EMITW(1) NTK_EMITW(2) NTK_EMITW(3) "s_mov_b64 exec, -1\n"
-                         : [sum] "+v"(sum), [xlo] "+v"(xlo)
-                         : [o0] "v"(off[0]), [l0] "v"(v[0]), [V0] "s"(V[pos[0]]), [o1] "v"(off[1]), [l1] "v"(v[1]), [V1] "s"(V[pos[1]]),
-                           [o2] "v"(off[2]), [l2] "v"(v[2]), [V2] "s"(V[pos[2]]), [o3] "v"(off[3]), [l3] "v"(v[3]), [V3] "s"(V[pos[3]]),
-                           [one] "v"(one)
-                         : "memory", "vcc");
-        } else {
-            uint64_t F[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) F[i] = __builtin_amdgcn_ballot_w64(fwd[i]);   // the compare's own SGPR pair
-            asm volatile(NTK_EMITWF(0) NTK_EMITWF(1) NTK_EMITWF(2) NTK_EMITWF(3) "s_mov_b64 exec, -1\n"
-                         : [sum] "+v"(sum), [xlo] "+v"(xlo)
-                         : [o0] "v"(off[0]), [l0] "v"(v[0]), [V0] "s"(V[pos[0]]), [F0] "s"(F[0]),
-                           [o1] "v"(off[1]), [l1] "v"(v[1]), [V1] "s"(V[pos[1]]), [F1] "s"(F[1]),
-                           [o2] "v"(off[2]), [l2] "v"(v[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
-                           [o3] "v"(off[3]), [l3] "v"(v[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
-                           [cell] "v"(cell), [one] "v"(one)
-                         : "memory", "vcc", "scc");
-        }
-#undef NTK_EMITWF
-#undef NTK_EMITW
-    }
-
-    // NTK_SV2_CMPIN (LIGHT builds): emit4 with the strand compare and the lo select INSIDE the masked region.  Under exec = V the
-    // compare's mask is already F & V (inactive lanes compare as 0), so the forward count needs no s_and: it is either one more
-    // exec move + an LDS op (own cell, or ds_append with NTK_SV2_NFWD_APPEND), or two scalar ops and no LDS op at all
-    // (NTK_SV2_NFWD_SCNT: s_bcnt1 + s_add).  ft / rt: the T words, fl / rl: the lo candidates, off from the packed minimum as in emit4.
-    template <bool TIE_RC_, int N, class S>   // N = 4 or 8 positions per masked region (8: half as many exec restores and group sums)
-    __device__ __forceinline__ void emit4c(S &, const int (&pos)[N], const uint32_t (&ft)[N], const uint32_t (&rt)[N], const uint32_t (&fl)[N],
-                                           const uint32_t (&rl)[N], const uint32_t (&off)[N])
-    {
-        static_assert(N == 4 || N == 8, "4 or 8 positions per region");
-        uint32_t t0, t1, t2, t3;
-        uint64_t sd;
-#if defined(NTK_SV2_NFWD_SCNT)
-#define NTK_C_NFWD "s_bcnt1_i32_b64 %[cn], vcc\n s_add_u32 %[nf], %[nf], %[cn]\n"
-#define NTK_C_NFWD_FIRST "s_bcnt1_i32_b64 %[nf], vcc\n"   // (the group's first position starts the group's count)
-#define NTK_C_OUT , [nf] "=&s"(nf_grp), [cn] "=&s"(cn)
-#define NTK_C_IN [one] "v"(one)
-#define NTK_C_PRE ""
-        uint32_t cn, nf_grp;
-#elif defined(NTK_SV2_NFWD_APPEND)
-#define NTK_C_NFWD "s_mov_b64 exec, vcc\n ds_append %[apd] offset:32768\n"
-#define NTK_C_OUT , [apd] "+v"(app_sink)
-#define NTK_C_IN [one] "v"(one), [m0v] "s"(app_m0)
-#define NTK_C_PRE "s_mov_b32 m0, %[m0v]\n"
-#elif defined(NTK_SV2_NFWD_VADDC)
-        // per-lane forward count on the VALU without an exec change: nf_v += vcc (the carry-in of an add with 0)
-#define NTK_C_NFWD "v_addc_co_u32 %[nfv], %[sd], 0, %[nfv], vcc\n"
-#define NTK_C_OUT , [nfv] "+v"(nf_v)
-#define NTK_C_IN [one] "v"(one)
-#define NTK_C_PRE ""
+    // ---- the masked regions ---------------------------------------------------------------------------------------------------
+    // One asm block holds the side effects of FOUR positions.  Per position: exec <- VA & VB (the validity of the window ending
+    // there); canonical builds: the strand compare - under that exec its mask is already "valid and forward", so the forward
+    // count is s_bcnt1 + s_add on the scalar unit - and the select of the lo word; the digests; the histogram atomic last.  exec
+    // is restored once per block.  Everything that does not depend on validity (window words, packed minimum, cell offsets) is
+    // computed outside under the full exec mask.  Operand roles: ft / rt = T words (first 16 bases) of the forward / reverse-
+    // complement value, fl / rl = their lo words, o = histogram cell offset, t = the chosen lo word.
+    // Measured against the round-2 region (exec move; atomic; mad; xor; exec AND; own-cell atomic): -6.5 % kernel time at k = 21
+    // (profiles/r03a): every exec write stalls the VALU for ~3 cycles and LDS ops are the most expensive instructions of the loop.
+#define NTK_R_EXEC(i) "s_and_b64 exec, %[A" #i "], %[B" #i "]\n"
+#define NTK_R_MASKS(i) [A##i] "s"(VA[pos[i]]), [B##i] "s"(VB[pos[i]])
+#ifdef NTK_ABL_NOLDS      // ablations of tools/kbench.hip (wrong results, same instruction stream otherwise)
+#define NTK_R_HIST(i) ""
 #else
-#define NTK_C_NFWD "s_mov_b64 exec, vcc\n ds_add_u32 %[cell], %[one]\n"
-#define NTK_C_OUT
-#define NTK_C_IN [one] "v"(one), [cell] "v"(cell)
-#define NTK_C_PRE ""
+#define NTK_R_HIST(i) "ds_add_u32 %[o" #i "], %[one]\n"
 #endif
-#define NTK_C_CMP(i) "v_cmp_lt_u32 vcc, %[ft" #i "], %[rt" #i "]\n"
-#define NTK_C_CMPE(i) "v_cmp_le_u32 vcc, %[ft" #i "], %[rt" #i "]\n"
-#ifdef NTK_SV2_LAZYV
-#define NTK_C_EXEC(i) "s_and_b64 exec, %[V" #i "], %[W" #i "]\n"
-#define NTK_C_VIN(i) [V##i] "s"(VA[pos[i]]), [W##i] "s"(VB[pos[i]])
-#else
-#define NTK_C_EXEC(i) "s_mov_b64 exec, %[V" #i "]\n"
-#define NTK_C_VIN(i) [V##i] "s"(V[pos[i]])
-#endif
-#ifndef NTK_C_NFWD_FIRST
-#define NTK_C_NFWD_FIRST NTK_C_NFWD
-#endif
-#ifdef NTK_SV2_CXOR_LDS   // the xor digest on the LDS pipe: the thread's own cell (free once the forward count is scalar)
-#define NTK_C_XOR(t) "ds_xor_b32 %[xcell], %[t" #t "]\n"
-#define NTK_C_XIN , [xcell] "v"(cell)
-#else
-#define NTK_C_XOR(t) "v_xor_b32 %[xlo], %[xlo], %[t" #t "]\n"
-#define NTK_C_XIN
-#endif
-#ifdef NTK_SV2_ACC2   // two accumulator pairs, alternating: no position waits for the previous position's 64-bit add
-#define NTK_C_SUM_0 "v_mad_u64_u32 %[sumA], %[sd], %[t0], 1, %[sumA]\n"
-#define NTK_C_SUM_1 "v_mad_u64_u32 %[sumB], %[sd], %[t1], 1, %[sumB]\n"
-#define NTK_C_SUM_2 "v_mad_u64_u32 %[sumA], %[sd], %[t2], 1, %[sumA]\n"
-#define NTK_C_SUM_3 "v_mad_u64_u32 %[sumB], %[sd], %[t3], 1, %[sumB]\n"
-#define NTK_C_SUM(t) NTK_C_SUM_##t
-#define NTK_C_SUMOPS [sumA] "+v"(sum), [sumB] "+v"(sum_b)
-#else
-#define NTK_C_SUM(t) "v_mad_u64_u32 %[sum], %[sd], %[t" #t "], 1, %[sum]\n"
-#define NTK_C_SUMOPS [sum] "+v"(sum)
-#endif
-#ifdef NTK_SV2_LDSLAST
-#define NTK_C_POS_(i, t, CMP, NF)                                           \
-        NTK_C_EXEC(i)                                                       \
-        CMP(i)                                                              \
-        "v_cndmask_b32 %[t" #t "], %[rl" #i "], %[fl" #i "], vcc\n"          \
-        NTK_C_SUM(t)                                                        \
-        NTK_C_XOR(t)                                                        \
-        "ds_add_u32 %[o" #i "], %[one]\n"                                   \
-        NF
-#else
-#define NTK_C_POS_(i, t, CMP, NF)                                           \
-        NTK_C_EXEC(i)                                                       \
-        CMP(i)                                                              \
-        "ds_add_u32 %[o" #i "], %[one]\n"                                   \
-        "v_cndmask_b32 %[t" #t "], %[rl" #i "], %[fl" #i "], vcc\n"          \
-        NTK_C_SUM(t)                                                        \
-        NTK_C_XOR(t)                                                        \
-        NF
-#endif
-#define NTK_C_POS(i, t, CMP) NTK_C_POS_(i, t, CMP, NTK_C_NFWD)
-#define NTK_C_POS0(i, t, CMP) NTK_C_POS_(i, t, CMP, NTK_C_NFWD_FIRST)
-#define NTK_C_PIN(i) [o##i] "v"(off[i]), [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_C_VIN(i)
-#define NTK_C_OUTS : NTK_C_SUMOPS, [xlo] "+v"(xlo), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sd] "=&s"(sd) NTK_C_OUT
-#define NTK_C_CLOB : "memory", "vcc", "scc"
-#define NTK_C_BODY4(CMP) NTK_C_PRE NTK_C_POS0(0, 0, CMP) NTK_C_POS(1, 1, CMP) NTK_C_POS(2, 2, CMP) NTK_C_POS(3, 3, CMP) "s_mov_b64 exec, -1\n"
-#define NTK_C_BODY8(CMP) NTK_C_PRE NTK_C_POS0(0, 0, CMP) NTK_C_POS(1, 1, CMP) NTK_C_POS(2, 2, CMP) NTK_C_POS(3, 3, CMP)            \
-                         NTK_C_POS(4, 0, CMP) NTK_C_POS(5, 1, CMP) NTK_C_POS(6, 2, CMP) NTK_C_POS(7, 3, CMP) "s_mov_b64 exec, -1\n"
-        if constexpr (N == 4) {
-            if constexpr (TIE_RC_)
-                asm volatile(NTK_C_BODY4(NTK_C_CMP) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
-            else
-                asm volatile(NTK_C_BODY4(NTK_C_CMPE) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
-        } else {
-            if constexpr (TIE_RC_)
-                asm volatile(NTK_C_BODY8(NTK_C_CMP) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_PIN(4), NTK_C_PIN(5),
-                             NTK_C_PIN(6), NTK_C_PIN(7), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
-            else
-                asm volatile(NTK_C_BODY8(NTK_C_CMPE) NTK_C_OUTS : NTK_C_PIN(0), NTK_C_PIN(1), NTK_C_PIN(2), NTK_C_PIN(3), NTK_C_PIN(4), NTK_C_PIN(5),
-                             NTK_C_PIN(6), NTK_C_PIN(7), NTK_C_IN NTK_C_XIN NTK_C_CLOB);
-        }
-#if defined(NTK_SV2_NFWD_SCNT)
-        nf_s += nf_grp;
-#endif
-#undef NTK_C_BODY8
-#undef NTK_C_BODY4
-#undef NTK_C_CLOB
-#undef NTK_C_OUTS
-#undef NTK_C_PIN
-#undef NTK_C_POS0
-#undef NTK_C_POS
-#undef NTK_C_POS_
-#undef NTK_C_NFWD_FIRST
-#undef NTK_C_SUM
-#undef NTK_C_SUM_0
-#undef NTK_C_SUM_1
-#undef NTK_C_SUM_2
-#undef NTK_C_SUM_3
-#undef NTK_C_SUMOPS
-#undef NTK_C_XOR
-#undef NTK_C_XIN
-#undef NTK_C_EXEC
-#undef NTK_C_VIN
-#undef NTK_C_CMPE
-#undef NTK_C_CMP
-#undef NTK_C_PRE
-#undef NTK_C_IN
-#undef NTK_C_OUT
-#undef NTK_C_NFWD
-    }
-    // histogram cell offsets of the two positions that share a packed minimum (hi half: position j, lo half: position j + 8)
-    __device__ __forceinline__ uint32_t cell_offset_hi(uint32_t T) const
-    {
-#ifdef NTK_SV2_PRIV
-        return and_or(T >> 16, pmask, ptag);
-#else
-        return cell_offset(T, 0);
-#endif
-    }
-    __device__ __forceinline__ uint32_t cell_offset_lo(uint32_t T) const
-    {
-#ifdef NTK_SV2_PRIV
-        return and_or(T, pmask, ptag);
-#else
-        return cell_offset(T, 2);
-#endif
-    }
-
-    // Side effects of four positions pos[0..3].  exec is full on entry (wave-uniform control flow, whole waves) and on exit.
-    // Per position, under the validity mask: histogram cell += 1 and the digests; under validity & strand mask: the
-    // thread's own forward counter += 1 (non-returning LDS atomics: no VALU work for either count).
-    // LIGHT: T[0], T[1] carry their position's histogram prefix in bits 31:16, T[2], T[3] in bits 15:0.
-    template <class S>
-    __device__ __forceinline__ void emit4(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4],
-                                          const uint32_t (&lo)[4])
-    {
-        uint64_t F[4], val[4];
-        uint32_t off[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            F[i] = __builtin_amdgcn_ballot_w64(fwd[i]);   // the compare's own SGPR pair
-            val[i] = ((uint64_t)hi[i] << 32) | lo[i];
-            // byte offset of the histogram cell: the value's top HB bits, * 4
-            // (LDS atomics at an address that is not 4-byte aligned raise a memory violation on gfx950 - measured - so the low
-            //  two bits have to be cleared)
-#ifdef NTK_SV2_PRIV
-            // cell = (the value's top 12 bits : lane & 3): the 32 lanes of an LDS lane group spread over four disjoint bank sets
-            if (kLight && i >= 2) off[i] = and_or(T[i], pmask, ptag);
-            else off[i] = and_or(T[i] >> 16, pmask, ptag);
-#else
-            if (kLight && i >= 2) off[i] = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
-            else if (HB == 14) {
-                const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
-                asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off[i]) : "s"(kMask), "v"(T[i]));
-            } else off[i] = (T[i] >> 18) & 0x3FFCu;
-#endif
-        }
-#ifdef NTK_ABL_NOLDS
-#define NTK_DS_HIST(i) ""
-#define NTK_DS_CELL ""
-#else
-#define NTK_DS_HIST(i) "ds_add_u32 %[o" #i "], %[one]\n"
-#define NTK_DS_CELL "ds_add_u32 %[cell], %[one]\n"
-#endif
-#ifdef NTK_ABL_NOEXEC
-#define NTK_SETEXEC(i) ""
-#else
-#define NTK_SETEXEC(i) "s_mov_b64 exec, %[V" #i "]\n"
-#endif
+#define NTK_R_CNT_FIRST "s_bcnt1_i32_b64 %[nf], vcc\n"                                   /* the block's first position starts its count */
+#define NTK_R_CNT "s_bcnt1_i32_b64 %[cn], vcc\n s_add_u32 %[nf], %[nf], %[cn]\n"
 #ifdef NTK_ABL_NODIGEST
-#define NTK_DIGEST_L(i) ""
+#define NTK_R_SUM_0(x) ""
+#define NTK_R_SUM_1(x) ""
+#define NTK_R_XOR(x) ""
 #else
-#ifdef NTK_SV2_XOR_LDS
-#define NTK_DIGEST_L(i) "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n" "ds_xor_b32 %[xcell], %[l" #i "]\n"
-#else
-#define NTK_DIGEST_L(i) "v_mad_u64_u32 %[sum], vcc, %[l" #i "], 1, %[sum]\n" "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"
+#define NTK_R_SUM_0(x) "v_mad_u64_u32 %[sumA], %[sd], " x ", 1, %[sumA]\n"
+#define NTK_R_SUM_1(x) "v_mad_u64_u32 %[sumB], %[sd], " x ", 1, %[sumB]\n"
+#define NTK_R_XOR(x) "v_xor_b32 %[xlo], %[xlo], " x "\n"
 #endif
-#endif
-#ifdef NTK_SV2_NFWD_APPEND
-#define NTK_M0_CLOB   /* (m0 is a reserved register: the compiler does not track it and does not use it in this kernel) */
-#else
-#define NTK_M0_CLOB
-#endif
-#if defined(NTK_ABL_NOEXEC)
-#define NTK_NFWD(i) NTK_DS_CELL
-#define NTK_NF_OUT
-#define NTK_CELL_IN [cell] "v"(cell), [one] "v"(one)
-#define NTK_NF_ZERO
-#elif defined(NTK_SV2_NFWD_VALU)
-#define NTK_NFWD(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n v_add_u32 %[nfv], %[nfv], %[one]\n"
-#define NTK_NF_OUT , [nfv] "+v"(nf_v)
-#define NTK_CELL_IN [one] "v"(one)
-#define NTK_NF_ZERO
-#elif defined(NTK_SV2_NFWD_APPEND)
-        // the forward-strand count on ds_append: LDS[M0 + offset] += popcount(exec), no address / data VGPRs to move
-#define NTK_NFWD(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n ds_append %[apd] offset:32768\n"
-#define NTK_NF_OUT , [apd] "+v"(app_sink)
-#define NTK_CELL_IN [one] "v"(one), [m0v] "s"(app_m0)
-#define NTK_NF_ZERO "s_mov_b32 m0, %[m0v]\n"
-#elif defined(NTK_SV2_NFWD_SALU)
-#define NTK_NFWD(i) "s_and_b64 vcc, %[V" #i "], %[F" #i "]\n s_bcnt1_i32_b64 vcc_lo, vcc\n s_add_u32 %[nf], %[nf], vcc_lo\n"
-#define NTK_NF_OUT , [nf] "=&s"(nf_grp)
-#define NTK_CELL_IN [one] "v"(one), [xcell] "v"(cell)
-#define NTK_NF_ZERO "s_mov_b32 %[nf], 0\n"
-        uint32_t nf_grp = 0;
-#else
-#define NTK_NF_ZERO
-#define NTK_NFWD(i) "s_and_b64 exec, %[V" #i "], %[F" #i "]\n" NTK_DS_CELL
-#define NTK_NF_OUT
-#define NTK_CELL_IN [cell] "v"(cell), [one] "v"(one)
-#endif
-        if constexpr (kLight) {
-#define NTK_EMIT1(i)                                             \
-        NTK_SETEXEC(i)                                           \
-        NTK_DS_HIST(i)                                           \
-        NTK_DIGEST_L(i)                                          \
-        NTK_NFWD(i)
-            asm volatile(NTK_NF_ZERO NTK_EMIT1(0) NTK_EMIT1(1) NTK_EMIT1(2) NTK_EMIT1(3) "s_mov_b64 exec, -1\n"
-                         : [sum] "+v"(sum), [xlo] "+v"(xlo) NTK_NF_OUT
-                         : [o0] "v"(off[0]), [l0] "v"(lo[0]), [V0] "s"(V[pos[0]]), [F0] "s"(F[0]),
-                           [o1] "v"(off[1]), [l1] "v"(lo[1]), [V1] "s"(V[pos[1]]), [F1] "s"(F[1]),
-                           [o2] "v"(off[2]), [l2] "v"(lo[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
-                           [o3] "v"(off[3]), [l3] "v"(lo[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
-                           NTK_CELL_IN
-                         : "memory", "vcc", "scc" NTK_M0_CLOB);
-#undef NTK_EMIT1
-        } else {
-#define NTK_EMIT1(i)                                             \
-        "s_mov_b64 exec, %[V" #i "]\n"                          \
-        NTK_DS_HIST(i)                                           \
-        "v_lshl_add_u64 %[sum], %[v" #i "], 0, %[sum]\n"        \
-        "v_xor_b32 %[xT], %[xT], %[T" #i "]\n"                  \
-        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"                \
-        NTK_NFWD(i)
-            asm volatile(NTK_NF_ZERO NTK_EMIT1(0) NTK_EMIT1(1) NTK_EMIT1(2) NTK_EMIT1(3) "s_mov_b64 exec, -1\n"
-                         : [sum] "+v"(sum), [xT] "+v"(xT), [xlo] "+v"(xlo) NTK_NF_OUT
-                         : [o0] "v"(off[0]), [v0] "v"(val[0]), [l0] "v"(lo[0]), [T0] "v"(T[0]), [V0] "s"(V[pos[0]]), [F0] "s"(F[0]),
-                           [o1] "v"(off[1]), [v1] "v"(val[1]), [l1] "v"(lo[1]), [T1] "v"(T[1]), [V1] "s"(V[pos[1]]), [F1] "s"(F[1]),
-                           [o2] "v"(off[2]), [v2] "v"(val[2]), [l2] "v"(lo[2]), [T2] "v"(T[2]), [V2] "s"(V[pos[2]]), [F2] "s"(F[2]),
-                           [o3] "v"(off[3]), [v3] "v"(val[3]), [l3] "v"(lo[3]), [T3] "v"(T[3]), [V3] "s"(V[pos[3]]), [F3] "s"(F[3]),
-                           NTK_CELL_IN
-                         : "memory", "vcc", "scc" NTK_M0_CLOB);
-#undef NTK_EMIT1
-        }
-#undef NTK_DS_HIST
-#undef NTK_DS_CELL
-#undef NTK_NFWD
-#undef NTK_NF_OUT
-#undef NTK_CELL_IN
-#undef NTK_NF_ZERO
-#undef NTK_M0_CLOB
-#undef NTK_SETEXEC
-#undef NTK_DIGEST_L
-#ifdef NTK_SV2_NFWD_SALU
+#define NTK_R_SUM_2(x) NTK_R_SUM_0(x)
+#define NTK_R_SUM_3(x) NTK_R_SUM_1(x)
+
+    // canonical, kLight (17 <= K <= 23 with the 14-bit histogram)
+    template <bool TIE_RC_, class S>
+    __device__ __forceinline__ void emit_canon(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
+                                               const uint32_t (&rl)[4], uint32_t Tm0, uint32_t Tm1)
+    {
+        static_assert(kLight, "light builds");
+        const uint32_t off[4] = {cell_offset_hi(Tm0), cell_offset_hi(Tm1), cell_offset_lo(Tm0), cell_offset_lo(Tm1)};
+        uint32_t t0, t1, t2, t3, cn, nf_grp;
+        uint64_t sd;
+#define NTK_R_POS(i, CMP, CNT)                                              \
+        NTK_R_EXEC(i)                                                       \
+        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
+        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_R_SUM_##i("%[t" #i "]")                                         \
+        NTK_R_XOR("%[t" #i "]")                                             \
+        NTK_R_HIST(i)                                                       \
+        CNT
+#define NTK_R_IN(i) [o##i] "v"(off[i]), [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_R_MASKS(i)
+#define NTK_R_BODY(CMP) NTK_R_POS(0, CMP, NTK_R_CNT_FIRST) NTK_R_POS(1, CMP, NTK_R_CNT) NTK_R_POS(2, CMP, NTK_R_CNT) NTK_R_POS(3, CMP, NTK_R_CNT) "s_mov_b64 exec, -1\n"
+#define NTK_R_OPS                                                                                                                        \
+        : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),           \
+          [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                                                                             \
+        : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one)                                                            \
+        : "memory", "vcc", "scc"
+        if constexpr (TIE_RC_) asm volatile(NTK_R_BODY("v_cmp_lt_u32") NTK_R_OPS);   // byte path: ties report the reverse complement (src/kmer.rs:124-128)
+        else asm volatile(NTK_R_BODY("v_cmp_le_u32") NTK_R_OPS);                     // bit path: ties stay forward (src/bitkmer.rs:136-143)
         nf_s += nf_grp;
-#endif
+#undef NTK_R_OPS
+#undef NTK_R_BODY
+#undef NTK_R_IN
+#undef NTK_R_POS
     }
+
+    // canonical, K >= 24: the hi word of the chosen value does not follow from the histogram cell, so the whole 64-bit value is summed
+    // (v_lshl_add_u64 on a register pair).  The pair has to be built by the compiler, i.e. OUTSIDE the asm block: strand compare
+    // (its mask F in an SGPR pair), T = min(ft, rt) - the chosen T word: equal T words mean equal values, ntk_tile.hpp -, the lo
+    // select, the hi word T >> (64 - 2K) and the cell all run under the full exec mask; the region keeps the side effects, and the
+    // forward count is s_and (F with the window's validity, which is exec) + s_bcnt1 + s_add.  (Measured, k = 31, profiles/r03a/wide_ab.txt: the
+    // select inside the region with separate sums of the lo and hi words costs 16 more VALU instructions per tile and is 4-8 % slower;
+    // these builds are VALU-bound at 235 instructions per tile - scalar count, LDS count and the round-2 region all run within 1 %.)
+    template <bool TIE_RC_, class S>
+    __device__ __forceinline__ void emit_canon_wide(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
+                                                    const uint32_t (&rl)[4])
+    {
+        static_assert(!kLight && K >= 17, "wide builds");
+        constexpr int SH = 64 - 2 * K;
+        uint32_t hi[4], lo[4], off[4], cn, nf_grp;
+        uint64_t F[4], val[4], fm;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool fwd = TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i];
+            F[i] = __builtin_amdgcn_ballot_w64(fwd);   // the compare's own SGPR pair
+            const uint32_t T = ft[i] < rt[i] ? ft[i] : rt[i];
+            lo[i] = fwd ? fl[i] : rl[i];
+            hi[i] = SH ? T >> SH : T;
+            off[i] = cell_offset_hi(T);
+            val[i] = ((uint64_t)hi[i] << 32) | lo[i];
+        }
+#define NTK_R_POS(i, CNT)                                                   \
+        NTK_R_EXEC(i)                                                       \
+        NTK_R_WSUM_##i("%[v" #i "]")                                        \
+        "v_xor_b32 %[xh], %[xh], %[h" #i "]\n"                              \
+        NTK_R_XOR("%[l" #i "]")                                             \
+        NTK_R_HIST(i)                                                       \
+        NTK_R_WFWD(i)                                                       \
+        CNT
+#define NTK_R_WSUM_0(x) "v_lshl_add_u64 %[sumA], " x ", 0, %[sumA]\n"
+#define NTK_R_WSUM_1(x) "v_lshl_add_u64 %[sumB], " x ", 0, %[sumB]\n"
+#define NTK_R_WSUM_2(x) NTK_R_WSUM_0(x)
+#define NTK_R_WSUM_3(x) NTK_R_WSUM_1(x)
+#define NTK_R_WFWD(i) "s_and_b64 %[fm], exec, %[F" #i "]\n"
+#define NTK_R_WCNT_FIRST "s_bcnt1_i32_b64 %[nf], %[fm]\n"
+#define NTK_R_WCNT "s_bcnt1_i32_b64 %[cn], %[fm]\n s_add_u32 %[nf], %[nf], %[cn]\n"
+#define NTK_R_IN(i) [o##i] "v"(off[i]), [v##i] "v"(val[i]), [h##i] "v"(hi[i]), [l##i] "v"(lo[i]), [F##i] "s"(F[i]), NTK_R_MASKS(i)
+        asm volatile(NTK_R_POS(0, NTK_R_WCNT_FIRST) NTK_R_POS(1, NTK_R_WCNT) NTK_R_POS(2, NTK_R_WCNT) NTK_R_POS(3, NTK_R_WCNT) "s_mov_b64 exec, -1\n"
+                     : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [xh] "+v"(xh), [nf] "=&s"(nf_grp), [cn] "=&s"(cn), [fm] "=&s"(fm)
+                     : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one)
+                     : "memory", "scc");
+        nf_s += nf_grp;
+#undef NTK_R_IN
+#undef NTK_R_WFWD
+#undef NTK_R_WCNT
+#undef NTK_R_WCNT_FIRST
+#undef NTK_R_WSUM_3
+#undef NTK_R_WSUM_2
+#undef NTK_R_WSUM_1
+#undef NTK_R_WSUM_0
+#undef NTK_R_POS
+    }
+
+    // Word builds (K <= 16, lane_tile_sv2w), canonical: f / r = the two candidate values, left-aligned; the chosen value is their
+    // minimum (formed outside), its top HB bits the cell; the compare inside the region only feeds the forward count.
+    // K <= 6: 4^K bins do not fill the cells: the lane's copy number (rep = lane mod kWordCopies) goes on top of the value, so that
+    // the lanes of a wave do not queue up on a handful of cells.  The left-aligned word has zeros below the value: one funnel
+    // shift yields (rep : value : 00), the 4-byte-aligned offset of cell rep * 4^K + value.
+    __device__ __forceinline__ uint32_t word_cell(uint32_t v) const
+    {
+        if constexpr (K <= 6) return alignbit(rep, v, 30 - 2 * K);
+        else return cell_offset_hi(v);
+    }
+    template <bool TIE_RC_, class S>
+    __device__ __forceinline__ void emit_word(S &, const int (&pos)[4], const uint32_t (&f)[4], const uint32_t (&r)[4])
+    {
+        uint32_t v[4], off[4], cn, nf_grp;
+        uint64_t sd;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[i] = f[i] < r[i] ? f[i] : r[i]; off[i] = word_cell(v[i]); }
+#define NTK_R_POS(i, CMP, CNT)                                              \
+        NTK_R_EXEC(i)                                                       \
+        CMP " vcc, %[f" #i "], %[r" #i "]\n"                                \
+        NTK_R_SUM_##i("%[v" #i "]")                                         \
+        NTK_R_XOR("%[v" #i "]")                                             \
+        NTK_R_HIST(i)                                                       \
+        CNT
+#define NTK_R_IN(i) [o##i] "v"(off[i]), [f##i] "v"(f[i]), [r##i] "v"(r[i]), [v##i] "v"(v[i]), NTK_R_MASKS(i)
+#define NTK_R_BODY(CMP) NTK_R_POS(0, CMP, NTK_R_CNT_FIRST) NTK_R_POS(1, CMP, NTK_R_CNT) NTK_R_POS(2, CMP, NTK_R_CNT) NTK_R_POS(3, CMP, NTK_R_CNT) "s_mov_b64 exec, -1\n"
+#define NTK_R_OPS                                                                                                                        \
+        : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                       \
+        : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one)                                                            \
+        : "memory", "vcc", "scc"
+        if constexpr (TIE_RC_) asm volatile(NTK_R_BODY("v_cmp_lt_u32") NTK_R_OPS);
+        else asm volatile(NTK_R_BODY("v_cmp_le_u32") NTK_R_OPS);
+        nf_s += nf_grp;
+#undef NTK_R_OPS
+#undef NTK_R_BODY
+#undef NTK_R_IN
+#undef NTK_R_POS
+    }
+
+    // One word per position, no strand: the forward-only word builds (v = the value, left-aligned), the forward-only kLight builds
+    // (lo word; T carries the prefixes of positions j and j + 8 in its halves) and the fused minimizers (lo word of the window's
+    // minimizer, fb = its strand bit, summed per lane).
+    template <bool WITH_BITS>
+    __device__ __forceinline__ void region_plain(const int (&pos)[4], const uint32_t (&off)[4], const uint32_t (&w)[4], const uint32_t (&fb)[4])
+    {
+        uint64_t sd;
+#define NTK_R_POS(i, BITS)                                                  \
+        NTK_R_EXEC(i)                                                       \
+        NTK_R_SUM_##i("%[w" #i "]")                                         \
+        NTK_R_XOR("%[w" #i "]")                                             \
+        BITS                                                                \
+        NTK_R_HIST(i)
+#define NTK_R_IN(i) [o##i] "v"(off[i]), [w##i] "v"(w[i]), [f##i] "v"(fb[i]), NTK_R_MASKS(i)
+        if constexpr (WITH_BITS)
+            asm volatile(NTK_R_POS(0, "v_add_u32 %[nfb], %[nfb], %[f0]\n") NTK_R_POS(1, "v_add_u32 %[nfb], %[nfb], %[f1]\n")
+                         NTK_R_POS(2, "v_add_u32 %[nfb], %[nfb], %[f2]\n") NTK_R_POS(3, "v_add_u32 %[nfb], %[nfb], %[f3]\n") "s_mov_b64 exec, -1\n"
+                         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [nfb] "+v"(nf_bits), [sd] "=&s"(sd)
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
+        else
+            asm volatile(NTK_R_POS(0, "") NTK_R_POS(1, "") NTK_R_POS(2, "") NTK_R_POS(3, "") "s_mov_b64 exec, -1\n"
+                         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [sd] "=&s"(sd)
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
+#undef NTK_R_IN
+#undef NTK_R_POS
+    }
+    template <class S>
+    __device__ __forceinline__ void emit_word_fwd(S &, const int (&pos)[4], const uint32_t (&v)[4])
+    {
+        const uint32_t off[4] = {word_cell(v[0]), word_cell(v[1]), word_cell(v[2]), word_cell(v[3])};
+        region_plain<false>(pos, off, v, v);
+    }
+    template <class S>
+    __device__ __forceinline__ void emit_min4(S &, const int (&pos)[4], const uint32_t (&prefix)[4], const uint32_t (&lo)[4], const uint32_t (&fb)[4])
+    {
+        uint32_t off[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) off[i] = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
+        region_plain<true>(pos, off, lo, fb);
+    }
+    // Forward-only builds, 17 <= K <= 32 (lane_tile_sv2_fwd).  kLight: T[0], T[1] carry their position's prefix in bits 31:16 and
+    // that of T[2], T[3] (the same registers) in bits 15:0.
+    template <class S>
+    __device__ __forceinline__ void emit_fwd(S &, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&lo)[4])
+    {
+        if constexpr (kLight) {
+            const uint32_t off[4] = {cell_offset_hi(T[0]), cell_offset_hi(T[1]), cell_offset_lo(T[2]), cell_offset_lo(T[3])};
+            region_plain<false>(pos, off, lo, lo);
+        } else {
+            constexpr int SH = 64 - 2 * K;
+            uint32_t hi[4], off[4];
+            uint64_t sd;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { hi[i] = SH ? T[i] >> SH : T[i]; off[i] = cell_offset_hi(T[i]); }
+#define NTK_R_POS(i)                                                        \
+        NTK_R_EXEC(i)                                                       \
+        NTK_R_SUM_##i("%[l" #i "]")                                         \
+        NTK_R_XOR("%[l" #i "]")                                             \
+        "v_add_u32 %[sumh], %[sumh], %[h" #i "]\n"                           \
+        "v_xor_b32 %[xh], %[xh], %[h" #i "]\n"                              \
+        NTK_R_HIST(i)
+#define NTK_R_IN(i) [o##i] "v"(off[i]), [l##i] "v"(lo[i]), [h##i] "v"(hi[i]), NTK_R_MASKS(i)
+            asm volatile(NTK_R_POS(0) NTK_R_POS(1) NTK_R_POS(2) NTK_R_POS(3) "s_mov_b64 exec, -1\n"
+                         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [sumh] "+v"(sumh), [xlo] "+v"(xlo), [xh] "+v"(xh), [sd] "=&s"(sd)
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
+#undef NTK_R_IN
+#undef NTK_R_POS
+        }
+    }
+#undef NTK_R_XOR
+#undef NTK_R_SUM_3
+#undef NTK_R_SUM_2
+#undef NTK_R_SUM_1
+#undef NTK_R_SUM_0
+#undef NTK_R_CNT
+#undef NTK_R_CNT_FIRST
+#undef NTK_R_HIST
+#undef NTK_R_MASKS
+#undef NTK_R_EXEC
 };
 
 struct NoSink {};
@@ -876,9 +716,9 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     constexpr int kCells = 1 << HB;
     // One LDS object, histogram first: the masked regions address the histogram with the cell's byte offset alone, which
     // is only right while the histogram sits at LDS address 0 (checked below; the kernel has no other LDS object).
-    struct Lds { uint32_t hist[kCells]; uint32_t nfwd[1024]; uint64_t red[16 * 6]; uint32_t nfw[16]; };   // nfw: per-wave forward counters (ds_append)
+    struct Lds { uint32_t hist[kCells]; uint64_t red[16 * 6]; };
     __shared__ Lds L;
-    uint32_t *const s_hist = L.hist, *const s_nfwd = L.nfwd;  // nfwd: per-thread forward-strand counters
+    uint32_t *const s_hist = L.hist;
     uint64_t *const s_red = L.red;
     if ((uint32_t)(uintptr_t)&L.hist[0] != 0u) __builtin_trap();
 
@@ -889,8 +729,6 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     if (a.zero_acc && blockIdx.x == 0)   // NTK_FLAG_RESET: the accumulators start from zero (see ScanArgs)
         for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
     for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
-    s_nfwd[threadIdx.x] = 0;
-    if (threadIdx.x < 16) L.nfw[threadIdx.x] = 0;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -905,15 +743,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     DevXL xl;
     DevMasks2<K, HB> mp;
     NoSink sink;
-    mp.cell = (uint32_t)(uintptr_t)&s_nfwd[threadIdx.x];   // LDS byte address: the asm blocks address LDS directly
     mp.rep = lane & (uint32_t)(DevMasks2<K, HB>::kWordCopies - 1);
-#ifdef NTK_SV2_NFWD_APPEND
-    mp.app_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&L.nfw[wave] - 32768u);   // ds_append: M0[15:0] + offset:32768
-#endif
-#ifdef NTK_SV2_PRIV
-    mp.ptag = (lane & 3u) << 2; mp.pmask = 0xFFF0u;
-    asm volatile("" : "+v"(mp.pmask));   // keep the constant in a VGPR (v_bitop3 with an SGPR operand is half-rate)
-#endif
 
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
@@ -952,12 +782,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         uint32_t fl_code = lane * 0x9E3779B9u + r0, fl_rcode = ~fl_code, fl_step = 0x85EBCA6Bu + lane;
         asm volatile("" : "+v"(fl_step));
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            mp.V[i] = ~3ull;
-#ifdef NTK_SV2_LAZYV
-            mp.VA[i] = ~3ull; mp.VB[i] = ~0ull;
-#endif
-        }
+        for (int i = 0; i < 16; i++) { mp.VA[i] = ~3ull; mp.VB[i] = ~0ull; }
 #endif
         auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r) {
             const bool tail = r >= a.tail_tile_rel;
@@ -1018,33 +843,15 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #endif
     // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
-    constexpr int S = WORD ? 0 : 64 - 2 * K;
-    uint64_t sum = mp.sum + mp.sum_b, xr = WORD ? (uint64_t)mp.xlo : ((uint64_t)(S ? mp.xT >> S : mp.xT) << 32) | mp.xlo, nf, nv = 0;
+    // sum: the two alternating accumulators of the lo words, plus (K >= 24) the hi words' sum; xor: lo words, and (K >= 24) T words
+    uint64_t sum = mp.sum + mp.sum2 + ((uint64_t)mp.sumh << 32);
+    uint64_t xr = (WORD || LIGHT) ? (uint64_t)mp.xlo : ((uint64_t)mp.xh << 32) | mp.xlo, nf, nv = 0;
     uint64_t shi = 0, xf = 0;   // LIGHT: high parts of the digests, from the histogram
     uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
-#if defined(NTK_SV2_XOR_LDS) || defined(NTK_SV2_CXOR_LDS)
-    mp.xlo = s_nfwd[threadIdx.x];   // the cell holds the lane's xor of lo words
-#endif
-#if defined(NTK_SV2_NFWD_APPEND)
-    asm volatile("" : : "v"(mp.app_sink));   // the ds_append return register stayed reserved up to here
-    nf = 0;   // (read after the barrier below: the wave's LDS counter)
-#elif defined(NTK_SV2_NFWD_VALU) || defined(NTK_SV2_NFWD_VADDC)
-    nf = mp.nf_v;
-#elif defined(NTK_SV2_NFWD_SALU) || defined(NTK_SV2_NFWD_SCNT)
-    nf = lane == 0 ? mp.nf_s : 0u;
-#else
-    nf = s_nfwd[threadIdx.x];
-#endif
+    nf = lane == 0 ? mp.nf_s : 0u;          // the wave's forward-strand count lives in a scalar register
     if constexpr (W > 0) nf = mp.nf_bits;   // strand bits of the chosen keys: forward count (TIE_RC) or rc count
     __syncthreads();
-#if defined(NTK_SV2_NFWD_APPEND)
-    if constexpr (W == 0 && !FWD && !WORD) nf = lane == 0 ? L.nfw[wave] : 0u;
-#endif
-#ifdef NTK_SV2_PRIV
-    constexpr int HBE = (LIGHT && W == 0 && !FWD) ? 12 : HB;   // bits of the value's prefix in a cell index (the rest: lane copies)
-#else
     constexpr int HBE = HB;
-#endif
     for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
         uint32_t tot = 0;
         if constexpr (K <= 6) {   // word builds up to 6 bases: cell = copy * 4^K + value, bin = value

@@ -62,18 +62,31 @@ const void *ntk_pick_scan2_q(int k, bool canonical, bool tie_rc, bool accept_u)
 }
 
 #else
-// (compiled a second time with -DNTK_SCAN2_MIN_BUILDS and the DEFAULT scheduler into ntk_scan2_min.o: the iterative one crashes the
-// register allocator on these builds)
-// Fused windowed-minimizer builds (ntk_tile.hpp lane_tile_sv2_min): w = 11 for 17 <= k <= 22 (configs[4] is w = 11, k = 21), plus a
-// few neighbours of that point; every other (k, w) takes the two-pass path (materialise + window-min).
-const void *ntk_pick_scan2_min(int k, int w, bool tie_rc, bool accept_u)
+// (compiled with -DNTK_SCAN2_MIN_BUILDS=1 / =2 and the DEFAULT scheduler into ntk_scan2_min.o / ntk_scan2_min2.o: the iterative one
+// crashes the register allocator on these builds)
+// Fused windowed-minimizer builds (ntk_tile.hpp lane_tile_sv2_min): every k = 15..22 x w = 9..12 with k + w - 1 <= 32 - the sketch
+// parameters in common use ((15, 10), (19, 10), (21, 11): configs[4]) and their neighbours - plus quality-masked builds of
+// (21, 11) and (15, 10); every other (k, w) takes the two-pass path (materialise + window-min).
+#define NTK_PICK_MIN(KF, WF, T, U, Q) if (k == KF && w == WF && tie_rc == T && accept_u == U && quality == Q) return (const void *)&scan2_kernel<KF, T, U, Q, kScan2HistBits, WF>;
+#define NTK_PICK_MIN4(KF, WF, Q) NTK_PICK_MIN(KF, WF, false, false, Q) NTK_PICK_MIN(KF, WF, false, true, Q) NTK_PICK_MIN(KF, WF, true, false, Q) NTK_PICK_MIN(KF, WF, true, true, Q)
+#define NTK_PICK_MINW(KF) NTK_PICK_MIN4(KF, 9, false) NTK_PICK_MIN4(KF, 10, false) NTK_PICK_MIN4(KF, 11, false) NTK_PICK_MIN4(KF, 12, false)
+#if NTK_SCAN2_MIN_BUILDS == 1
+const void *ntk_pick_scan2_min_a(int k, int w, bool tie_rc, bool accept_u, bool quality)
 {
-#define NTK_PICK_MIN(KF, WF, T, U) if (k == KF && w == WF && tie_rc == T && accept_u == U) return (const void *)&scan2_kernel<KF, T, U, false, kScan2HistBits, WF>;
-#define NTK_PICK_MIN4(KF, WF) NTK_PICK_MIN(KF, WF, false, false) NTK_PICK_MIN(KF, WF, false, true) NTK_PICK_MIN(KF, WF, true, false) NTK_PICK_MIN(KF, WF, true, true)
-    NTK_PICK_MIN4(17, 11) NTK_PICK_MIN4(18, 11) NTK_PICK_MIN4(19, 11) NTK_PICK_MIN4(20, 11) NTK_PICK_MIN4(21, 11) NTK_PICK_MIN4(22, 11)
-    NTK_PICK_MIN4(21, 9) NTK_PICK_MIN4(21, 10) NTK_PICK_MIN4(21, 12)
-#undef NTK_PICK_MIN4
-#undef NTK_PICK_MIN
+    NTK_PICK_MINW(15) NTK_PICK_MINW(16) NTK_PICK_MINW(17) NTK_PICK_MINW(18)
+    NTK_PICK_MIN4(15, 10, true)
     return nullptr;
 }
+#else
+const void *ntk_pick_scan2_min_b(int k, int w, bool tie_rc, bool accept_u, bool quality)
+{
+    NTK_PICK_MINW(19) NTK_PICK_MINW(20) NTK_PICK_MINW(21)
+    NTK_PICK_MIN4(22, 9, false) NTK_PICK_MIN4(22, 10, false) NTK_PICK_MIN4(22, 11, false)
+    NTK_PICK_MIN4(21, 11, true)
+    return nullptr;
+}
+#endif
+#undef NTK_PICK_MINW
+#undef NTK_PICK_MIN4
+#undef NTK_PICK_MIN
 #endif

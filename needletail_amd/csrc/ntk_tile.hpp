@@ -534,6 +534,66 @@ NTK_HD void window_masks1(const uint64_t (&G)[16], uint64_t (&OK)[16])
     for (int j = K; j < 16; j++) OK[j] &= ~3ull;
 }
 
+// window_masks1 with the last AND left open (OK[j] = A[j] & B[j], see window_masks_ab): the scan2 builds form exec with it.
+template <int K>
+NTK_HD void window_masks1_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
+{
+    static_assert(K >= 1 && K <= 16, "k <= 16 variant");
+    constexpr uint64_t kAll = ~0ull, kNoHalo = ~3ull;   // halo lanes 0/1 emit nothing
+    if constexpr (K >= 9) {
+        uint64_t P[16], S[16], S8[8], P8[16];
+        P[0] = G[0] & kNoHalo;            // cleared in every window that contains own byte 0 ...
+#pragma unroll
+        for (int j = 1; j < 16; j++) P[j] = P[j - 1] & G[j];
+        S[15] = G[15];
+#pragma unroll
+        for (int i = 14; i >= 0; i--) S[i] = S[i + 1] & G[i];
+        S8[7] = G[7];
+#pragma unroll
+        for (int i = 6; i >= 1; i--) S8[i] = S8[i + 1] & G[i];
+        P8[8] = G[8] & kNoHalo;           // ... in every inside window (they all contain byte 8) ...
+#pragma unroll
+        for (int j = 9; j < 15; j++) P8[j] = P8[j - 1] & G[j];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int a = j - K + 1;   // first byte of the window (negative: in the previous lane)
+            if (a < 0) { A[j] = P[j]; B[j] = S[(16 + a) & 15] << 1; }
+            else if (a == 0) { A[j] = P[j]; B[j] = kAll; }
+            else if (j == 15) { A[j] = S[a & 15]; B[j] = kNoHalo; }     // ... and explicitly in the suffix windows
+            else { A[j] = S8[a & 7]; B[j] = P8[j & 15]; }
+        }
+        return;
+    }
+    constexpr int P = K >= 8 ? 8 : (K >= 4 ? 4 : (K >= 2 ? 2 : 1));  // largest power of two <= K
+    uint64_t E[32];  // E[16 + i] = own byte i, E[i] = previous lane's byte i (a lane shift is a 1-bit shift of the mask)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { E[16 + i] = G[i]; E[i] = G[i] << 1; }
+    E[16] &= kNoHalo;  // cleared in own byte 0 (part of the windows ending at j <= K-1) ...
+#pragma unroll
+    for (int w = 1; w < P; w *= 2) {   // E[e] becomes the AND of the 2w entries ending at e
+#pragma unroll
+        for (int e = 31; e >= 2 * w - 1; e--) E[e] &= E[e - w];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        // ... and explicitly in the windows that do not contain own byte 0 (j >= K)
+        if constexpr (K > P) {
+            A[j] = E[16 + j];
+            B[j] = j >= K ? (E[16 + j - (K - P)] & kNoHalo) : E[16 + j - (K - P)];
+        } else {
+            A[j] = E[16 + j];
+            B[j] = j >= K ? kNoHalo : kAll;
+        }
+    }
+}
+
+// OK[j] = A[j] & B[j] for any window length 1 .. 32
+template <int KM>
+NTK_HD void window_masks_ab_any(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
+{
+    if constexpr (KM >= 17) window_masks_ab<KM>(G, A, B); else window_masks1_ab<KM>(G, A, B);
+}
+
 template <bool CANON, bool TIE_RC, int K, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv1(Sink &sink, XL &xl, MP &mp, const EncSV &en)
 {
@@ -624,7 +684,7 @@ template <bool TIE_RC, int K, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
 {
     static_assert(K >= 17 && K <= 32, "sv2 is the 64-bit-value path");
-    constexpr int D = K - 16, S = 64 - 2 * K;
+    constexpr int D = K - 16;
     constexpr bool LIGHT = MP::kLight;
     uint32_t fw[16 + D], rw[16 + D];   // index g + D
     const uint32_t c1 = xl.prev(kSlotCode, code), r1 = xl.prev(kSlotRcode, rcode);
@@ -637,80 +697,30 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
     }
     // The previous lane's forward words 16-g (its window ending g bases before our base 0) are T words here: compared and
     // min-ed, so they are fetched once (DPP move).  Its reverse-complement words are only ever the lo candidate of one
-    // position: they are fetched inside that position's select (select_prev: v_cndmask_b32_dpp on the device).
+    // position and are fetched where that position is handled.
 #pragma unroll
-    for (int g = 2; g <= D; g++) {
-#ifdef NTK_ABL_HALFIMPORTS   // what-if (WRONG results): every other cross-lane move dropped - what 32 bytes per lane could save at most
-        if (g & 1) { fw[D - g] = fw[D + 16 - g]; continue; }
-#endif
-        fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
-    }
+    for (int g = 2; g <= D; g++) fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
     // Positions are taken in groups {jp, jp+1, jp+8, jp+9}: the T words of positions j and j+8 sit in ONE register on
     // either strand - fw[j-D] = (top half of T_fwd(j) : top half of T_fwd(j+8)), rw[j+8] = (top half of T_rc(j+8) : top half
-    // of T_rc(j)) - so in the LIGHT build one packed 16-bit min with crossed halves yields both histogram prefixes.
+    // of T_rc(j)) - so in the LIGHT build one packed 16-bit min with crossed halves yields both histogram prefixes
+    // (min of the halves == half of the min, whatever the tie rule).
+    // The strand compare and the select of the lo word happen inside the group's masked region (MP::emit_canon / emit_canon_wide).
 #pragma unroll
     for (int jp = 0; jp < 8; jp += 2) {
         const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
-        uint32_t T[4], lo[4], hi[4];
-        bool fwd[4];
-#if defined(NTK_SV2_CMPIN) && defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (LIGHT) {   // compare + select inside the masked region (DevMasks2::emit4c)
-#ifdef NTK_SV2_G8
-            constexpr int N = 8;
-            if (jp & 2) continue;   // positions {jp .. jp+3, jp+8 .. jp+11}, jp = 0, 4
-            const int ps[N] = {jp, jp + 1, jp + 2, jp + 3, jp + 8, jp + 9, jp + 10, jp + 11};
-#else
-            constexpr int N = 4;
-            const int ps[N] = {jp, jp + 1, jp + 8, jp + 9};
-#endif
-            uint32_t ftw[N], rtw[N], flw[N], rlw[N], off[N];
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                const int j = ps[i];
-                ftw[i] = fw[j]; rtw[i] = rw[D + j]; flw[i] = fw[D + j];
-                rlw[i] = j - D >= -1 ? rw[j] : xl.prev(kSlotRw + 16 + j - D, rw[16 + j]);
-            }
-#pragma unroll
-            for (int i = 0; i < N / 2; i++) {   // positions ps[i] and ps[i] + 8 share one packed minimum
-                const uint32_t Tm = mp.pk_min16_crossed(fw[ps[i]], rw[D + ps[i] + 8]);
-                off[i] = mp.cell_offset_hi(Tm); off[i + N / 2] = mp.cell_offset_lo(Tm);
-            }
-            mp.template emit4c<TIE_RC, N>(sink, ps, ftw, rtw, flw, rlw, off);
-            continue;
-        }
-#endif
+        uint32_t ft[4], rt[4], fl[4], rl[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int j = pos[i];
-            const uint32_t ft = fw[j], rt = rw[D + j];            // fw[(j - D) + D], rw[j + D]
-            fwd[i] = TIE_RC ? (ft < rt) : (ft <= rt);
-            if (j - D >= -1) lo[i] = fwd[i] ? fw[D + j] : rw[j];  // rw[(j - D) + D]: own word, or r1
-#ifndef NTK_SV2_SELPREV   // (fusing the cross-lane move into the select - select_prev - measured slower: profiles/r02b)
-#ifdef NTK_ABL_HALFIMPORTS
-            else if (j & 1) lo[i] = fwd[i] ? fw[D + j] : rw[16 + j];
-#endif
-            else { const uint32_t pw = xl.prev(kSlotRw + 16 + j - D, rw[16 + j]); lo[i] = fwd[i] ? fw[D + j] : pw; }
-#else
-            else lo[i] = xl.select_prev(kSlotRw + 16 + j - D, fwd[i], fw[D + j], rw[16 + j]);   // previous lane's word 16 + (j - D)
-#endif
-            if (!LIGHT) {
-                T[i] = fwd[i] ? ft : rt;
-                hi[i] = S ? T[i] >> S : T[i];
-            } else {
-                hi[i] = 0;
-            }
+            ft[i] = fw[j]; rt[i] = rw[D + j];                   // T words: fw[(j - D) + D], rw[j + D]
+            fl[i] = fw[D + j];                                  // lo words: forward = the word ending at base j,
+            rl[i] = j - D >= -1 ? rw[j] : xl.prev(kSlotRw + 16 + j - D, rw[16 + j]);   // reverse complement = rw[(j - D) + D]: own word, r1, or the previous lane's word 16 + (j - D)
         }
-        if (LIGHT) {
-            // (min of the halves == half of the min, whatever the tie rule)
-#ifdef NTK_SV2_NO_PKMIN
-#pragma unroll
-            for (int i = 0; i < 4; i++) { const uint32_t ft = fw[pos[i]], rt = rw[D + pos[i]], m = ft < rt ? ft : rt; T[i] = i < 2 ? m : m >> 16; }
-#else
-            T[0] = T[2] = mp.pk_min16_crossed(fw[pos[0]], rw[D + pos[2]]);   // bits 31:16 -> position jp, bits 15:0 -> jp+8
-            T[1] = T[3] = mp.pk_min16_crossed(fw[pos[1]], rw[D + pos[3]]);
-#endif
-        }
-        mp.emit4(sink, pos, fwd, T, hi, lo);
+        if constexpr (LIGHT)
+            mp.template emit_canon<TIE_RC>(sink, pos, ft, rt, fl, rl, mp.pk_min16_crossed(fw[pos[0]], rw[D + pos[2]]),   // bits 31:16 -> position jp, bits 15:0 -> jp + 8
+                                           mp.pk_min16_crossed(fw[pos[1]], rw[D + pos[3]]));
+        else
+            mp.template emit_canon_wide<TIE_RC>(sink, pos, ft, rt, fl, rl);
     }
 }
 
@@ -731,21 +741,16 @@ NTK_HD void lane_tile_sv2w(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t r
 #pragma unroll
     for (int jp = 0; jp < 8; jp += 2) {
         const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
-        uint32_t v[4];
-        bool fwd[4];
+        uint32_t f[4], r[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int j = pos[i];
             const uint32_t fwj = j == 15 ? code : alignbit(c1, code, 30 - 2 * j);
-            const uint32_t f = S ? fwj << S : fwj;
-            if (FWD) { v[i] = f; fwd[i] = true; }
-            else {
-                const uint32_t r = (j == 15 ? rcode : alignbit(rcode, r1, 2 * j + 2)) & hmask;
-                fwd[i] = TIE_RC ? (f < r) : (f <= r);
-                v[i] = f < r ? f : r;
-            }
+            f[i] = S ? fwj << S : fwj;
+            r[i] = FWD ? 0u : ((j == 15 ? rcode : alignbit(rcode, r1, 2 * j + 2)) & hmask);
         }
-        mp.template emit4w<FWD>(sink, pos, fwd, v);
+        if constexpr (FWD) mp.emit_word_fwd(sink, pos, f);
+        else mp.template emit_word<TIE_RC>(sink, pos, f, r);   // the chosen value is min(f, r); the compare (ties: TIE_RC) only feeds the strand count
     }
 }
 
@@ -756,7 +761,7 @@ template <int K, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 {
     static_assert(K >= 17 && K <= 32, "sv2 is the 64-bit-value path");
-    constexpr int D = K - 16, S = 64 - 2 * K;
+    constexpr int D = K - 16;
     constexpr bool LIGHT = MP::kLight;
     uint32_t fw[16 + D];   // index g + D
     const uint32_t c1 = xl.prev(kSlotCode, code);
@@ -769,15 +774,14 @@ NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 #pragma unroll
     for (int jp = 0; jp < 8; jp += 2) {
         const int pos[4] = {jp, jp + 1, jp + 8, jp + 9};
-        uint32_t T[4], lo[4], hi[4];
+        uint32_t T[4], lo[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             // LIGHT: fw[j - D] carries the histogram prefix of position j in bits 31:16 and that of position j + 8 in bits 15:0
             T[i] = LIGHT ? fw[pos[i & 1]] : fw[pos[i]];
             lo[i] = fw[D + pos[i]];
-            hi[i] = LIGHT ? 0u : (S ? T[i] >> S : T[i]);
         }
-        mp.emit4_fwd(sink, pos, T, hi, lo);
+        mp.emit_fwd(sink, pos, T, lo);
     }
 }
 
@@ -798,13 +802,13 @@ NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 // The digests follow the LIGHT scheme of lane_tile_sv2 (K <= 22): lo word per position, high parts from the histogram.
 // ---------------------------------------------------------------------------------------------
 template <int K, int W> struct Sv2MinFused {
-    static constexpr bool value = K >= 15 && K <= 22 && W >= 9 && K + W - 1 <= 32;
+    static constexpr bool value = K >= 15 && K <= 22 && W >= 9 && W <= 16 && K + W - 1 <= 32;   // (W <= 16: a window reaches one lane back)
 };
 
 template <bool TIE_RC, int K, int W, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
 {
-    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 22, 9 <= W, K + W - 1 <= 32");
+    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 22, 9 <= W <= 16, K + W - 1 <= 32");
     constexpr int D = K > 16 ? K - 16 : 0;
     constexpr int HS = K > 16 ? 58 - 2 * K : 26;           // key hi word = T >> HS (| bit 30); K <= 16: the value is one word, T = value
     constexpr uint32_t kBit62 = 1u << (HS - 2);            // alignbit(kBit62, T, HS) == (T >> HS) | 0x40000000

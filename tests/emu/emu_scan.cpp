@@ -153,50 +153,83 @@ template <int K, int HB>
 struct EmuMP2 {
     static constexpr bool kLight = Sv2Light<K, HB>::value;
     static constexpr int kWordCopies = K <= 6 ? (((1 << HB) >> (2 * (K <= 6 ? K : 0))) < 64 ? ((1 << HB) >> (2 * (K <= 6 ? K : 0))) : 64) : 1;
-    uint64_t V[16];
+    uint64_t VA[16], VB[16];   // the window ending at byte j is emitted where VA[j] & VB[j] is set (the region forms exec with that AND)
     int lane = 0;
-    uint64_t sum = 0, n_fwd = 0;
-    uint32_t xT = 0, xlo = 0;
+    uint64_t sum = 0, sumh = 0, n_fwd = 0;
+    uint32_t xh = 0, xlo = 0;
     std::vector<uint32_t> cells = std::vector<uint32_t>(1u << HB, 0u);
+    bool valid(int j) const { return ((VA[j] & VB[j]) >> lane) & 1; }
     uint32_t pk_min16_crossed(uint32_t a, uint32_t b) const   // v_pk_min_u16 op_sel:[0,1] op_sel_hi:[1,0]
     {
         const uint32_t h = (a >> 16) < (b & 0xFFFFu) ? (a >> 16) : (b & 0xFFFFu), l = (a & 0xFFFFu) < (b >> 16) ? (a & 0xFFFFu) : (b >> 16);
         return (h << 16) | l;
     }
-    template <class S>
-    void emit4(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
+    static uint32_t cell_offset_hi(uint32_t T) { return HB == 14 ? ((T >> 16) & 0xFFFCu) : ((T >> 18) & 0x3FFCu); }
+    static uint32_t cell_offset_lo(uint32_t T) { return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu); }
+    // the masked regions of DevMasks2 (ntk_kernels.hpp), one lane at a time: strand compare and select under the validity mask
+    template <bool TIE_RC_, class S>
+    void emit_canon(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4], const uint32_t (&rl)[4],
+                    uint32_t Tm0, uint32_t Tm1)
     {
+        const uint32_t off[4] = {cell_offset_hi(Tm0), cell_offset_hi(Tm1), cell_offset_lo(Tm0), cell_offset_lo(Tm1)};
         for (int i = 0; i < 4; i++) {
-            if (!((V[pos[i]] >> lane) & 1)) continue;
-            uint32_t off;
-            if (kLight && i >= 2) off = HB == 14 ? (T[i] & 0xFFFCu) : ((T[i] >> 2) & 0x3FFCu);
-            else off = HB == 14 ? ((T[i] >> 16) & 0xFFFCu) : ((T[i] >> 18) & 0x3FFCu);
-            cells[off >> 2]++;
-            if (kLight) { sum += lo[i]; xlo ^= lo[i]; }
-            else { sum += ((uint64_t)hi[i] << 32) | lo[i]; xT ^= T[i]; xlo ^= lo[i]; }
-            n_fwd += fwd[i] ? 1 : 0;
+            if (!valid(pos[i])) continue;
+            const bool fwd = TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i];
+            const uint32_t t = fwd ? fl[i] : rl[i];
+            sum += t; xlo ^= t; cells[off[i] >> 2]++; n_fwd += fwd ? 1 : 0;
+        }
+    }
+    template <bool TIE_RC_, class S>
+    void emit_canon_wide(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4], const uint32_t (&rl)[4])
+    {
+        constexpr int SH = 64 - 2 * K;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t T = ft[i] < rt[i] ? ft[i] : rt[i], hi = SH ? T >> (SH & 31) : T, off = cell_offset_hi(T);
+            if (!valid(pos[i])) continue;
+            const bool fwd = TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i];
+            const uint32_t t = fwd ? fl[i] : rl[i];
+            sum += t; xlo ^= t; sumh += hi; xh ^= hi; cells[off >> 2]++; n_fwd += fwd ? 1 : 0;
         }
     }
     bool fwd_only = false;
-    template <bool FWD_ONLY, class S>
-    void emit4w(S &, const int (&pos)[4], const bool (&fwd)[4], const uint32_t (&v)[4])   // word builds (K <= 16): left-aligned values
+    uint32_t word_cell(uint32_t v) const
     {
-        if (FWD_ONLY) fwd_only = true;
+        const uint32_t rep = (uint32_t)lane & (uint32_t)(kWordCopies - 1);
+        return K <= 6 ? ((v >> ((30 - 2 * K) & 31)) | (rep << ((2 * K + 2) & 31))) : cell_offset_hi(v);
+    }
+    template <bool TIE_RC_, class S>
+    void emit_word(S &, const int (&pos)[4], const uint32_t (&f)[4], const uint32_t (&r)[4])   // word builds (K <= 16): left-aligned values
+    {
         for (int i = 0; i < 4; i++) {
-            if (!((V[pos[i]] >> lane) & 1)) continue;
-            const uint32_t rep = (uint32_t)lane & (uint32_t)(kWordCopies - 1);
-            const uint32_t off = K <= 6 ? ((v[i] >> ((30 - 2 * K) & 31)) | (rep << ((2 * K + 2) & 31))) : (HB == 14 ? ((v[i] >> 16) & 0xFFFCu) : ((v[i] >> 18) & 0x3FFCu));
-            cells[off >> 2]++;
-            sum += v[i]; xlo ^= v[i];
-            n_fwd += fwd[i] ? 1 : 0;
+            if (!valid(pos[i])) continue;
+            const uint32_t v = f[i] < r[i] ? f[i] : r[i];
+            cells[word_cell(v) >> 2]++;
+            sum += v; xlo ^= v;
+            n_fwd += (TIE_RC_ ? f[i] < r[i] : f[i] <= r[i]) ? 1 : 0;
         }
     }
     template <class S>
-    void emit4_fwd(S &s_, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&hi)[4], const uint32_t (&lo)[4])
+    void emit_word_fwd(S &, const int (&pos)[4], const uint32_t (&v)[4])
     {
-        const bool all[4] = {true, true, true, true};
         fwd_only = true;
-        emit4(s_, pos, all, T, hi, lo);
+        for (int i = 0; i < 4; i++) {
+            if (!valid(pos[i])) continue;
+            cells[word_cell(v[i]) >> 2]++;
+            sum += v[i]; xlo ^= v[i];
+        }
+    }
+    template <class S>
+    void emit_fwd(S &, const int (&pos)[4], const uint32_t (&T)[4], const uint32_t (&lo)[4])
+    {
+        constexpr int SH = 64 - 2 * K;
+        fwd_only = true;
+        for (int i = 0; i < 4; i++) {
+            if (!valid(pos[i])) continue;
+            const uint32_t off = (kLight && i >= 2) ? cell_offset_lo(T[i]) : cell_offset_hi(T[i]);
+            cells[off >> 2]++;
+            sum += lo[i]; xlo ^= lo[i];
+            if (!kLight) { const uint32_t hi = SH ? T[i] >> (SH & 31) : T[i]; sumh += hi; xh ^= hi; }
+        }
     }
     uint64_t min64(uint64_t a, uint64_t b) const { return a < b ? a : b; }   // v_min_f64 on positive normal doubles
     uint64_t nf_bits = 0;
@@ -206,7 +239,7 @@ struct EmuMP2 {
     {
         min_mode = true;
         for (int i = 0; i < 4; i++) {
-            if (!((V[pos[i]] >> lane) & 1)) continue;
+            if (!valid(pos[i])) continue;
             const uint32_t off = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
             cells[off >> 2]++;
             sum += lo[i]; xlo ^= lo[i]; nf_bits += fb[i];
@@ -215,8 +248,7 @@ struct EmuMP2 {
     void finish(HostStats *st)   // the block-end arithmetic of scan2_kernel
     {
         constexpr bool WORD = K <= 16, LIGHT = kLight && !WORD;
-        constexpr int S = WORD ? 0 : 64 - 2 * K;
-        uint64_t s = sum, xr = WORD ? (uint64_t)xlo : ((uint64_t)(S ? xT >> S : xT) << 32) | xlo, shi = 0, xf = 0, nv = 0;
+        uint64_t s = sum + (sumh << 32), xr = (WORD || LIGHT) ? (uint64_t)xlo : ((uint64_t)xh << 32) | xlo, shi = 0, xf = 0, nv = 0;
         const uint32_t per = (1u << HB) / kHistBins;
         for (uint32_t c = 0; c < (uint32_t)kHistBins; c++) {
             uint32_t tot = 0;
@@ -236,7 +268,7 @@ struct EmuMP2 {
             s += shi << 32;
             xr = (xf << ((2 * K - HB) & 63)) | (uint64_t)(xlo & low_mask);
         }
-        if (WORD && K < 16) { s >>= (32 - 2 * K) & 31; xr >>= (32 - 2 * K) & 31; }
+        if (WORD && K < 16 && !min_mode) { s >>= (32 - 2 * K) & 31; xr >>= (32 - 2 * K) & 31; }   // (the fused minimizers keep plain values)
         if (min_mode) n_fwd = tie_rc ? nf_bits : nv - nf_bits;
         if (fwd_only) n_fwd = nv;   // the forward-only kernel keeps no strand counter: n_fwd = n_total
         st->n_total += nv; st->n_fwd += n_fwd; st->sum += s; st->xr ^= xr;
@@ -264,15 +296,15 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
                 if (good) G[i] |= 1ull << l;
             }
         }
-        if constexpr (K >= 17) window_masks<(W ? K + W - 1 : K)>(G, mp.V); else window_masks1<K>(G, mp.V);
+        window_masks_ab_any<(W ? K + W - 1 : K)>(G, mp.VA, mp.VB);
         mp.tie_rc = TIE_RC;
         EmuXL xl;
         for (int l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             mp.lane = l;
-            if constexpr (K <= 16) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en[l].code, en[l].rcode);
+            if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en[l].code, en[l].rcode);
+            else if constexpr (K <= 16) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en[l].code, en[l].rcode);
             else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en[l].code);
-            else if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en[l].code, en[l].rcode);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en[l].code, en[l].rcode);
         }
     }
@@ -369,6 +401,7 @@ int emu_minimizers(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k
 #define EMU_MIN4(KF, WF) EMU_MIN(KF, WF, false, false) EMU_MIN(KF, WF, false, true) EMU_MIN(KF, WF, true, false) EMU_MIN(KF, WF, true, true)
     EMU_MIN4(17, 11) EMU_MIN4(18, 11) EMU_MIN4(19, 11) EMU_MIN4(20, 11) EMU_MIN4(21, 11) EMU_MIN4(22, 11)
     EMU_MIN4(21, 9) EMU_MIN4(21, 10) EMU_MIN4(21, 12) EMU_MIN4(17, 16) EMU_MIN4(19, 14)
+    EMU_MIN4(15, 10) EMU_MIN4(15, 9) EMU_MIN4(16, 12) EMU_MIN4(16, 16) EMU_MIN4(15, 16) EMU_MIN4(19, 10) EMU_MIN4(22, 9) EMU_MIN4(20, 13)
     if (done) {
         out[0] = st->n_total; out[1] = st->n_fwd; out[2] = st->sum; out[3] = st->xr;
         memcpy(out + 4, st->hist, sizeof(st->hist));

@@ -261,7 +261,9 @@ def emu_minimizers(L, buf: bytes, k, w, tie_rc, accept_u, hb14):
             "xor": int(out[3]), "hist": out[4:].copy()}
 
 
-FUSED_KW = ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12))
+# (k <= 16: the value is one word and the key is built from it; the product ships k = 15..22 x w = 9..12 with k + w - 1 <= 32)
+FUSED_KW = ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12),
+            (15, 10), (15, 9), (16, 12), (16, 16), (15, 16), (19, 10), (22, 9), (20, 13))
 
 
 def test_emu_fused_minimizers_match_the_literal_minimizer(emu):
