@@ -285,6 +285,11 @@ int ntk_canonical_kmers_batch(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *
                               uint64_t *counts, uint64_t *pos_out, uint8_t *is_rc_out, uint64_t cap, uint64_t *total);
 int ntk_bit_kmers_batch(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,
                         uint64_t *counts, uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *total);
+/* Both batched calls cut the batch into chunks of <= 16 MiB of packed bytes and keep up to three chunks in flight: while the copy engine
+ * returns chunk i's items (9 or 17 bytes each - the bound of this face) the host packs chunk i + 1 into pinned staging and the
+ * GPU scans it.  The caller's arrays may be pageable; page-locked ones (below) take the copies without a staging pass. */
+int ntk_pinned_alloc(uint64_t bytes, void **out);   /* hipHostMalloc: for the arrays handed to the batched calls */
+void ntk_pinned_free(void *p);
 
 /* ---- minimizers and quality masking ------------------------------------------------ */
 /* Windowed minimizers, reduce mode (BASELINE.json configs[4], "minimizers (w, k)"): for every window of w+k-1 good

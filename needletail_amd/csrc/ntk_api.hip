@@ -13,6 +13,8 @@
 #include <mutex>
 #include <new>
 #include <utility>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "ntk_kernels.hpp"
@@ -93,6 +95,17 @@ struct Scratch {
 
 }  // namespace
 
+// Everything one in-flight chunk of the batched compat face owns (ntk_canonical_kmers_batch / ntk_bit_kmers_batch).
+struct CompatBank {
+    void *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned: record starts + packed bytes
+    uint64_t *h_total = nullptr;                         // pinned: the chunk's item total
+    Scratch d[7];   // 0 packed bytes, 1 values (bit path) / flag bytes (byte path), 2 valid16, 3 rc16, 4 compaction scratch, 5 record starts, 6 dense outputs
+    hipEvent_t ev_total = nullptr, ev_scattered = nullptr, ev_done = nullptr;
+    uint64_t r0 = 0, nrec = 0, n = 0, n_words = 0, nblocks = 0;
+    size_t o_off = 0, o_total = 0, o_counts = 0;
+    bool busy = false;   // its D2H may still be running
+};
+
 struct ntk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream (kernels, compat-face copies)
@@ -109,8 +122,8 @@ struct ntk_ctx {
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
-    Scratch scratch[7];   // [6]: dense outputs of the batched compat face
-    void *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned staging of the batched compat face
+    Scratch scratch[6];
+    CompatBank bank[3];        // the chunks the batched compat face keeps in flight (see compat_batch)
     void *h_pinned = nullptr;  // small pinned staging for scalar read-backs
     bool timing = false;
     std::vector<hipEvent_t> ev_free;
@@ -471,7 +484,12 @@ void ntk_ctx_destroy(ntk_ctx *c)
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (CompatBank &b : c->bank) {
+        if (b.h_stage) (void)hipHostFree(b.h_stage);
+        if (b.h_total) (void)hipHostFree(b.h_total);
+        for (auto &s : b.d) if (s.p) (void)hipFree(s.p);
+        for (hipEvent_t e : {b.ev_total, b.ev_scattered, b.ev_done}) if (e) (void)hipEventDestroy(e);
+    }
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -891,90 +909,189 @@ int ntk_bit_kmers(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t k, int ca
 
 /* ---- batched compat face ------------------------------------------------------------------------------------------- */
 namespace {
-// Packs the records (one break byte after each) into pinned memory, uploads bytes and packed record starts.
-// Device: scratch[0] = packed bytes, scratch[5] = rec_start (n_records + 1 u64).
-int upload_packed_records(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint64_t *packed_n)
+// The items of Sequence::canonical_kmers / bit_kmers (reference src/sequence.rs:237-252) for a whole batch of records in ONE call.
+// The batch is cut into chunks of <= kCompatChunkBytes packed bytes that run through a two-deep pipeline, each chunk owning one
+// CompatBank (pinned staging + device buffers):
+//     A(c):  pack chunk c into pinned memory (one break byte after each record) -> H2D -> scan -> valid / is_rc planes ->
+//            count + scan of the items per 16 384-position block -> the chunk's item total to pinned memory        [ctx stream]
+//     B(c):  (total known) scatter into dense (pos, value, flag) arrays + per-record counts                        [ctx stream]
+//            -> D2H straight into the caller's arrays at the chunk's item offset                                   [copy stream]
+// and the host issues A(c+1) before B(c): while the copy engine drains chunk c's items (the 9 B per item going back over PCIe are
+// the bound of this face), the CPU packs chunk c+1 and the GPU scans it.  THREE banks rotate: a bank is free again when its
+// chunk's D2H has finished, and with two the host would wait for D2H(c-1) - enqueued a moment ago - before it could pack chunk
+// c+1 (measured: 3.85 ms per chunk = 2.35 ms of copies + 1.5 ms of packing in series, profiles/r03b/compat_trace.txt).
+// Caller arrays may be pageable or pinned (ntk_pinned_alloc).
+constexpr uint64_t kCompatChunkBytes = (uint64_t)16 << 20;
+
+int bank_scratch(ntk_ctx *c, CompatBank &b, int slot, size_t bytes)
 {
-    if (offsets[0] > offsets[n_records]) return NTK_ERR_BAD_ARG;
-    for (uint64_t r = 0; r < n_records; r++) if (offsets[r] > offsets[r + 1]) return NTK_ERR_BAD_ARG;
-    const uint64_t n = offsets[n_records] - offsets[0] + n_records;
-    const size_t stage_bytes = (size_t)n + (size_t)(n_records + 1) * 8 + 64;
-    if (c->h_stage_bytes < stage_bytes) {
-        if (c->h_stage) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->h_stage)); c->h_stage = nullptr; c->h_stage_bytes = 0; }
-        HIPCHK(hipHostMalloc(&c->h_stage, stage_bytes + stage_bytes / 4, hipHostMallocDefault));
-        c->h_stage_bytes = stage_bytes + stage_bytes / 4;
-    }
-    uint64_t *h_start = (uint64_t *)c->h_stage;                       // 8-byte aligned head
-    uint8_t *h_seq = (uint8_t *)c->h_stage + (size_t)(n_records + 1) * 8;
-    uint64_t w = 0;
-    for (uint64_t r = 0; r < n_records; r++) {
-        const uint64_t len = offsets[r + 1] - offsets[r];
-        h_start[r] = w;
-        if (len) memcpy(h_seq + w, seq + offsets[r], len);
-        h_seq[w + len] = '\n';
-        w += len + 1;
-    }
-    h_start[n_records] = w;
-    int rc;
-    const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 0, nt + 16))) return rc;
-    if ((rc = ensure_scratch(c, 5, (size_t)(n_records + 1) * 8))) return rc;
-    HIPCHK(hipMemcpyAsync(c->scratch[0].p, h_seq, n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->scratch[5].p, h_start, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    *packed_n = n;
+    if (bytes < 256) bytes = 256;
+    Scratch &s = b.d[slot];
+    if (s.bytes >= bytes) return NTK_OK;
+    // (only this bank's own earlier work can still use the buffer, and that was waited for before the bank was re-used)
+    if (s.p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->copy_stream)); HIPCHK(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&s.p, want));
+    s.bytes = want;
     return NTK_OK;
 }
 
-// Planes -> dense per-record item arrays on the device, then to the caller.  d_values may be null (byte path).
-int compact_items(ntk_ctx *c, const uint16_t *d_v16, const uint16_t *d_r16, const uint64_t *d_values, uint64_t n, uint64_t n_records,
-                  uint32_t index_shift, uint64_t *counts, uint64_t *pos_out, uint64_t *val_out, uint8_t *flag_out, uint64_t cap,
-                  uint64_t *total)
+int bank_init(ntk_ctx *c, CompatBank &b)
 {
-    const uint64_t n_words = (n + 15) >> 4;
-    const uint64_t nblocks = (n_words + kCpBlockWords - 1) / kCpBlockWords;
+    (void)c;
+    if (b.ev_total) return NTK_OK;
+    HIPCHK(hipEventCreateWithFlags(&b.ev_total, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b.ev_scattered, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void **)&b.h_total, 64, hipHostMallocDefault));
+    return NTK_OK;
+}
+
+struct CompatJob {
+    const uint8_t *seq; const uint64_t *offsets;
+    uint32_t k; int kind;   // 0: byte path (raw-byte CanonicalKmers, any k <= 255), 1: bit path canonical, 2: bit path forward
+    uint64_t *counts, *pos_out, *val_out; uint8_t *flag_out;
+    uint64_t cap;
+};
+
+// A: records [r0, r0 + nrec) of the job into bank b, up to the item total
+int compat_stage_a(ntk_ctx *c, CompatBank &b, const CompatJob &j, uint64_t r0, uint64_t nrec)
+{
     int rc;
-    // one scratch slot holds: block_items u32[nblocks] | block_off u64[nblocks] | total u64 | counts u64[n_records]
-    const size_t o_off = ((size_t)nblocks * 4 + 7) & ~(size_t)7, o_total = o_off + (size_t)nblocks * 8, o_counts = o_total + 8;
-    auto fail = [c](int status) { (void)hipStreamSynchronize(c->stream); return status; };   // (the upload may still be in flight)
-    if ((rc = ensure_scratch(c, 4, o_counts + (size_t)n_records * 8))) return fail(rc);
-    uint8_t *base = (uint8_t *)c->scratch[4].p;
-    uint32_t *d_items = (uint32_t *)base;
-    uint64_t *d_off = (uint64_t *)(base + o_off), *d_total = (uint64_t *)(base + o_total), *d_counts = (uint64_t *)(base + o_counts);
-    hipLaunchKernelGGL(cp_count_kernel, dim3((unsigned)nblocks), dim3(kCpThreads), 0, c->stream, d_v16, n_words, d_items);
-    hipLaunchKernelGGL(cp_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_items, d_off, nblocks, d_total);
-    if (hipGetLastError() != hipSuccess) { g_last_hip = (int)hipGetLastError(); return fail(NTK_ERR_HIP); }
-    uint64_t *h = (uint64_t *)c->h_pinned;
-    if (hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); return fail(NTK_ERR_HIP); }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    const uint64_t m = h[0];
-    *total = m;
-    const uint64_t take = m < cap ? m : cap;
-    // dense outputs on the device: a growable slot of the ctx (no hipMalloc / hipFree per call: both synchronise the device)
-    uint64_t *d_pos = nullptr, *d_val = nullptr; uint8_t *d_flag = nullptr;
-    const size_t out_bytes = (size_t)take * (8 + (d_values ? 8 : 0) + 1) + 64;
-    if ((rc = ensure_scratch(c, 6, out_bytes))) return rc;   // (the stream is idle here: synchronised above)
-    d_pos = (uint64_t *)c->scratch[6].p;
-    d_val = d_values ? d_pos + take : nullptr;
-    d_flag = (uint8_t *)(d_pos + take + (d_values ? take : 0));
-    int status = NTK_OK;
-    do {
-        if (hipMemsetAsync(d_counts, 0, (size_t)n_records * 8, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
-        hipLaunchKernelGGL(cp_scatter_kernel, dim3((unsigned)nblocks), dim3(kCpThreads), 0, c->stream, d_v16, d_r16, d_values, n_words,
-                           (const uint64_t *)d_off, (const uint64_t *)c->scratch[5].p, n_records, index_shift, take, d_pos, d_val, d_flag,
-                           (unsigned long long *)d_counts);
-        if (hipGetLastError() != hipSuccess) { status = NTK_ERR_HIP; break; }
-        if (counts && hipMemcpyAsync(counts, d_counts, (size_t)n_records * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
-        if (take && pos_out && hipMemcpyAsync(pos_out, d_pos, (size_t)take * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
-        if (take && val_out && d_val && hipMemcpyAsync(val_out, d_val, (size_t)take * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
-        if (take && flag_out && hipMemcpyAsync(flag_out, d_flag, (size_t)take, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { status = NTK_ERR_HIP; break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) status = NTK_ERR_HIP;
-    } while (0);
-    if (status == NTK_ERR_HIP) {
-        g_last_hip = (int)hipGetLastError();
-        (void)hipStreamSynchronize(c->stream);   // nothing of this call may still be reading the pinned staging or writing the caller's arrays
+    const uint64_t n = j.offsets[r0 + nrec] - j.offsets[r0] + nrec;
+    const size_t stage_bytes = (size_t)n + (size_t)(nrec + 1) * 8 + 64;
+    if (b.h_stage_bytes < stage_bytes) {
+        if (b.h_stage) { HIPCHK(hipHostFree(b.h_stage)); b.h_stage = nullptr; b.h_stage_bytes = 0; }
+        HIPCHK(hipHostMalloc(&b.h_stage, stage_bytes + stage_bytes / 4, hipHostMallocDefault));
+        b.h_stage_bytes = stage_bytes + stage_bytes / 4;
     }
-    if (status != NTK_OK) return status;
-    return m > cap ? NTK_ERR_CAPACITY : NTK_OK;
+    uint64_t *h_start = (uint64_t *)b.h_stage;                       // 8-byte aligned head
+    uint8_t *h_seq = (uint8_t *)b.h_stage + (size_t)(nrec + 1) * 8;
+    // record r of the chunk lands at offsets[r0 + r] - offsets[r0] + r (one break byte after every record before it): the
+    // packing splits over threads without a prefix pass (one core packs ~5 GB/s of 150-byte records - less than the PCIe link
+    // takes back - so a chunk is packed by up to NTK_COMPAT_PACK_THREADS threads, default 8)
+    const uint64_t o0 = j.offsets[r0];
+    auto pack = [&](uint64_t ra, uint64_t rb) {
+        for (uint64_t r = ra; r < rb; r++) {
+            const uint64_t o = j.offsets[r0 + r], len = j.offsets[r0 + r + 1] - o, w = o - o0 + r;
+            h_start[r] = w;
+            if (len) memcpy(h_seq + w, j.seq + o, len);
+            h_seq[w + len] = '\n';
+        }
+    };
+    static const unsigned pack_threads = [] {
+        const char *e = getenv("NTK_COMPAT_PACK_THREADS");
+        long v = e ? atol(e) : 8;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (v < 1) v = 1;
+        if (hw && (unsigned long)v > hw) v = (long)hw;
+        return (unsigned)(v > 64 ? 64 : v);
+    }();
+    const unsigned nth = (unsigned)std::min<uint64_t>(pack_threads, n / (256 << 10) + 1);   // a thread per 256 KiB at least
+    if (nth <= 1) pack(0, nrec);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nth; t++) th.emplace_back(pack, nrec * t / nth, nrec * (t + 1) / nth);
+        pack(0, nrec / nth);
+        for (auto &t : th) t.join();
+    }
+    h_start[nrec] = n;
+    b.r0 = r0; b.nrec = nrec; b.n = n;
+    const uint64_t nt = (n + 15) / 16 * 16;
+    if ((rc = bank_scratch(c, b, 0, nt + 16))) return rc;
+    if ((rc = bank_scratch(c, b, 5, (size_t)(nrec + 1) * 8))) return rc;
+    if ((rc = bank_scratch(c, b, 1, j.kind == 0 ? nt : nt * 8))) return rc;
+    if ((rc = bank_scratch(c, b, 2, nt / 8 + 16))) return rc;
+    if ((rc = bank_scratch(c, b, 3, nt / 8 + 16))) return rc;
+    b.n_words = (n + 15) >> 4;
+    b.nblocks = (b.n_words + kCpBlockWords - 1) / kCpBlockWords;
+    // one slot holds: block_items u32[nblocks] | block_off u64[nblocks] | total u64 | counts u64[nrec]
+    b.o_off = ((size_t)b.nblocks * 4 + 7) & ~(size_t)7; b.o_total = b.o_off + (size_t)b.nblocks * 8; b.o_counts = b.o_total + 8;
+    if ((rc = bank_scratch(c, b, 4, b.o_counts + (size_t)nrec * 8))) return rc;
+    HIPCHK(hipMemcpyAsync(b.d[0].p, h_seq, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b.d[5].p, h_start, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    uint16_t *d_v16 = (uint16_t *)b.d[2].p, *d_r16 = (uint16_t *)b.d[3].p;
+    if (j.kind == 0) {
+        // raw-byte comparison exactly as the reference (src/kmer.rs:84-129): any k <= 255, mixed case compares as bytes
+        uint8_t *d_flags = (uint8_t *)b.d[1].p;
+        hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
+                           (const uint8_t *)b.d[0].p, n, j.k, (const uint16_t *)(c->d_lut + 768), d_flags);
+        hipLaunchKernelGGL(pack_flags8_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, c->stream, (const uint8_t *)d_flags, n, d_v16, d_r16);
+        HIPCHK(hipGetLastError());
+    } else {
+        ntk_params p = {j.k, (uint32_t)(j.kind == 1 ? NTK_PATH_BITS_CANONICAL : NTK_PATH_BITS), NTK_PRE_NONE, 0};
+        Mode m;
+        if ((rc = resolve_mode(&p, true, &m))) return rc;
+        if ((rc = run_scan(c, (const uint8_t *)b.d[0].p, n, &p, m, false, (uint64_t *)b.d[1].p, d_v16, d_r16))) return rc;
+    }
+    uint8_t *base = (uint8_t *)b.d[4].p;
+    hipLaunchKernelGGL(cp_count_kernel, dim3((unsigned)b.nblocks), dim3(kCpThreads), 0, c->stream, d_v16, b.n_words, (uint32_t *)base);
+    hipLaunchKernelGGL(cp_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)base, (uint64_t *)(base + b.o_off), b.nblocks,
+                       (uint64_t *)(base + b.o_total));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b.h_total, base + b.o_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(b.ev_total, c->stream));
+    return NTK_OK;
+}
+
+// B: the chunk's items leave for the caller's arrays at item offset *base (capacity permitting); *base += the chunk's item total
+int compat_stage_b(ntk_ctx *c, CompatBank &b, const CompatJob &j, uint64_t *base_items)
+{
+    int rc;
+    HIPCHK(hipEventSynchronize(b.ev_total));
+    const uint64_t m = *b.h_total, at = *base_items;
+    const uint64_t take = at >= j.cap ? 0 : (m < j.cap - at ? m : j.cap - at);
+    const bool values = j.kind != 0;
+    if ((rc = bank_scratch(c, b, 6, (size_t)take * (8 + (values ? 8 : 0) + 1) + 64))) return rc;
+    uint64_t *d_pos = (uint64_t *)b.d[6].p, *d_val = values ? d_pos + take : nullptr;
+    uint8_t *d_flag = (uint8_t *)(d_pos + take + (values ? take : 0));
+    uint8_t *sb = (uint8_t *)b.d[4].p;
+    uint64_t *d_counts = (uint64_t *)(sb + b.o_counts);
+    HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)b.nrec * 8, c->stream));
+    hipLaunchKernelGGL(cp_scatter_kernel, dim3((unsigned)b.nblocks), dim3(kCpThreads), 0, c->stream, (const uint16_t *)b.d[2].p, (const uint16_t *)b.d[3].p,
+                       values ? (const uint64_t *)b.d[1].p : nullptr, b.n_words, (const uint64_t *)(sb + b.o_off), (const uint64_t *)b.d[5].p, b.nrec,
+                       j.kind == 0 ? 0u : j.k - 1, take, d_pos, d_val, d_flag, (unsigned long long *)d_counts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b.ev_scattered, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, b.ev_scattered, 0));
+    if (j.counts) HIPCHK(hipMemcpyAsync(j.counts + b.r0, d_counts, (size_t)b.nrec * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    if (take && j.pos_out) HIPCHK(hipMemcpyAsync(j.pos_out + at, d_pos, (size_t)take * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    if (take && j.val_out && d_val) HIPCHK(hipMemcpyAsync(j.val_out + at, d_val, (size_t)take * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    if (take && j.flag_out) HIPCHK(hipMemcpyAsync(j.flag_out + at, d_flag, (size_t)take, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipEventRecord(b.ev_done, c->copy_stream));
+    b.busy = true;
+    *base_items = at + m;
+    return NTK_OK;
+}
+
+int compat_batch(ntk_ctx *c, const CompatJob &j, uint64_t n_records, uint64_t *total)
+{
+    for (uint64_t r = 0; r < n_records; r++) if (j.offsets[r] > j.offsets[r + 1]) return NTK_ERR_BAD_ARG;
+    int rc = NTK_OK;
+    for (CompatBank &b : c->bank) if ((rc = bank_init(c, b))) return rc;
+    uint64_t items = 0, r0 = 0;
+    int cur = 0, prev = -1;
+    uint64_t chunk_bytes = kCompatChunkBytes;
+    if (const char *e = getenv("NTK_COMPAT_CHUNK_BYTES")) { const long long v = atoll(e); if (v > 0) chunk_bytes = (uint64_t)v; }   // test hook: many chunks from small batches
+    while (r0 < n_records && rc == NTK_OK) {
+        // the chunk: records up to chunk_bytes packed bytes (at least one record)
+        uint64_t r1 = r0 + 1;
+        while (r1 < n_records && j.offsets[r1 + 1] - j.offsets[r0] + (r1 + 1 - r0) <= chunk_bytes) r1++;
+        CompatBank &b = c->bank[cur];
+        if (b.busy) { if (hipEventSynchronize(b.ev_done) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = NTK_ERR_HIP; break; } b.busy = false; }
+        if ((rc = compat_stage_a(c, b, j, r0, r1 - r0))) break;
+        if (prev >= 0 && (rc = compat_stage_b(c, c->bank[prev], j, &items))) break;
+        prev = cur; cur = (cur + 1) % 3; r0 = r1;
+    }
+    if (rc == NTK_OK && prev >= 0) rc = compat_stage_b(c, c->bank[prev], j, &items);
+    // the call is synchronous: everything of it has landed (or, after an error, nothing of it is still reading the pinned
+    // staging buffers or writing the caller's arrays) when it returns
+    const hipError_t e1 = hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->copy_stream);
+    for (CompatBank &b : c->bank) b.busy = false;
+    if (rc != NTK_OK) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) { g_last_hip = (int)(e1 != hipSuccess ? e1 : e2); return NTK_ERR_HIP; }
+    *total = items;
+    return items > j.cap ? NTK_ERR_CAPACITY : NTK_OK;
 }
 }  // namespace
 
@@ -987,23 +1104,8 @@ int ntk_bit_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets,
     if (counts) memset(counts, 0, (size_t)n_records * 8);
     if (n_records == 0) return NTK_OK;
     HIPCHK(hipSetDevice(c->device));
-    ntk_params p = {k, (uint32_t)(canonical ? NTK_PATH_BITS_CANONICAL : NTK_PATH_BITS), NTK_PRE_NONE, 0};
-    Mode m;
-    int rc = resolve_mode(&p, true, &m);
-    if (rc) return rc;
-    uint64_t n = 0;
-    // from here on the pinned staging buffer is the source of an asynchronous copy: an early return waits for the stream, so
-    // that the next call cannot overwrite the buffer under a copy that is still in flight
-    auto fail = [c](int status) { (void)hipStreamSynchronize(c->stream); return status; };
-    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return fail(rc);
-    const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 1, nt * 8))) return fail(rc);
-    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return fail(rc);
-    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return fail(rc);
-    uint64_t *d_val = (uint64_t *)c->scratch[1].p;
-    uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
-    if ((rc = run_scan(c, (const uint8_t *)c->scratch[0].p, n, &p, m, false, d_val, d_v16, d_r16))) return fail(rc);
-    return compact_items(c, d_v16, d_r16, d_val, n, n_records, k - 1, counts, pos_out, val_out, was_rc_out, cap, total);
+    const CompatJob j = {seq, offsets, k, canonical ? 1 : 2, counts, pos_out, val_out, was_rc_out, cap};
+    return compat_batch(c, j, n_records, total);
 }
 
 int ntk_canonical_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
@@ -1015,23 +1117,20 @@ int ntk_canonical_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *of
     if (counts) memset(counts, 0, (size_t)n_records * 8);
     if (n_records == 0) return NTK_OK;
     HIPCHK(hipSetDevice(c->device));
-    int rc;
-    uint64_t n = 0;
-    auto fail = [c](int status) { (void)hipStreamSynchronize(c->stream); return status; };   // (see ntk_bit_kmers_batch)
-    if ((rc = upload_packed_records(c, seq, offsets, n_records, &n))) return fail(rc);
-    const uint64_t nt = (n + 15) / 16 * 16;
-    if ((rc = ensure_scratch(c, 1, nt))) return fail(rc);
-    if ((rc = ensure_scratch(c, 2, nt / 8 + 16))) return fail(rc);
-    if ((rc = ensure_scratch(c, 3, nt / 8 + 16))) return fail(rc);
-    uint8_t *d_flags = (uint8_t *)c->scratch[1].p;
-    uint16_t *d_v16 = (uint16_t *)c->scratch[2].p, *d_r16 = (uint16_t *)c->scratch[3].p;
-    // raw-byte comparison exactly as the reference (src/kmer.rs:84-129): any k <= 255, mixed case compares as bytes
-    hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
-                       (const uint8_t *)c->scratch[0].p, n, k, (const uint16_t *)(c->d_lut + 768), d_flags);
-    hipLaunchKernelGGL(pack_flags8_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, c->stream, (const uint8_t *)d_flags, n, d_v16, d_r16);
-    if (hipGetLastError() != hipSuccess) { g_last_hip = (int)hipGetLastError(); return fail(NTK_ERR_HIP); }
-    return compact_items(c, d_v16, d_r16, nullptr, n, n_records, 0, counts, pos_out, nullptr, is_rc_out, cap, total);
+    const CompatJob j = {seq, offsets, k, 0, counts, pos_out, nullptr, is_rc_out, cap};
+    return compat_batch(c, j, n_records, total);
 }
+
+/* Page-locked host memory for the arrays the batched calls read and fill (what a Rust host would back its Vecs with): copies to
+ * and from it run at the PCIe rate without a staging pass. */
+int ntk_pinned_alloc(uint64_t bytes, void **out)
+{
+    if (!out || bytes == 0) return NTK_ERR_BAD_ARG;
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return NTK_OK;
+}
+void ntk_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
 /* ---- minimizers, quality mask --------------------------------------------------------------------------------- */
 

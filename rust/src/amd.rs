@@ -90,6 +90,8 @@ extern "C" {
     pub fn ntk_bit_kmers(ctx: *mut NtkCtx, seq: *const u8, n: u64, k: u32, canonical: c_int, pos_out: *mut u64, val_out: *mut u64, was_rc_out: *mut u8, cap: u64, count: *mut u64) -> c_int;
     pub fn ntk_canonical_kmers_batch(ctx: *mut NtkCtx, seq: *const u8, offsets: *const u64, n_records: u64, k: u32, counts: *mut u64, pos_out: *mut u64, is_rc_out: *mut u8, cap: u64, total: *mut u64) -> c_int;
     pub fn ntk_bit_kmers_batch(ctx: *mut NtkCtx, seq: *const u8, offsets: *const u64, n_records: u64, k: u32, canonical: c_int, counts: *mut u64, pos_out: *mut u64, val_out: *mut u64, was_rc_out: *mut u8, cap: u64, total: *mut u64) -> c_int;
+    pub fn ntk_pinned_alloc(bytes: u64, out: *mut *mut c_void) -> c_int;
+    pub fn ntk_pinned_free(p: *mut c_void);
     pub fn ntk_minimizers_reduce_device(ctx: *mut NtkCtx, d_seq: *const u8, n_bytes: u64, p: *const NtkParams, w: u32) -> c_int;
     pub fn ntk_minimizer(ctx: *mut NtkCtx, seq: *const u8, n: u64, m: u32, out: *mut u8) -> c_int;
     pub fn ntk_canonical(ctx: *mut NtkCtx, seq: *const u8, n: u64, out: *mut u8, was_rc: *mut c_int) -> c_int;

@@ -1031,10 +1031,15 @@ def test_bench_collective_fallback_is_opt_in():
     assert cfg["rccl_ranks"] == 0 and cfg["collective"].startswith("FALLBACK")
 
 
-def test_batched_compat_face_matches_the_iterators_per_record(ctx):
+@pytest.mark.parametrize("chunk_bytes", [None, 97, 4096])
+def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, monkeypatch):
     """ntk_bit_kmers_batch / ntk_canonical_kmers_batch: one call for a whole batch of records, element-wise against the
     oracle's literal iterators (reference src/sequence.rs:237-252) record by record; ragged, empty and all-N records,
-    mixed case, k up to 255 on the byte path, and the capacity protocol."""
+    mixed case, k up to 255 on the byte path, and the capacity protocol.  The call pipelines chunks of the batch (two in
+    flight, 16 MiB of packed bytes each); NTK_COMPAT_CHUNK_BYTES = 97 / 4096 forces hundreds of chunks out of this small batch:
+    chunks of one record, records larger than a chunk, the capacity running out in the middle of a chunk."""
+    if chunk_bytes:
+        monkeypatch.setenv("NTK_COMPAT_CHUNK_BYTES", str(chunk_bytes))
     rng = np.random.default_rng(21)
     alphabet = np.frombuffer(b"ACGTACGTACGTacgtNn-", dtype=np.uint8)
     records = [b"", b"A", b"N" * 40, b"ACGT" * 10, b"acgtACGTnACGTTGCA" * 3]
