@@ -73,7 +73,35 @@ def oracle_shard(batches, seed, read_len, n_per_1024, k, path, pre, threads, lit
     return stats_sum(parts)
 
 
-def cpu_baseline(gpu_ctx, seq, k, read_len, n_per_1024, n_reads, budget_s):
+def reference_toolchain_note():
+    """if `cargo` AND a needletail crate with a vendored registry are on this box, the real crate is the baseline to
+    prefer (rust/cpu_baseline/ holds the harness that reads the same synthetic reads and prints the same reduced result; build:
+    `cargo build --release --offline` there with NEEDLETAIL_SRC pointing at the crate).  This image has neither, so the C port
+    is timed; the note says which of the two was missing."""
+    import shutil
+    cargo = shutil.which("cargo")
+    src = os.environ.get("NEEDLETAIL_SRC", "")
+    vendored = bool(src) and os.path.isfile(os.path.join(src, "Cargo.toml")) and os.path.isdir(os.path.join(src, "vendor"))
+    if cargo and vendored:
+        return (f"cargo at {cargo} and a vendored crate at {src}: build rust/cpu_baseline (cargo build --release --offline) and pass "
+                "--cpu-reference-bin to time the real crate (kind: reference)")
+    missing = [w for w, ok in (("cargo on PATH", cargo), ("NEEDLETAIL_SRC = a needletail crate with vendor/", vendored)) if not ok]
+    return "absent (" + "; ".join("no " + m for m in missing) + "): the C port is the baseline"
+
+
+def cpu_reference_run(binary, host, n_reads, read_len, k, threads):
+    """Times the reference crate's own chain through rust/cpu_baseline's harness (a binary built elsewhere with cargo): the reads
+    go in as a file of fixed-stride records, the harness prints one JSON line with the reduced result and its seconds."""
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".reads") as f:
+        f.write(memoryview(host)); f.flush()
+        r = subprocess.run([binary, f.name, str(n_reads), str(read_len), str(k), str(threads)], capture_output=True, text=True, timeout=1800)
+    if r.returncode != 0:
+        raise SystemExit(f"cpu_baseline: {binary} failed: {r.stderr[-400:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline(gpu_ctx, seq, k, read_len, n_per_1024, n_reads, budget_s, reference_bin=None):
     """the needletail-equivalent CPU path (C restatement of the reference's per-record chain, allocations
     included; the Rust toolchain is unavailable) built -O3 -march=native on this host, four variants, each asserted equal to
     the GPU result on the same reads: bytes / bits x 1 thread / all host threads.  The N-thread variants run the GPU's
@@ -122,12 +150,33 @@ def cpu_baseline(gpu_ctx, seq, k, read_len, n_per_1024, n_reads, budget_s):
             raise SystemExit(f"cpu_baseline: cpu-{name}-1t result differs from the GPU result")
         variants[f"cpu-{name}-1t"] = {"Gbases_s": round(n1 * read_len / dt1 / 1e9, 4), "reads": n1, "threads": 1,
                                       "repetitions": 1, "equal_to_gpu": True}
+        # informational: every thread keeps its normalize / reverse-complement buffers across records - NOT the reference's
+        # behaviour (it allocates three Vecs per record); shows what the allocator costs in the number above
+        t0 = time.perf_counter()
+        got_a = O.reduce_batch(host, offs, 1, k, path, pre, threads, reuse_buffers=True)
+        dta = time.perf_counter() - t0
+        if not stats_equal(got_a, got):
+            raise SystemExit(f"cpu_baseline: cpu-{name}-Nt-arena result differs")
+        variants[f"cpu-{name}-{threads}t-arena"] = {"Gbases_s": round(n_reads * read_len / dta / 1e9, 4), "reads": n_reads, "threads": threads,
+                                                   "repetitions": 1, "equal_to_gpu": True,
+                                                   "note": "per-thread buffers reused across records: not the reference's behaviour"}
     head = variants[f"cpu-bytes-{threads}t"]
+    if reference_bin:   # the real crate: its result must equal the GPU's too
+        ref = cpu_reference_run(reference_bin, host, n_reads, read_len, k, threads)
+        gpu = gpu_result(n_reads, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+        if not all(int(ref[x]) == int(gpu[x]) for x in ("n_total", "n_fwd", "sum", "xor")):
+            raise SystemExit("cpu_baseline: the reference crate's result differs from the GPU result")
+        variants[f"needletail-crate-{threads}t"] = {"Gbases_s": round(n_reads * read_len / float(ref["seconds"]) / 1e9, 4), "reads": n_reads,
+                                                  "threads": threads, "equal_to_gpu": True}
+        head = variants[f"needletail-crate-{threads}t"]
+        return {"value": head["Gbases_s"], "unit": "Gbases/s", "cores": threads, "kind": "reference",
+                "sample": f"the GPU's own {n_reads} reads through the needletail crate (rust/cpu_baseline harness)", "variants": variants}
     return {
         "value": head["Gbases_s"],
         "unit": "Gbases/s",
         "cores": threads,
         "kind": "port",
+        "reference_toolchain": reference_toolchain_note(),
         "sample": f"the GPU's own {n_reads} reads ({n_reads * read_len / 1e6:.0f} Mbases) for the {threads}-thread variants, a "
                   f"prefix for the 1-thread ones; needletail-equivalent CPU path (C restatement of normalize -> "
                   f"reverse_complement -> CanonicalKmers / strip_returns -> BitNuclKmer per record, allocations included; Rust "
@@ -236,12 +285,15 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
         out["minimizers_w11_k21_resident"] = {"error": str(e)}
 
     # H2D-inclusive pipeline: FASTQ text in host memory -> parallel record parser -> pinned batches -> overlapped copies + scans
-    p_reads = min(reads, 2_000_000)
+    p_reads = reads   # the whole read set (a 2 M-read sample under-reports by ~27 %: the ramp-up of the first batches dominates it)
     seqs = k21_seq[: p_reads * (read_len + 1)].cpu().numpy().reshape(p_reads, read_len + 1)
     idw = 9
     rec = np.empty((p_reads, 1 + idw + 1 + read_len + 1 + 2 + read_len + 1), dtype=np.uint8)
     rec[:, 0] = ord("@")
-    rec[:, 1:1 + idw] = np.frombuffer("".join(np.char.zfill(np.arange(p_reads).astype(str), idw)).encode(), dtype=np.uint8).reshape(p_reads, idw)
+    ids = np.arange(p_reads, dtype=np.int64)
+    for d_ in range(idw):   # zero-padded decimal record numbers, digit by digit
+        rec[:, 1 + d_] = (ids // 10 ** (idw - 1 - d_)) % 10 + 48
+    del ids
     rec[:, 1 + idw] = 10
     rec[:, 2 + idw:2 + idw + read_len] = seqs[:, :read_len]
     rec[:, 2 + idw + read_len] = 10
@@ -303,10 +355,10 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
                                         "pageable_arrays": {"seconds": round(best_pg, 4), "Gbases_s": round(c_reads * read_len / best_pg / 1e9, 2)}}
     except (nt.NtkError, AttributeError) as e:  # pragma: no cover
         out["compat_batch_face_k21"] = {"error": str(e)}
-    del rec, seqs
     ctx.accum_reset()
     ctx.reduce_device(k21_seq, p_reads * (read_len + 1), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
     want = ctx.accum_read()
+    del rec, seqs
     th = min(32, os.cpu_count() or 1)
     best = None
     for _ in range(3):
@@ -379,6 +431,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="threads per block (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=24.0)
+    ap.add_argument("--cpu-reference-bin", default=os.environ.get("NTK_CPU_REFERENCE_BIN"),
+                    help="rust/cpu_baseline's harness built against the real needletail crate (needs cargo + a vendored registry, "
+                         "absent from this image): timed as cpu_baseline with kind 'reference'")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -670,7 +725,7 @@ def main():
         }
     if world == 1 and rank == 0 and seed == SEED_C2:
         out["cpu_baseline"] = None if args.no_cpu_baseline else \
-            cpu_baseline(ctx, seq, args.k, args.read_len, args.n_per_1024, total_reads, args.cpu_budget_s)
+            cpu_baseline(ctx, seq, args.k, args.read_len, args.n_per_1024, total_reads, args.cpu_budget_s, args.cpu_reference_bin)
         if not args.no_secondary:
             out["secondary"] = secondary_measurements(ctx, nt, torch, seq, n_bytes, total_reads, args.read_len)
     elif rank == 0:

@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
         L.ntko_reduce_batch.argtypes = [C.POINTER(Stats), C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int]
         L.ntko_reduce_batch_mt.restype = C.c_int
         L.ntko_reduce_batch_mt.argtypes = [C.POINTER(Stats), C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
+        L.ntko_reduce_batch_mt2.restype = C.c_int
+        L.ntko_reduce_batch_mt2.argtypes = [C.POINTER(Stats), C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ntko_count_batch_mt.restype = C.c_int
         L.ntko_count_batch_mt.argtypes = [u64p, u64p, C.c_void_p, C.c_void_p, sz, sz, C.c_uint8, C.c_int, C.c_int, C.c_int]
         L.ntko_reduce_fused.restype = C.c_int
@@ -269,16 +271,19 @@ def reduce_records(records, k: int, path: int, pre: int) -> dict:
 
 
 def reduce_batch(buf: np.ndarray, offsets: np.ndarray, gap: int, k: int, path: int, pre: int,
-                 threads: int = 1) -> dict:
+                 threads: int = 1, reuse_buffers: bool = False) -> dict:
+    """reuse_buffers: every thread keeps its normalize / reverse-complement buffers across records - NOT what the reference does
+    (it allocates per record); the cpu_baseline's informational "arena" variant."""
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     st = Stats()
     lib().ntko_stats_clear(C.byref(st))
     nrec = len(offsets) - 1
-    if threads <= 1:
+    if threads <= 1 and not reuse_buffers:
         rc = lib().ntko_reduce_batch(C.byref(st), buf.ctypes.data, offsets.ctypes.data, nrec, gap, k, path, pre)
     else:
-        rc = lib().ntko_reduce_batch_mt(C.byref(st), buf.ctypes.data, offsets.ctypes.data, nrec, gap, k, path, pre, threads)
+        rc = lib().ntko_reduce_batch_mt2(C.byref(st), buf.ctypes.data, offsets.ctypes.data, nrec, gap, k, path, pre, max(1, threads),
+                                         int(reuse_buffers))
     if rc:
         raise ValueError("ntko_reduce_batch failed")
     return st.as_dict()

@@ -382,7 +382,22 @@ static unsigned hist_shift(uint8_t k)
     return 2u * (k - p);
 }
 
+/* Two buffers a thread may keep across records (the "arena" variant of the CPU baseline: NOT the reference's behaviour - the
+ * reference allocates per record, sequence.rs:20,176,202-208 - it only shows what the allocator costs next to the literal chain). */
+typedef struct { uint8_t *a, *b; size_t cap_a, cap_b; } ntko_scratch;
+static uint8_t *scratch_get(uint8_t **p, size_t *cap, size_t n)
+{
+    if (*cap < n || !*p) { free(*p); *cap = n + n / 2 + 64; *p = (uint8_t *)malloc(*cap); }
+    return *p;
+}
+
+static int reduce_record_impl(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, int path, int pre, ntko_scratch *sc);
 int ntko_reduce_record(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, int path, int pre)
+{
+    return reduce_record_impl(s, seq, n, k, path, pre, NULL);
+}
+
+static int reduce_record_impl(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, int path, int pre, ntko_scratch *sc)
 {
     if (k < 1 || k > 32) return -1;
     unsigned shift = hist_shift(k);
@@ -391,12 +406,12 @@ int ntko_reduce_record(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, i
     const uint8_t *cur = seq;
     size_t cn = n;
     if (pre == NTKO_PRE_STRIP_RETURNS) {
-        tmp = (uint8_t *)malloc(n ? n : 1);
+        tmp = sc ? scratch_get(&sc->a, &sc->cap_a, n ? n : 1) : (uint8_t *)malloc(n ? n : 1);
         int borrowed;
         cn = ntko_strip_returns(seq, n, tmp, &borrowed);
         cur = borrowed ? seq : tmp;
     } else if (pre == NTKO_PRE_NORMALIZE || pre == NTKO_PRE_NORMALIZE_IUPAC) {
-        tmp = (uint8_t *)malloc(n ? n : 1);
+        tmp = sc ? scratch_get(&sc->a, &sc->cap_a, n ? n : 1) : (uint8_t *)malloc(n ? n : 1);
         int changed;
         cn = ntko_normalize(seq, n, pre == NTKO_PRE_NORMALIZE_IUPAC, tmp, &changed);
         cur = changed ? tmp : seq; /* Cow::Borrowed when unchanged, sequence.rs:226-232 */
@@ -405,7 +420,7 @@ int ntko_reduce_record(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, i
     }
 
     if (path == NTKO_PATH_BYTES_CANONICAL) {
-        uint8_t *rc = (uint8_t *)malloc(cn ? cn : 1); /* sequence.rs:202-208 returns a Vec */
+        uint8_t *rc = sc ? scratch_get(&sc->b, &sc->cap_b, cn ? cn : 1) : (uint8_t *)malloc(cn ? cn : 1); /* sequence.rs:202-208 returns a Vec */
         ntko_reverse_complement(cur, cn, rc);
         ntko_canonical_kmers it;
         ntko_ck_new(&it, cur, cn, rc, cn, k);
@@ -414,17 +429,17 @@ int ntko_reduce_record(ntko_stats *s, const uint8_t *seq, size_t n, uint8_t k, i
             uint64_t v = ntko_bytes_to_bitmer(sl, k).seq; /* 2-bit value of the yielded slice */
             stats_emit(s, v, f, shift);
         }
-        free(rc);
+        if (!sc) free(rc);
     } else if (path == NTKO_PATH_BITS || path == NTKO_PATH_BITS_CANONICAL) {
         ntko_bit_nucl_kmer it;
         ntko_bnk_new(&it, cur, cn, k, path == NTKO_PATH_BITS_CANONICAL);
         size_t pos; ntko_bitkmer km; int f;
         while (ntko_bnk_next(&it, &pos, &km, &f)) stats_emit(s, km.seq, f, shift);
     } else {
-        free(tmp);
+        if (!sc) free(tmp);
         return -1;
     }
-    free(tmp);
+    if (!sc) free(tmp);
     return 0;
 }
 
@@ -520,19 +535,40 @@ int ntko_reduce_batch(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets
 
 typedef struct {
     ntko_stats st;
-    const uint8_t *seq; const uint64_t *offsets; size_t r0, r1, gap; uint8_t k; int path, pre, rcode;
+    const uint8_t *seq; const uint64_t *offsets; size_t r0, r1, gap; uint8_t k; int path, pre, rcode, reuse;
 } mt_job;
 
 static void *mt_run(void *p)
 {
     mt_job *j = (mt_job *)p;
     ntko_stats_clear(&j->st);
-    j->rcode = ntko_reduce_batch(&j->st, j->seq, j->offsets + j->r0, j->r1 - j->r0, j->gap, j->k, j->path, j->pre);
+    if (!j->reuse) {
+        j->rcode = ntko_reduce_batch(&j->st, j->seq, j->offsets + j->r0, j->r1 - j->r0, j->gap, j->k, j->path, j->pre);
+        return NULL;
+    }
+    ntko_scratch sc = {NULL, NULL, 0, 0};   /* the thread's own two buffers, kept across its records */
+    j->rcode = 0;
+    for (size_t r = j->r0; r < j->r1 && !j->rcode; r++) {
+        size_t b = j->offsets[r], e = j->offsets[r + 1];
+        size_t len = e - b >= j->gap ? e - b - j->gap : 0;
+        j->rcode = reduce_record_impl(&j->st, j->seq + b, len, j->k, j->path, j->pre, &sc);
+    }
+    free(sc.a); free(sc.b);
     return NULL;
 }
 
+int ntko_reduce_batch_mt2(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,
+                          size_t gap, uint8_t k, int path, int pre, int n_threads, int reuse_buffers);
 int ntko_reduce_batch_mt(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,
                          size_t gap, uint8_t k, int path, int pre, int n_threads)
+{
+    return ntko_reduce_batch_mt2(s, seq, offsets, n_records, gap, k, path, pre, n_threads, 0);
+}
+
+/* reuse_buffers: every thread keeps its normalize / reverse-complement buffers across records instead of allocating them per
+ * record as the reference does (cpu_baseline's "arena" variant: informational, not the reference's behaviour). */
+int ntko_reduce_batch_mt2(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,
+                          size_t gap, uint8_t k, int path, int pre, int n_threads, int reuse_buffers)
 {
     if (n_threads < 1) n_threads = 1;
     mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof(mt_job));
@@ -542,7 +578,7 @@ int ntko_reduce_batch_mt(ntko_stats *s, const uint8_t *seq, const uint64_t *offs
         jobs[t].seq = seq; jobs[t].offsets = offsets; jobs[t].gap = gap;
         jobs[t].r0 = n_records * (size_t)t / (size_t)n_threads;
         jobs[t].r1 = n_records * (size_t)(t + 1) / (size_t)n_threads;
-        jobs[t].k = k; jobs[t].path = path; jobs[t].pre = pre;
+        jobs[t].k = k; jobs[t].path = path; jobs[t].pre = pre; jobs[t].reuse = reuse_buffers;
         pthread_create(&th[t], NULL, mt_run, &jobs[t]);
     }
     for (int t = 0; t < n_threads; t++) {

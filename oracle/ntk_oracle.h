@@ -156,6 +156,9 @@ int ntko_reduce_batch(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets
 /* Same, records partitioned statically over n_threads pthreads. */
 int ntko_reduce_batch_mt(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,
                          size_t gap, uint8_t k, int path, int pre, int n_threads);
+/* reuse_buffers != 0: each thread keeps its two scratch buffers across records (NOT the reference's behaviour: informational) */
+int ntko_reduce_batch_mt2(ntko_stats *s, const uint8_t *seq, const uint64_t *offsets, size_t n_records,
+                          size_t gap, uint8_t k, int path, int pre, int n_threads, int reuse_buffers);
 
 /* Independent second formulation ("run length of good bases >= k") over a
  * whole separator-delimited buffer in one pass: every byte that is not a base is a break.
