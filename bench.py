@@ -36,6 +36,31 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 SCALARS = ("n_total", "n_fwd", "n_rc", "sum", "xor")
 
 
+def effective_cpus():
+    """CPUs this process can actually use: the logical CPUs, cut down by the affinity mask and by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs under a 16-CPU quota: 256 busy threads there are 16 cores' worth of time slices)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return eff, {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota}
+
+
 def stats_equal(a, b):
     import numpy as np
     return all(int(a[k]) == int(b[k]) for k in SCALARS) and np.array_equal(np.asarray(a["hist"], dtype=np.uint64),
@@ -111,7 +136,7 @@ def cpu_baseline(gpu_ctx, seq, k, read_len, n_per_1024, n_reads, budget_s, refer
     import needletail_amd as nt
     import oracle as O  # the checker / CPU port: only timed here, never part of the GPU path
     flags = O.use_native_build()
-    threads = os.cpu_count() or 1
+    threads, host_info = effective_cpus()
     stride = read_len + 1
     host = O.synth_reads(SEED_C2, 0, n_reads, read_len, n_per_1024)
     offs = np.arange(n_reads + 1, dtype=np.uint64) * stride
@@ -182,8 +207,9 @@ def cpu_baseline(gpu_ctx, seq, k, read_len, n_per_1024, n_reads, budget_s, refer
                   f"reverse_complement -> CanonicalKmers / strip_returns -> BitNuclKmer per record, allocations included; Rust "
                   f"toolchain unavailable), reduced outputs asserted equal to the GPU's",
         "build": f"gcc {flags}",
-        "bound": "allocator: the literal chain makes three heap allocations per record (normalize Vec, reverse_complement "
-                 "Vec, iterator state), as the reference does (src/sequence.rs:20,202-208); threads contend in malloc",
+        "host": host_info,
+        "bound": "the scalar per-record chain itself (three heap allocations per record as the reference makes them, src/sequence.rs:20,202-208, "
+                 "then a byte-at-a-time window walk); the -arena variants (buffers reused per thread) show the allocator's share",
         "variants": variants,
     }
 
@@ -404,6 +430,44 @@ class phase_deadline:
         return False
 
 
+def pmc_traffic(args, n_bytes):
+    """HBM bytes per scan-kernel launch from rocprofv3's TCC counters, collected live: one child run of this script per counter
+    (--pmc only, no trace domains), 5 steps each.  FETCH_SIZE counts 64-byte units of 128-byte requests on gfx950: a wide
+    coalesced streaming read shows up at exactly half its bytes (MI355X_MICROARCH.md, HBM) -> doubled; both counters are in KB.
+    Returns (bytes, source) or (None, None) when rocprofv3 is missing or a pass fails (the caller then falls back to the
+    profiles/ number and says so)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    tool = shutil.which("rocprofv3")
+    if not tool:
+        return None, None
+    got = {}
+    env = dict(os.environ, NTK_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--preheat-ms", "5", "--no-verify", "--no-cpu-baseline",
+             "--no-secondary", "--no-pmc", "--reads", str(args.reads or 10_000_000), "--read-len", str(args.read_len), "--k", str(args.k),
+             "--n-per-1024", str(args.n_per_1024), "--blocks", str(args.blocks), "--threads", str(args.threads)]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            try:
+                r = subprocess.run([tool, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=240)
+            except (OSError, subprocess.TimeoutExpired):
+                return None, None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "scan2_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None, None
+            got[counter] = sum(vals) / len(vals)
+    read_b, write_b = got["FETCH_SIZE"] * 1024 * 2, got["WRITE_SIZE"] * 1024
+    return read_b + write_b, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this command, "
+                              f"per scan2_kernel launch; read {read_b:.0f} B = FETCH_SIZE KB x 1024 x 2 (gfx950 correction), write {write_b:.0f} B)")
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -447,6 +511,7 @@ def main():
     ap.add_argument("--allow-collective-fallback", action="store_true",
                     help="if the library's own RCCL communicator (ntk_comm_*) cannot come up, reduce with torch.distributed's "
                          "all_reduce instead (noted in config.collective); without this flag that is a fatal error")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect roofline.traffic with rocprofv3 --pmc child passes (N = 1)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     args = ap.parse_args()
@@ -599,7 +664,7 @@ def main():
         ctx.reduce_device(seq, n_bytes, args.k, path, pre)
         got = ctx.accum_read()
         t0 = time.perf_counter()
-        threads = max(1, (os.cpu_count() or 1) // world)
+        threads = max(1, min(os.cpu_count() or 1, 4 * effective_cpus()[0]) // world)
         import oracle as O  # checker only
         literal = my_reads <= 12_000_000 and world == 1
         want_mine = oracle_shard(batches, seed, args.read_len, args.n_per_1024, args.k, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE, threads,
@@ -660,6 +725,10 @@ def main():
                     f"reads (5 scalars + 4096 bins; {verify_s:.1f} s of CPU per rank, untimed)")
 
     traffic, traffic_source = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes is not None else None)
+    if traffic is None and world == 1 and rank == 0 and not args.no_pmc and not os.environ.get("NTK_BENCH_PMC_CHILD"):
+        # measured in THIS run: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a short
+        # child run of this same command, per launch of the scan kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950
+        traffic, traffic_source = pmc_traffic(args, n_bytes)
     if traffic is None and world == 1 and seed == SEED_C2 and (total_reads, args.read_len, args.k, args.n_per_1024) == (10_000_000, 150, 21, 1):
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_scan_kernel.json")))
@@ -668,7 +737,7 @@ def main():
                 with open(cands[-1]) as fh:
                     pmc = json.load(fh)
                 traffic = pmc["hbm_read_bytes_per_launch_corrected"] + pmc.get("hbm_write_bytes_per_launch", 0.0)
-                traffic_source = os.path.relpath(cands[-1], ROOT) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
+                traffic_source = "CARRIED from " + os.path.relpath(cands[-1], ROOT) + " (an earlier profile round; the live rocprofv3 --pmc passes of this run were unavailable)"
             except (OSError, KeyError, ValueError):
                 traffic, traffic_source = None, None
 
@@ -709,8 +778,7 @@ def main():
                        "verified": verified},
             "roofline": {
                 "bound": "hbm",
-                "kernel": (f"ntk::scan2_kernel<{args.k}, true, true, false, 14>" if args.k > 16
-                           else f"ntk::scan_kernel<1, true, true, true, true, {args.k}, true, false>"),
+                "kernel": f"ntk::scan2_kernel<{args.k}, true, true, false, 14, 0, false>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
