@@ -812,7 +812,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         // the next tile's load is in flight while the current one is processed
         u32x4 ta = load_tile(voff), qa = ta, tb = ta, qb = ta;
         if constexpr (QM) qa = load_qual(voff);
-#ifndef NTK_SV2_PINGPONG   // (two tiles per loop trip without register moves doubles the loop body: measured 5 - 25 % slower, profiles/r02b)
+#ifndef NTK_SV2_PINGPONG   // (two tiles per loop trip without register moves doubles the loop body: measured 5 - 25 % slower, profiles/r02b; with
+                           //  the tile offset in the scalar operand and unconditional, clamped loads: no gain at k = 21, +4 % at k = 31, profiles/r03a/pp2_ab.txt)
         for (uint32_t r = r0; r < r1; r++) {
             if (r + 1 < r1) { tb = load_tile(voff + kTileStride); if constexpr (QM) qb = load_qual(voff + kTileStride); }
             process(ta, qa, r);

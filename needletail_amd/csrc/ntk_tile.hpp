@@ -117,6 +117,17 @@ NTK_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)  // v_alignbit_b
 #endif
 }
 
+NTK_HD uint32_t add_self(uint32_t t)  // t << 1 as a full-rate v_add_u32 (the compiler turns t + t into the half-rate v_lshlrev_b32)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(t));
+    return r;
+#else
+    return t + t;
+#endif
+}
+
 NTK_HD uint32_t brev32(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -660,9 +671,12 @@ NTK_HD EncSV2 encode16_sv2(Raw16 d)
         p[i] = dot4(perm(kCodeHi, kCodeLo, n), 0x01041040u, 0u);   // c0 c1 c2 c3 as one byte (weights 64, 16, 4, 1)
         r.uu[i] = w[i] & 0xDFDFDFDFu;
     }
-    r.code = (((((p[0] << 8) | p[1]) << 8) | p[2]) << 8) | p[3];   // three v_lshl_or_b32
+    // the four bytes into one word, first base on top: three v_perm_b32 (as shifts and ors the compiler makes it five ops; inline asm
+    // may not consume a v_dot4 result: gfx950 needs wait states between a DOT write and a VALU read that the compiler only inserts
+    // for instructions it can see - measured: wrong, run-to-run different results)
+    r.code = perm(perm(p[0], p[1], 0x0C0C0400u), perm(p[2], p[3], 0x0C0C0400u), 0x05040100u);
     const uint32_t t = brev32(r.code);
-    r.rcode = bitop3<0x35>(0x55555555u, t >> 1, t + t);        // complement, pairs swapped back after the bit reversal
+    r.rcode = bitop3<0x35>(0x55555555u, t >> 1, add_self(t));  // complement, pairs swapped back after the bit reversal
     return r;
 }
 
