@@ -142,7 +142,7 @@ def main():
             counts["materialize"] += 1
         elif what < 8 and canon and path == nt.PATH_BYTES_CANONICAL and pre == nt.PRE_NORMALIZE:
             w = int(rng.choice([1, 2, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
-            kk = k if rng.random() < 0.5 else int(rng.choice([17, 18, 19, 20, 21, 22]))
+            kk = k if rng.random() < 0.5 else int(rng.choice([15, 16, 17, 18, 19, 20, 21, 22]))
             ctx.accum_reset(); ctx.reduce_device(t, n, kk, path, pre, w=w)
             if not stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, kk, w, True, True)):
                 print("MISMATCH minimizers", tag, "w", w, "kk", kk); return 1
@@ -155,8 +155,16 @@ def main():
             tq = torch.full_like(t, 0x49)
             if n:
                 tq[:n] = torch.from_numpy(q).cuda()
-            ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre, d_qual=tq, quality_cutoff=cutoff)
             masked = O.quality_mask(buf, q.tobytes(), cutoff)
+            if canon and path == nt.PATH_BYTES_CANONICAL and pre == nt.PRE_NORMALIZE and rng.random() < 0.4:
+                # quality-masked windowed minimizers: the fused quality builds ((21, 11), (15, 10)) and the two-pass path
+                kq, wq = [(21, 11), (15, 10), (21, 10), (17, 5)][int(rng.integers(0, 4))]
+                ctx.accum_reset(); ctx.reduce_device(t, n, kq, path, pre, w=wq, d_qual=tq, quality_cutoff=cutoff)
+                if not stats_equal(ctx.accum_read(), O.minimizers_reduce(masked, kq, wq, True, True)):
+                    print("MISMATCH quality minimizers", tag, "cutoff", cutoff, "k", kq, "w", wq); return 1
+                counts["quality"] += 1
+                continue
+            ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre, d_qual=tq, quality_cutoff=cutoff)
             if not stats_equal(ctx.accum_read(), O.reduce_fused(masked, k, canon, tie, u)):
                 print("MISMATCH quality", tag, "cutoff", cutoff); return 1
             counts["quality"] += 1
