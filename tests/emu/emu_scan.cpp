@@ -313,6 +313,17 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
 
 }  // namespace
 
+// The window-mask algebra alone: OK[j] in its two forms (window_masks / window_masks1: the finished masks; *_ab: the masks with
+// their last AND left to the masked region) for window length k.  Returns -1 on bad k.
+template <int K>
+static void masks_both(const uint64_t (&G)[16], uint64_t *ok, uint64_t *ab)
+{
+    uint64_t V[16], A[16], B[16];
+    if constexpr (K >= 17) window_masks<K>(G, V); else window_masks1<K>(G, V);
+    window_masks_ab_any<K>(G, A, B);
+    for (int j = 0; j < 16; j++) { ok[j] = V[j]; ab[j] = A[j] & B[j]; }
+}
+
 extern "C" {
 
 // out: [n_total, n_fwd, sum, xor, hist[4096]].  canon/tie_rc/accept_u as the kernel's template flags.
@@ -408,6 +419,20 @@ int emu_minimizers(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k
     }
     delete st;
     return done ? 0 : -2;
+}
+
+int emu_window_masks(const uint64_t *g16, uint32_t k, uint64_t *ok16, uint64_t *ab16)
+{
+    uint64_t G[16];
+    memcpy(G, g16, sizeof(G));
+    switch (k) {
+#define EMU_WM(KF) case KF: masks_both<KF>(G, ok16, ab16); return 0;
+    EMU_WM(1) EMU_WM(2) EMU_WM(3) EMU_WM(4) EMU_WM(5) EMU_WM(6) EMU_WM(7) EMU_WM(8) EMU_WM(9) EMU_WM(10) EMU_WM(11) EMU_WM(12) EMU_WM(13)
+    EMU_WM(14) EMU_WM(15) EMU_WM(16) EMU_WM(17) EMU_WM(18) EMU_WM(19) EMU_WM(20) EMU_WM(21) EMU_WM(22) EMU_WM(23) EMU_WM(24) EMU_WM(25)
+    EMU_WM(26) EMU_WM(27) EMU_WM(28) EMU_WM(29) EMU_WM(30) EMU_WM(31) EMU_WM(32)
+#undef EMU_WM
+    }
+    return -1;
 }
 
 void emu_encode16(const uint8_t *raw16, int accept_u, uint32_t *out3)

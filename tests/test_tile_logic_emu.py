@@ -85,6 +85,37 @@ def test_encode16_all_bytes(emu):
                     assert (rcode >> (2 * slot)) & 3 == 3 - exp
 
 
+def test_window_masks_both_forms_against_the_definition(emu):
+    """The scalar mask algebra by itself, every window length 1..32: OK[j] (window ending at byte j of the lane is emitted) from
+    G[i] (byte i of the lane is a base), as 64-bit lane masks - in the finished form (window_masks / window_masks1, used by the
+    round-1 kernels) and in the form whose last AND is left to the masked region (window_masks*_ab: exec = A & B) - against
+    the definition: lanes 0 / 1 are halo lanes and emit nothing; lane l emits at byte j iff the k bytes ending there, reaching
+    back into lanes l - 1 and l - 2, are all bases."""
+    emu.emu_window_masks.restype = C.c_int
+    emu.emu_window_masks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(99)
+    for trial in range(60):
+        p_bad = [0.0, 0.01, 0.05, 0.3][trial % 4]
+        good = rng.random((64, 16)) >= p_bad                      # good[lane, byte]
+        if trial == 5:
+            good[:] = True
+        G = np.zeros(16, dtype=np.uint64)
+        for i in range(16):
+            G[i] = sum(1 << l for l in range(64) if good[l, i])
+        flat = good.reshape(-1)                                    # byte stream of the tile: lane * 16 + byte
+        for k in range(1, 33):
+            ok, ab = np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+            assert emu.emu_window_masks(G.ctypes.data, k, ok.ctypes.data, ab.ctypes.data) == 0
+            want = np.zeros(16, dtype=np.uint64)
+            for l in range(2, 64):
+                for j in range(16):
+                    e = l * 16 + j
+                    if flat[e - k + 1: e + 1].all():
+                        want[j] |= np.uint64(1 << l)
+            assert np.array_equal(ok, want), (trial, k, "finished form")
+            assert np.array_equal(ab, want), (trial, k, "A & B form")
+
+
 @pytest.mark.parametrize("k", list(range(1, 33)))
 def test_emu_vs_oracle_synthetic(emu, k):
     buf = O.synth_reads(0x5EED0002, 0, 40, 150, 8).tobytes()  # ~0.8% N, '\n' separators
