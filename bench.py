@@ -377,7 +377,7 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
                                         "seconds": round(best_pin, 4), "Gbases_s": round(c_reads * read_len / best_pin / 1e9, 2),
                                         "Mitems_s": round(items / best_pin / 1e6, 1), "bytes_out_per_item": 9,
                                         "GB_s_out": round(items * 9 / best_pin / 1e9, 1),
-                                        "note": "page-locked host arrays in and out (ntk_pinned_alloc), PCIe-inclusive; chunks of 16 MiB pipelined two deep",
+                                        "note": "page-locked host arrays in and out (ntk_pinned_alloc), PCIe-inclusive; chunks of 16 MiB, up to three in flight",
                                         "pageable_arrays": {"seconds": round(best_pg, 4), "Gbases_s": round(c_reads * read_len / best_pg / 1e9, 2)}}
     except (nt.NtkError, AttributeError) as e:  # pragma: no cover
         out["compat_batch_face_k21"] = {"error": str(e)}
