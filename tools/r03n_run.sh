@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03n
+mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r03n/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["roofline"]["traffic_source"][:60])
+PY
