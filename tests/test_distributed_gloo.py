@@ -125,3 +125,37 @@ def test_bench_refuses_more_gpus_than_are_visible():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "--gpus 64 but" in r.stderr and "usable gfx950 device(s) are visible" in r.stderr, r.stderr[-800:]
+
+
+def test_bench_reference_crate_harness_protocol(tmp_path):
+    """bench.py's `--cpu-reference-bin` path (prefer the real crate when cargo + a vendored registry exist; the
+    harness is rust/cpu_baseline, source only here): the reads go in as a file of fixed-stride records, one JSON line comes back.
+    A stand-in executable that speaks the same protocol through the oracle exercises the plumbing and the toolchain note."""
+    import json
+    import stat
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "fake_ntk_cpu_baseline"
+    fake.write_text(f"""#!{sys.executable}
+import json, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+import oracle as O
+path, n_reads, read_len, k, threads = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+buf = np.fromfile(path, dtype=np.uint8)[: n_reads * (read_len + 1)]
+offs = np.arange(n_reads + 1, dtype=np.uint64) * (read_len + 1)
+t0 = time.time()
+st = O.reduce_batch(buf, offs, 1, k, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE, threads)
+print(json.dumps({{"n_total": st["n_total"], "n_fwd": st["n_fwd"], "sum": st["sum"], "xor": st["xor"], "seconds": time.time() - t0}}))
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    n_reads, read_len, k = 3000, 150, 21
+    host = O.synth_reads(0x5EED0002, 0, n_reads, read_len, 1)
+    got = bench.cpu_reference_run(str(fake), host, n_reads, read_len, k, 2)
+    want = O.reduce_fused(host, k, True, True, True)
+    assert all(int(got[x]) == int(want[x]) for x in ("n_total", "n_fwd", "sum", "xor")) and got["seconds"] > 0
+    note = bench.reference_toolchain_note()
+    assert note.startswith("absent (") and "cargo" in note   # this image has no cargo: the C port is the baseline, and the line says why
+    eff, info = bench.effective_cpus()
+    assert 1 <= eff <= (os.cpu_count() or 1) and info["logical_cpus"] == os.cpu_count()
