@@ -469,7 +469,11 @@ struct DevMasks2 {
     // complement value, fl / rl = their lo words, o = histogram cell offset, t = the chosen lo word.
     // Measured against the round-2 region (exec move; atomic; mad; xor; exec AND; own-cell atomic): -6.5 % kernel time at k = 21
     // (profiles/r03a): every exec write stalls the VALU for ~3 cycles and LDS ops are the most expensive instructions of the loop.
+#ifdef NTK_ABL_NOEXEC    // ablation: exec is never narrowed (what a tile without breaks could run, were it not for the halo lanes)
+#define NTK_R_EXEC(i) ""
+#else
 #define NTK_R_EXEC(i) "s_and_b64 exec, %[A" #i "], %[B" #i "]\n"
+#endif
 #define NTK_R_MASKS(i) [A##i] "s"(VA[pos[i]]), [B##i] "s"(VB[pos[i]])
 #ifdef NTK_ABL_NOLDS      // ablations of tools/kbench.hip (wrong results, same instruction stream otherwise)
 #define NTK_R_HIST(i) ""
@@ -652,11 +656,11 @@ struct DevMasks2 {
         region_plain<false>(pos, off, v, v);
     }
     template <class S>
-    __device__ __forceinline__ void emit_min4(S &, const int (&pos)[4], const uint32_t (&prefix)[4], const uint32_t (&lo)[4], const uint32_t (&fb)[4])
+    __device__ __forceinline__ void emit_min4(S &, const int (&pos)[4], const uint32_t (&cell4)[4], const uint32_t (&lo)[4], const uint32_t (&fb)[4])
     {
-        uint32_t off[4];
+        uint32_t off[4];   // cell4 = the value's top 14 bits, times four
 #pragma unroll
-        for (int i = 0; i < 4; i++) off[i] = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
+        for (int i = 0; i < 4; i++) off[i] = HB == 14 ? cell4[i] : (cell4[i] >> 4) << 2;
         region_plain<true>(pos, off, lo, fb);
     }
     // Forward-only builds, 17 <= K <= 32 (lane_tile_sv2_fwd).  kLight: T[0], T[1] carry their position's prefix in bits 31:16 and

@@ -894,16 +894,16 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
 #pragma unroll
     for (int jb = 0; jb < 16; jb += 4) {
         const int pos[4] = {jb, jb + 1, jb + 2, jb + 3};
-        uint32_t lo[4], pfxw[4], fb[4];
+        uint32_t lo[4], cell4[4], fb[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t mh = (uint32_t)(win[jb + i] >> 32), ml = (uint32_t)win[jb + i];
             lo[i] = alignbit(mh, ml, 6);                                   // low 32 bits of the value
-            // the value's top 14 bits = key bits [2K-8, 2K+6)
-            pfxw[i] = (2 * K - 8 >= 32 ? mh >> ((2 * K - 40) & 31) : alignbit(mh, ml, (2 * K - 8) & 31)) & 0x3FFFu;
+            // the value's top 14 bits = key bits [2K-8, 2K+6); times four (the byte offset of a 14-bit histogram cell) = key >> (2K-10), low two bits cleared
+            cell4[i] = (2 * K - 10 >= 32 ? mh >> ((2 * K - 42) & 31) : alignbit(mh, ml, (2 * K - 10) & 31)) & 0xFFFCu;
             fb[i] = ml & 1u;
         }
-        mp.emit_min4(sink, pos, pfxw, lo, fb);
+        mp.emit_min4(sink, pos, cell4, lo, fb);
     }
 }
 

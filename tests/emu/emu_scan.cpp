@@ -235,12 +235,12 @@ struct EmuMP2 {
     uint64_t nf_bits = 0;
     bool min_mode = false, tie_rc = false;
     template <class S>
-    void emit_min4(S &, const int (&pos)[4], const uint32_t (&prefix)[4], const uint32_t (&lo)[4], const uint32_t (&fb)[4])
+    void emit_min4(S &, const int (&pos)[4], const uint32_t (&cell4)[4], const uint32_t (&lo)[4], const uint32_t (&fb)[4])
     {
         min_mode = true;
         for (int i = 0; i < 4; i++) {
             if (!valid(pos[i])) continue;
-            const uint32_t off = HB == 14 ? prefix[i] << 2 : (prefix[i] >> 2) << 2;
+            const uint32_t off = HB == 14 ? cell4[i] : (cell4[i] >> 4) << 2;
             cells[off >> 2]++;
             sum += lo[i]; xlo ^= lo[i]; nf_bits += fb[i];
         }
