@@ -739,7 +739,7 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
 }
 
 // sv2 for k <= 16 ("word" builds: a value is one 32-bit word).  Values are kept LEFT-ALIGNED (the k-mer in the top 2K bits,
-// zeros below): forward = fw[j] << (32 - 2K), reverse complement = the top 2K bits of rw[j] (one AND); left-aligned words order
+// zeros below): forward = the window ending 16 - K bases after j, reverse complement = rw[j], each with the low bits cleared (one AND); left-aligned words order
 // like the values, their top 14 bits are the histogram cell whatever K is (K < 7: the cell index is the value shifted up), and
 // the digests are accumulated left-aligned and shifted down once per block (sum of < 2^32 words of < 2^32: no overflow).
 // No cross-lane words beyond the two code words (a window never reaches past the previous lane).  FWD: forward-only builds.
@@ -759,8 +759,11 @@ NTK_HD void lane_tile_sv2w(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t r
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int j = pos[i];
-            const uint32_t fwj = j == 15 ? code : alignbit(c1, code, 30 - 2 * j);
-            f[i] = S ? fwj << S : fwj;
+            // forward: the K bases ending at base j on top, zeros below = the stream window that ends S / 2 bases later with its low S
+            // bits cleared (one shift-class op and a full-rate AND; shifting the window ending at j up would be two half-rate ops:
+            // v_lshlrev_b32 issues at half rate on gfx950 even with a constant shift, v_lshrrev_b32 at full rate - tools/ubench.hip)
+            const int sh = 30 - 2 * j - S;   // bits of `code` below the wanted window
+            f[i] = j == 15 ? (S ? code << S : code) : ((sh > 0 ? alignbit(c1, code, sh & 31) : (sh == 0 ? code : code << ((-sh) & 31))) & hmask);
             r[i] = FWD ? 0u : ((j == 15 ? rcode : alignbit(rcode, r1, 2 * j + 2)) & hmask);
         }
         if constexpr (FWD) mp.emit_word_fwd(sink, pos, f);

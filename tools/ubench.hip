@@ -142,6 +142,51 @@ BENCH_KERNEL(k_lshlrev, {
     asm volatile("v_lshlrev_b32 %0, %0, %1\n v_lshlrev_b32 %2, %2, %3\n v_lshlrev_b32 %4, %4, %5\n v_lshlrev_b32 %6, %6, %7\n"
                  "v_lshlrev_b32 %1, %1, %0\n v_lshlrev_b32 %3, %3, %2\n v_lshlrev_b32 %5, %5, %4\n v_lshlrev_b32 %7, %7, %6\n"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_lshl_const, {
+    asm volatile("v_lshlrev_b32 %0, 3, %1\n v_lshlrev_b32 %2, 3, %3\n v_lshlrev_b32 %4, 3, %5\n v_lshlrev_b32 %6, 3, %7\n"
+                 "v_lshlrev_b32 %1, 5, %0\n v_lshlrev_b32 %3, 5, %2\n v_lshlrev_b32 %5, 5, %4\n v_lshlrev_b32 %7, 5, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_lshr_vgpr, {
+    asm volatile("v_lshrrev_b32 %0, %0, %1\n v_lshrrev_b32 %2, %2, %3\n v_lshrrev_b32 %4, %4, %5\n v_lshrrev_b32 %6, %6, %7\n"
+                 "v_lshrrev_b32 %1, %1, %0\n v_lshrrev_b32 %3, %3, %2\n v_lshrrev_b32 %5, %5, %4\n v_lshrrev_b32 %7, %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_brev, {
+    asm volatile("v_bfrev_b32 %0, %1\n v_bfrev_b32 %2, %3\n v_bfrev_b32 %4, %5\n v_bfrev_b32 %6, %7\n"
+                 "v_bfrev_b32 %1, %0\n v_bfrev_b32 %3, %2\n v_bfrev_b32 %5, %4\n v_bfrev_b32 %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_min_f64, {
+    asm volatile("v_min_f64 %0, %0, %1\n v_min_f64 %1, %1, %2\n v_min_f64 %2, %2, %3\n v_min_f64 %3, %3, %0\n"
+                 "v_min_f64 %0, %0, %2\n v_min_f64 %1, %1, %3\n v_min_f64 %2, %2, %0\n v_min_f64 %3, %3, %1\n"
+                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)); })
+BENCH_KERNEL(k_mov, {
+    asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %4, %5\n v_mov_b32 %6, %7\n"
+                 "v_mov_b32 %1, %0\n v_mov_b32 %3, %2\n v_mov_b32 %5, %4\n v_mov_b32 %7, %6\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+#define UB_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+BENCH_KERNEL(k_min_dpp, {
+    asm volatile("v_min_u32_dpp %0, %1, %0" UB_DPP "v_min_u32_dpp %2, %3, %2" UB_DPP "v_min_u32_dpp %4, %5, %4" UB_DPP "v_min_u32_dpp %6, %7, %6" UB_DPP
+                 "v_min_u32_dpp %1, %0, %1" UB_DPP "v_min_u32_dpp %3, %2, %3" UB_DPP "v_min_u32_dpp %5, %4, %5" UB_DPP "v_min_u32_dpp %7, %6, %7" UB_DPP
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_cndmask_dpp, {
+    asm volatile("v_cndmask_b32_dpp %0, %1, %0, vcc" UB_DPP "v_cndmask_b32_dpp %2, %3, %2, vcc" UB_DPP "v_cndmask_b32_dpp %4, %5, %4, vcc" UB_DPP "v_cndmask_b32_dpp %6, %7, %6, vcc" UB_DPP
+                 "v_cndmask_b32_dpp %1, %0, %1, vcc" UB_DPP "v_cndmask_b32_dpp %3, %2, %3, vcc" UB_DPP "v_cndmask_b32_dpp %5, %4, %5, vcc" UB_DPP "v_cndmask_b32_dpp %7, %6, %7, vcc" UB_DPP
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3)); })
+BENCH_KERNEL(k_subb_dpp, {
+    asm volatile("v_subb_co_u32_dpp %0, vcc, %1, %0, vcc" UB_DPP "v_subb_co_u32_dpp %2, vcc, %3, %2, vcc" UB_DPP "v_subb_co_u32_dpp %4, vcc, %5, %4, vcc" UB_DPP "v_subb_co_u32_dpp %6, vcc, %7, %6, vcc" UB_DPP
+                 "v_subb_co_u32_dpp %1, vcc, %0, %1, vcc" UB_DPP "v_subb_co_u32_dpp %3, vcc, %2, %3, vcc" UB_DPP "v_subb_co_u32_dpp %5, vcc, %4, %5, vcc" UB_DPP "v_subb_co_u32_dpp %7, vcc, %6, %7, vcc" UB_DPP
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3) : : "vcc"); })
+// the strand pick of the wide builds as the kernel issues it (s_nop; borrow compare; min; select; mask to an SGPR pair), two per iteration
+BENCH_KERNEL(k_pick_dpp, {
+    asm volatile("s_mov_b64 vcc, -1\n v_subb_co_u32_dpp %4, vcc, %0, %1, vcc" UB_DPP "v_min_u32_dpp %5, %0, %1" UB_DPP "v_cndmask_b32_dpp %6, %2, %3, vcc" UB_DPP "s_mov_b64 s[20:21], vcc\n"
+                 "s_mov_b64 vcc, -1\n v_subb_co_u32_dpp %4, vcc, %1, %0, vcc" UB_DPP "v_min_u32_dpp %7, %1, %0" UB_DPP "v_cndmask_b32_dpp %6, %3, %2, vcc" UB_DPP "s_mov_b64 s[22:23], vcc\n"
+                 "v_xor_b32 %0, %0, %5\n v_xor_b32 %1, %1, %7\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3) : : "vcc", "s20", "s21", "s22", "s23"); })
+// ... and with plain instructions plus the two moves they save
+BENCH_KERNEL(k_pick_mov, {
+    asm volatile("v_mov_b32_dpp %4, %0" UB_DPP "v_mov_b32_dpp %6, %2" UB_DPP "v_cmp_le_u32 s[20:21], %4, %1\n v_min_u32 %5, %4, %1\n v_cndmask_b32 %6, %6, %3, s[20:21]\n"
+                 "v_mov_b32_dpp %4, %1" UB_DPP "v_mov_b32_dpp %6, %3" UB_DPP "v_cmp_le_u32 s[22:23], %4, %0\n v_min_u32 %7, %4, %0\n v_cndmask_b32 %6, %6, %2, s[22:23]\n"
+                 "v_xor_b32 %0, %0, %5\n v_xor_b32 %1, %1, %7\n"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3) : : "vcc", "s20", "s21", "s22", "s23"); })
 BENCH_KERNEL(k_sub, {
     asm volatile("v_sub_u32 %0, %0, %1\n v_sub_u32 %2, %2, %3\n v_sub_u32 %4, %4, %5\n v_sub_u32 %6, %6, %7\n"
                  "v_sub_u32 %1, %1, %0\n v_sub_u32 %3, %3, %2\n v_sub_u32 %5, %5, %4\n v_sub_u32 %7, %7, %6\n"
@@ -410,7 +455,7 @@ int main()
                 {"v_mad_u64_u32", k_mulu64u32}, {"v_cmp_ne_u32_sdwa (byte sel)", k_cmp_sdwa}, {"SALU only (or/lshl/bcnt/add b64)", k_salu_or64},
                 {"VALU add + SALU 1:1", k_mixed_valu_salu}, {"VALU add + SALU 1:3", k_mixed_valu_2salu}, {"v_lshl_or_b32", k_lshl_or}, {"v_bfe_u32", k_bfe},
                 {"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32_e64 sgpr", k_cndmask_e64}, {"v_min_u32_sdwa word1", k_min_sdwa}, {"v_and_b32 literal", k_and_literal}, {"v_and_b32 sgpr", k_and_sgpr}, {"ds_add_u32 own cell", k_ds_add_own}, {"ds_add_u32 random cell", k_ds_add_rand}, {"mix alignbit/xor alternating", k_mix_align_xor}, {"mix alignbit x2 / xor x2", k_mix_align2_xor2}, {"mix xor/and-literal/lshr", k_mix_xor_and_lshr}, {"mix runs: 8 alignbit then 8 xor (16 per 8 counted -> x0.5)", k_mix_run8},
-                {"P6a masked region x4 (x2 = cycles per position)", k_p6a}, {"P6b no LDS, v_add count (x2/pos)", k_p6b}, {"P6c hist LDS + v_add count (x2/pos)", k_p6c}, {"P6d exec + 2 LDS only (x2/pos)", k_p6d}, {"P6e cndmask-zero, no exec (x2/pos)", k_p6e}, {"P6f exec + mad + xor (x2/pos)", k_p6f}, {"P6g exec + lshl_add_u64 + xor (x2/pos)", k_p6g}, {"P6h exec + xor (x2/pos)", k_p6h}, {"v_lshrrev_b32", k_lshr32}, {"v_and_or_b32", k_and_or}, {"v_xor_b32", k_xor32}, {"v_min_u32", k_min_u32}, {"v_mul_u32_u24", k_mul_u24}, {"v_lshlrev_b32", k_lshlrev}, {"v_sub_u32", k_sub}, {"v_dot4_u32_u8", k_dot4}, {"v_mad_u32_u24", k_mad_u24}, {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_xad_u32", k_xad}, {"v_pk_add_u16", k_pk_add_u16}, {"v_pk_min_u16", k_pk_min_u16}, {"v_sad_u8", k_sad_u8}, {"v_msad_u8", k_msad}, {"v_lerp_u8", k_cvt_pk_u8}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
+                {"P6a masked region x4 (x2 = cycles per position)", k_p6a}, {"P6b no LDS, v_add count (x2/pos)", k_p6b}, {"P6c hist LDS + v_add count (x2/pos)", k_p6c}, {"P6d exec + 2 LDS only (x2/pos)", k_p6d}, {"P6e cndmask-zero, no exec (x2/pos)", k_p6e}, {"P6f exec + mad + xor (x2/pos)", k_p6f}, {"P6g exec + lshl_add_u64 + xor (x2/pos)", k_p6g}, {"P6h exec + xor (x2/pos)", k_p6h}, {"v_lshrrev_b32", k_lshr32}, {"v_and_or_b32", k_and_or}, {"v_xor_b32", k_xor32}, {"v_min_u32", k_min_u32}, {"v_mul_u32_u24", k_mul_u24}, {"v_lshlrev_b32", k_lshlrev}, {"v_lshlrev_b32 by a constant", k_lshl_const}, {"v_lshrrev_b32 by a VGPR", k_lshr_vgpr}, {"v_bfrev_b32", k_brev}, {"v_min_f64", k_min_f64}, {"v_mov_b32", k_mov}, {"v_min_u32_dpp", k_min_dpp}, {"v_cndmask_b32_dpp", k_cndmask_dpp}, {"v_subb_co_u32_dpp", k_subb_dpp}, {"strand pick x2, DPP-fused (8 VALU counted; x4 = cycles per pick)", k_pick_dpp}, {"strand pick x2, moves + plain (8 counted of 12; x4 = cycles per pick)", k_pick_mov}, {"v_sub_u32", k_sub}, {"v_dot4_u32_u8", k_dot4}, {"v_mad_u32_u24", k_mad_u24}, {"v_add3_u32", k_add3}, {"v_or3_b32", k_or3}, {"v_xad_u32", k_xad}, {"v_pk_add_u16", k_pk_add_u16}, {"v_pk_min_u16", k_pk_min_u16}, {"v_sad_u8", k_sad_u8}, {"v_msad_u8", k_msad}, {"v_lerp_u8", k_cvt_pk_u8}, {"lds atomicAdd random bin (+lcg)", k_ldsadd}, {"lcg only", k_ldsadd_lcg_only}};
     // (k_ds_misaligned is not run: on gfx950 a ds_add_u32 whose address is not 4-byte aligned raises a memory violation - measured, r02a)
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
