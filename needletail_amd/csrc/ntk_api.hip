@@ -270,8 +270,9 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
                             : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));
     if (!fn) return NTK_ERR_BAD_ARG;
     // every reduce-mode scan (any path, any k, with or without a quality stream, fused minimizers) is a scan2 build: 768 threads, two
-    // blocks per CU = 6 waves per SIMD, which needs <= 80 VGPRs.  A build above that (the quality-masked k = 28..30 builds: 82-84)
-    // would get ONE 768-thread block per CU; it runs 640-thread blocks instead (two per CU: 5 waves per SIMD).
+    // blocks per CU = 6 waves per SIMD, which needs <= 80 VGPRs.  A build above that would get ONE 768-thread block per CU; it runs
+    // 640-thread blocks instead (two per CU: 5 waves per SIMD).  (No shipped build is above it: the k-mer builds need <= 75, the
+    // fused-minimizer builds are compiled under the 6-wave budget, csrc/Makefile MIN_FLAGS.)
     int threads = !reduce ? 256 : (c->launch_threads ? c->launch_threads : 768);
     if (reduce && !c->launch_threads) {
         auto it = c->auto_threads.find(fn);

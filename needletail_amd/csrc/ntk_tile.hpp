@@ -844,22 +844,31 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
         fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
         rw[D - g] = xl.prev(kSlotRw + 16 - g, rw[D + 16 - g]);
     }
-    // canonical keys of the 16 own positions
+    // canonical keys of the 16 own positions.  Low word = (lo word << 6) | tag: shifting a stream window up by three bases is the window
+    // that ends three bases LATER (forward) / starts three bases EARLIER (reverse complement) with its low 6 bits replaced - one
+    // full-rate v_bitop3 on a word that is in a register anyway, where the shift-and-or is a half-rate op (13 of the 16 positions
+    // per strand: the other three would need the next lane's / an unfetched word).
     uint64_t key[16];
+    constexpr uint32_t kTagMask = 0xFFFFFFC0u;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t idx2 = (uint32_t)(16 + j) << 1;
         if constexpr (K > 16) {
-            const uint64_t kf = ((uint64_t)alignbit(kBit62, fw[j], HS) << 32) | ((fw[D + j] << 6) | (idx2 | fbitF));
-            const uint64_t kr = ((uint64_t)alignbit(kBit62, rw[D + j], HS) << 32) | ((rw[j] << 6) | (idx2 | fbitR));
+            const uint32_t lf = j <= 12 ? and_or(fw[D + (j <= 12 ? j + 3 : j)], kTagMask, idx2 | fbitF) : ((fw[D + j] << 6) | (idx2 | fbitF));
+            const uint32_t lr = j >= 3 ? and_or(rw[j >= 3 ? j - 3 : j], kTagMask, idx2 | fbitR) : ((rw[j] << 6) | (idx2 | fbitR));
+            const uint64_t kf = ((uint64_t)alignbit(kBit62, fw[j], HS) << 32) | lf;
+            const uint64_t kr = ((uint64_t)alignbit(kBit62, rw[D + j], HS) << 32) | lr;
             key[j] = mp.min64(kf, kr);
         } else {
             // K <= 16 (the common (15, 10) sketch): the value is the low 2K bits of the forward word ending at base j / the top 2K
             // bits of the reverse-complement word starting there; the key is built from that one word
             constexpr uint32_t vmask = K == 16 ? 0xFFFFFFFFu : ((1u << ((2 * K) & 31)) - 1u);
+            constexpr int G = K - 13;   // (value << 6) of the right-aligned reverse-complement value = the word starting G bases earlier, low 6 bits cleared
             const uint32_t vf = K == 16 ? fw[j] : (fw[j] & vmask), vr = K == 16 ? rw[j] : (rw[j] >> ((32 - 2 * K) & 31));
-            const uint64_t kf = ((uint64_t)alignbit(kBit62, vf, HS) << 32) | ((vf << 6) | (idx2 | fbitF));
-            const uint64_t kr = ((uint64_t)alignbit(kBit62, vr, HS) << 32) | ((vr << 6) | (idx2 | fbitR));
+            const uint32_t lf = j <= 12 ? and_or(fw[j <= 12 ? j + 3 : j], vmask << 6, idx2 | fbitF) : ((vf << 6) | (idx2 | fbitF));
+            const uint32_t lr = j >= G ? and_or(rw[j >= G ? j - G : j], kTagMask, idx2 | fbitR) : ((vr << 6) | (idx2 | fbitR));
+            const uint64_t kf = ((uint64_t)alignbit(kBit62, vf, HS) << 32) | lf;
+            const uint64_t kr = ((uint64_t)alignbit(kBit62, vr, HS) << 32) | lr;
             key[j] = mp.min64(kf, kr);
         }
     }
