@@ -294,19 +294,14 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     del qual
     torch.cuda.empty_cache()
 
-    # fused minimizers (configs[4] kernel side): w = 11, k = 21, resident
+    # fused minimizers (configs[4] kernel side): w = 11, k = 21, resident; a prefix against the oracle first
     try:
-        ms_t0 = time.perf_counter()
-        for _ in range(2):
-            ctx.accum_reset(); ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            ctx.accum_reset(); ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
-        out["minimizers_w11_k21_resident"] = {"ms_per_pass": round(dt * 1e3, 3), "Gbases_s": round(reads * read_len / dt / 1e9, 1)}
-        del ms_t0
+        ctx.accum_reset()
+        ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
+        if not stats_equal(ctx.accum_read(), O.minimizers_reduce(hs, 21, 11, True, True)):
+            raise SystemExit("secondary: fused minimizers differ from the oracle on the prefix")
+        ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)), 10)
+        out["minimizers_w11_k21_resident"] = {"kernel_ms": round(ms, 4), "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
     except nt.NtkError as e:  # pragma: no cover
         out["minimizers_w11_k21_resident"] = {"error": str(e)}
 

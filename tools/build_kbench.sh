@@ -19,6 +19,7 @@ hipcc $S -DNTK_ABL_NOMASKALG -o kb_a_nomaskalg kbench.hip 2>/dev/null &
 hipcc $S -DNTK_ABL_NOSDWA -DNTK_ABL_NOMASKALG -o kb_a_nosdwa kbench.hip 2>/dev/null &
 hipcc $S -DNTK_ABL_NODIGEST -o kb_a_nodigest kbench.hip 2>/dev/null &
 hipcc $S -DNTK_ABL_NODIGEST -DNTK_ABL_NOLDS -o kb_a_noemit kbench.hip 2>/dev/null &
+hipcc $S -DNTK_ABL_NOEXEC -o kb_a_noexec kbench.hip 2>/dev/null &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ubench ubench.hip 2>/dev/null &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -o ubench3 ubench3.hip 2>/dev/null &
 wait

@@ -20,7 +20,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 if [ -x tools/kb_s2_hb14 ]; then   # tools/build_kbench.sh; 2 x 768 threads per CU, 256 work counters, chunks of 24 tiles
   ( cd tools; for v in cur; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 768 512 20 r01_kernel 16 8; done
     [ -x ./kb_old ] && ./kb_old 10000000 21 512 768 20 r02_region 24 256
-    for v in s2_hb14 s2_default a_floor a_nolds a_nomaskalg a_nosdwa a_nodigest a_noemit a_loads; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 512 768 20 $v 24 256; done
+    for v in s2_hb14 s2_default a_floor a_nolds a_nomaskalg a_nosdwa a_nodigest a_noemit a_noexec a_loads; do [ -x ./kb_$v ] && ./kb_$v 10000000 21 512 768 20 $v 24 256; done
     ./kb_a_loads 10000000 21 512 768 20 loads_8_counters 16 8
     [ -x ./kb_old ] && ./kb_old 10000000 31 512 768 20 r02_region_k31 24 256
     ./kb_s2_hb14 10000000 31 512 768 20 s2_hb14_k31 24 256
