@@ -223,8 +223,15 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     out = {}
 
     def kernel_ms(fn, reps):
-        for _ in range(3):
+        # warm-up by time, not by count: each of these measurements follows an oracle check on the CPU (an idle GPU clocks down)
+        # and a sub-millisecond kernel needs some tens of launches to be back at its steady-state clock (the headline has --preheat-ms)
+        t_warm = time.perf_counter()
+        n_warm = 0
+        while n_warm < 3 or time.perf_counter() - t_warm < 0.05:
             fn()
+            n_warm += 1
+            if n_warm % 8 == 0:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         ctx.scan_time_ms()
         ctx.enable_timing(True)
