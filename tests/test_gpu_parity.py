@@ -1091,6 +1091,50 @@ def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, 
         assert np.array_equal(pos[o:o + len(p_)], p_) and np.array_equal(val[o:o + len(p_)], v_)
 
 
+def test_batched_compat_face_with_page_locked_arrays(ctx):
+    """ntk_pinned_alloc / ntk_pinned_free: the caller's arrays page-locked by the library (the copies of the batched compat face then
+    run at the PCIe rate instead of through a bounce buffer) - same results as with pageable arrays, element-wise against the oracle."""
+    import ctypes as C
+    from needletail_amd import _lib as L
+    lib = L.lib()
+    assert lib.ntk_pinned_alloc(64, None) != 0                       # no out pointer: an argument error, not a crash
+    lib.ntk_pinned_free(None)                                        # freeing nothing is allowed
+    held = []
+
+    def pinned(n_items, dtype):
+        n_bytes = max(int(n_items) * np.dtype(dtype).itemsize, 8)
+        ptr = C.c_void_p()
+        L.check(lib.ntk_pinned_alloc(n_bytes, C.byref(ptr)), "ntk_pinned_alloc")
+        assert ptr.value
+        held.append(ptr)
+        return np.frombuffer((C.c_uint8 * n_bytes).from_address(ptr.value), dtype=dtype)[:int(n_items)]
+
+    reads = [bytes(r) for r in O.synth_reads(0x5EED0002, 3, 5000, 150, 16).reshape(5000, 151)[:, :150]] + [b"", b"ACGTN" * 7]
+    want_counts, want_pos, want_flg = nt.canonical_kmers_batch(reads, 21, ctx)   # pageable arrays (checked against the oracle above)
+    flat = pinned(sum(len(r) for r in reads), np.uint8); flat[:] = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = pinned(len(reads) + 1, np.uint64); offs[0] = 0; np.cumsum([len(r) for r in reads], out=offs[1:])
+    cap = len(want_pos)
+    counts, pos, flg = pinned(len(reads), np.uint64), pinned(cap, np.uint64), pinned(cap, np.uint8)
+    tot = C.c_uint64(0)
+    try:
+        for _ in range(3):   # the banks of the pipeline are re-used from call to call
+            counts[:] = 0; pos[:] = 0; flg[:] = 0
+            L.check(lib.ntk_canonical_kmers_batch(ctx._h, C.cast(flat.ctypes.data, C.c_char_p), offs.ctypes.data, len(reads), 21, counts.ctypes.data,
+                                                  pos.ctypes.data, flg.ctypes.data, cap, C.byref(tot)), "ntk_canonical_kmers_batch")
+            assert tot.value == cap and np.array_equal(counts, want_counts) and np.array_equal(pos, want_pos) and np.array_equal(flg, want_flg)
+        o = 0
+        for r, n in list(zip(reads, counts.tolist()))[:50] + [(reads[-1], int(counts[-1]))]:
+            p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), 21)
+            if r is reads[-1]:
+                o = cap - n
+            assert n == len(p_) and np.array_equal(pos[o:o + n], p_) and np.array_equal(flg[o:o + n], f_)
+            o += n
+    finally:
+        del flat, offs, counts, pos, flg
+        for ptr in held:
+            lib.ntk_pinned_free(ptr)
+
+
 def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatch):
     """configs[4] kernel side: the fused minimizer builds (one pass, no scratch planes) against the literal minimizer of every
     window (oracle) and against the two-pass path (materialise + window-min) on the same buffer, for every fused (k, w),
