@@ -594,13 +594,13 @@ struct DevMasks2 {
         if constexpr (K <= 6) return alignbit(rep, v, 30 - 2 * K);
         else return cell_offset_hi(v);
     }
-    template <bool TIE_RC_, class S>
+    template <bool TIE_RC_, uint32_t VMASK, class S>   // VMASK != ~0: the candidates carry junk below the value (odd K, lane_tile_sv2w): the chosen word is masked
     __device__ __forceinline__ void emit_word(S &, const int (&pos)[4], const uint32_t (&f)[4], const uint32_t (&r)[4])
     {
         uint32_t v[4], off[4], cn, nf_grp;
         uint64_t sd;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { v[i] = f[i] < r[i] ? f[i] : r[i]; off[i] = word_cell(v[i]); }
+        for (int i = 0; i < 4; i++) { v[i] = (f[i] < r[i] ? f[i] : r[i]) & VMASK; off[i] = word_cell(v[i]); }
 #define NTK_R_POS(i, CMP, CNT)                                              \
         NTK_R_EXEC(i)                                                       \
         CMP " vcc, %[f" #i "], %[r" #i "]\n"                                \

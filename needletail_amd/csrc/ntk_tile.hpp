@@ -743,12 +743,17 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
 // like the values, their top 14 bits are the histogram cell whatever K is (K < 7: the cell index is the value shifted up), and
 // the digests are accumulated left-aligned and shifted down once per block (sum of < 2^32 words of < 2^32: no overflow).
 // No cross-lane words beyond the two code words (a window never reaches past the previous lane).  FWD: forward-only builds.
+// Odd K, canonical (LAZY): a k-mer of odd length is never its own reverse complement (its middle base would have to be its own
+// complement), so the top 2K bits of the two candidates always differ and decide compare and minimum whatever sits below them:
+// the candidates go into the region UNMASKED and only the chosen word is masked (one AND per position instead of two).
 template <bool TIE_RC, int K, bool FWD, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2w(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
 {
     static_assert(K >= 1 && K <= 16, "word builds");
     constexpr int S = 32 - 2 * K;
-    constexpr uint32_t hmask = K == 16 ? 0xFFFFFFFFu : ~((1u << (S & 31)) - 1u);
+    constexpr bool LAZY = (K & 1) && !FWD;
+    constexpr uint32_t vmask = K == 16 ? 0xFFFFFFFFu : ~((1u << (S & 31)) - 1u);   // the value's bits
+    constexpr uint32_t hmask = LAZY ? 0xFFFFFFFFu : vmask;                           // applied to each candidate
     const uint32_t c1 = xl.prev(kSlotCode, code);
     uint32_t r1 = 0;
     if (!FWD) r1 = xl.prev(kSlotRcode, rcode);
@@ -767,7 +772,7 @@ NTK_HD void lane_tile_sv2w(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t r
             r[i] = FWD ? 0u : ((j == 15 ? rcode : alignbit(rcode, r1, 2 * j + 2)) & hmask);
         }
         if constexpr (FWD) mp.emit_word_fwd(sink, pos, f);
-        else mp.template emit_word<TIE_RC>(sink, pos, f, r);   // the chosen value is min(f, r); the compare (ties: TIE_RC) only feeds the strand count
+        else mp.template emit_word<TIE_RC, (LAZY ? vmask : 0xFFFFFFFFu)>(sink, pos, f, r);   // the chosen value is min(f, r) [& vmask]; the compare (ties: TIE_RC) only feeds the strand count
     }
 }
 

@@ -197,12 +197,12 @@ struct EmuMP2 {
         const uint32_t rep = (uint32_t)lane & (uint32_t)(kWordCopies - 1);
         return K <= 6 ? ((v >> ((30 - 2 * K) & 31)) | (rep << ((2 * K + 2) & 31))) : cell_offset_hi(v);
     }
-    template <bool TIE_RC_, class S>
+    template <bool TIE_RC_, uint32_t VMASK, class S>
     void emit_word(S &, const int (&pos)[4], const uint32_t (&f)[4], const uint32_t (&r)[4])   // word builds (K <= 16): left-aligned values
     {
         for (int i = 0; i < 4; i++) {
             if (!valid(pos[i])) continue;
-            const uint32_t v = f[i] < r[i] ? f[i] : r[i];
+            const uint32_t v = (f[i] < r[i] ? f[i] : r[i]) & VMASK;
             cells[word_cell(v) >> 2]++;
             sum += v; xlo ^= v;
             n_fwd += (TIE_RC_ ? f[i] < r[i] : f[i] <= r[i]) ? 1 : 0;
