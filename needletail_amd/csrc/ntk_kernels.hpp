@@ -788,21 +788,24 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #pragma unroll
         for (int i = 0; i < 16; i++) { mp.VA[i] = ~3ull; mp.VB[i] = ~0ull; }
 #endif
-        auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r) {
+        auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r, auto &&after_encode) {
             const bool tail = r >= a.tail_tile_rel;
             Raw16 raw{t.x, t.y, t.z, t.w};
             if constexpr (QM) raw = quality_break16(raw, Raw16{q.x, q.y, q.z, q.w}, a.q_add, a.q_sel);
 #ifdef NTK_ABL_LOADSONLY
             mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
+            after_encode();
 #elif defined(NTK_ABL_FLOOR)
             // floor kernel (tools/kbench.hip, profiles/r03*/floor.txt): no load, no encode, no validity - only the window words and
             // the per-position work, on synthetic register-resident stream words (two adds keep them changing from tile to tile)
             (void)tail; (void)raw;
+            after_encode();
             fl_code += fl_step; fl_rcode += fl_code;
             lane_tile_sv2<TIE_RC, K>(sink, xl, mp, fl_code, fl_rcode);
 #else
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
             mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
+            after_encode();
             if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
@@ -818,20 +821,24 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         if constexpr (QM) qa = load_qual(voff);
 #ifndef NTK_SV2_PINGPONG   // (two tiles per loop trip without register moves doubles the loop body: measured 5 - 25 % slower, profiles/r02b; with
                            //  the tile offset in the scalar operand and unconditional, clamped loads: no gain at k = 21, +4 % at k = 31, profiles/r03a/pp2_ab.txt)
-        for (uint32_t r = r0; r < r1; r++) {
-            if (r + 1 < r1) { tb = load_tile(voff + kTileStride); if constexpr (QM) qb = load_qual(voff + kTileStride); }
-            process(ta, qa, r);
-            ta = tb; qa = qb;
-        }
+        // One tile per trip.  The next tile is loaded into the SAME registers as soon as the encode and the validity compares have
+        // consumed the current one - the rest of the tile's work (most of it) hides the latency, and no rotation moves are needed
+        // (a separate next-tile buffer loaded at the top of the trip and moved at its end: +2 v_mov_b64, about 1 % slower at k = 21, 23
+        // and 31, profiles/r03d/lateload_ab*.txt; pinning the load's place with scheduling barriers: 3.7 % slower).
+        for (uint32_t r = r0; r < r1; r++)
+            process(ta, qa, r, [&] {
+                if (r + 1 < r1) { ta = load_tile(voff + kTileStride); if constexpr (QM) qa = load_qual(voff + kTileStride); }
+            });
+        (void)tb; (void)qb;
         if (false)
 #endif
         for (uint32_t r = r0; r < r1; r += 2) {
             const bool has_b = r + 1 < r1;   // wave-uniform
             if (has_b) { tb = load_tile(voff + kTileStride); if constexpr (QM) qb = load_qual(voff + kTileStride); }
-            process(ta, qa, r);
+            process(ta, qa, r, [] {});
             if (!has_b) break;
             if (r + 2 < r1) { ta = load_tile(voff + kTileStride); if constexpr (QM) qa = load_qual(voff + kTileStride); }
-            process(tb, qb, r + 1);
+            process(tb, qb, r + 1, [] {});
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }
