@@ -480,16 +480,37 @@ struct DevMasks2 {
 #else
 #define NTK_R_HIST(i) "ds_add_u32 %[o" #i "], %[one]\n"
 #endif
+#ifdef NTK_ABL_NOCOUNT     // ablation (wrong n_fwd): what the scalar forward count costs
+#define NTK_R_CNT_FIRST "s_mov_b32 %[nf], 0\n"
+#define NTK_R_CNT ""
+#define NTK_R_CNT_A ""
+#define NTK_R_CNT_B ""
+#else
 #define NTK_R_CNT_FIRST "s_bcnt1_i32_b64 %[nf], vcc\n"                                   /* the block's first position starts its count */
 #define NTK_R_CNT "s_bcnt1_i32_b64 %[cn], vcc\n s_add_u32 %[nf], %[nf], %[cn]\n"
+#define NTK_R_CNT_A "s_bcnt1_i32_b64 %[cn], vcc\n"
+#define NTK_R_CNT_B "s_add_u32 %[nf], %[nf], %[cn]\n"
+#endif
 #ifdef NTK_ABL_NODIGEST
 #define NTK_R_SUM_0(x) ""
 #define NTK_R_SUM_1(x) ""
 #define NTK_R_XOR(x) ""
 #else
+#ifdef NTK_ABL_NOSUM
+#define NTK_R_SUM_0(x) ""
+#define NTK_R_SUM_1(x) ""
+#elif defined(NTK_ABL_SUM32)   // ablation (wrong sum): the 64-bit sum as a full-rate 32-bit add
+#define NTK_R_SUM_0(x) "v_add_u32 %[sumA], %[sumA], " x "\n"
+#define NTK_R_SUM_1(x) "v_add_u32 %[sumB], %[sumB], " x "\n"
+#else
 #define NTK_R_SUM_0(x) "v_mad_u64_u32 %[sumA], %[sd], " x ", 1, %[sumA]\n"
 #define NTK_R_SUM_1(x) "v_mad_u64_u32 %[sumB], %[sd], " x ", 1, %[sumB]\n"
+#endif
+#ifdef NTK_ABL_NOXOR
+#define NTK_R_XOR(x) ""
+#else
 #define NTK_R_XOR(x) "v_xor_b32 %[xlo], %[xlo], " x "\n"
+#endif
 #endif
 #define NTK_R_SUM_2(x) NTK_R_SUM_0(x)
 #define NTK_R_SUM_3(x) NTK_R_SUM_1(x)
@@ -503,16 +524,50 @@ struct DevMasks2 {
         const uint32_t off[4] = {cell_offset_hi(Tm0), cell_offset_hi(Tm1), cell_offset_lo(Tm0), cell_offset_lo(Tm1)};
         uint32_t t0, t1, t2, t3, cn, nf_grp;
         uint64_t sd;
-#define NTK_R_POS(i, CMP, CNT)                                              \
+#ifndef NTK_REGION_ORDER
+#define NTK_REGION_ORDER 0
+#endif
+#if NTK_REGION_ORDER == 0
+#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
         NTK_R_EXEC(i)                                                       \
         CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
         "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
         NTK_R_SUM_##i("%[t" #i "]")                                         \
         NTK_R_XOR("%[t" #i "]")                                             \
         NTK_R_HIST(i)                                                       \
-        CNT
+        CNTA CNTB
+#elif NTK_REGION_ORDER == 1   /* a scalar op straight after each half-rate op: cmp, bcnt, cndmask, xor, mad, ds, add */
+#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
+        NTK_R_EXEC(i)                                                       \
+        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
+        CNTA                                                                \
+        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_R_XOR("%[t" #i "]")                                             \
+        NTK_R_SUM_##i("%[t" #i "]")                                         \
+        NTK_R_HIST(i)                                                       \
+        CNTB
+#elif NTK_REGION_ORDER == 2   /* cmp, bcnt, add, cndmask, xor, ds, mad */
+#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
+        NTK_R_EXEC(i)                                                       \
+        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
+        CNTA CNTB                                                           \
+        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_R_XOR("%[t" #i "]")                                             \
+        NTK_R_HIST(i)                                                       \
+        NTK_R_SUM_##i("%[t" #i "]")
+#else                          /* cmp, bcnt, cndmask, xor, add, mad, ds */
+#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
+        NTK_R_EXEC(i)                                                       \
+        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
+        CNTA                                                                \
+        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_R_XOR("%[t" #i "]")                                             \
+        CNTB                                                                \
+        NTK_R_SUM_##i("%[t" #i "]")                                         \
+        NTK_R_HIST(i)
+#endif
 #define NTK_R_IN(i) [o##i] "v"(off[i]), [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_R_MASKS(i)
-#define NTK_R_BODY(CMP) NTK_R_POS(0, CMP, NTK_R_CNT_FIRST) NTK_R_POS(1, CMP, NTK_R_CNT) NTK_R_POS(2, CMP, NTK_R_CNT) NTK_R_POS(3, CMP, NTK_R_CNT) "s_mov_b64 exec, -1\n"
+#define NTK_R_BODY(CMP) NTK_R_POS(0, CMP, NTK_R_CNT_FIRST, "") NTK_R_POS(1, CMP, NTK_R_CNT_A, NTK_R_CNT_B) NTK_R_POS(2, CMP, NTK_R_CNT_A, NTK_R_CNT_B) NTK_R_POS(3, CMP, NTK_R_CNT_A, NTK_R_CNT_B) "s_mov_b64 exec, -1\n"
 #define NTK_R_OPS                                                                                                                        \
         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),           \
           [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                                                                             \
@@ -697,6 +752,8 @@ struct DevMasks2 {
 #undef NTK_R_SUM_2
 #undef NTK_R_SUM_1
 #undef NTK_R_SUM_0
+#undef NTK_R_CNT_B
+#undef NTK_R_CNT_A
 #undef NTK_R_CNT
 #undef NTK_R_CNT_FIRST
 #undef NTK_R_HIST
