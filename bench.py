@@ -19,6 +19,7 @@ Before anything is timed every rank compares its WHOLE shard bit-exactly with th
 4096 bins); after timing, the all-reduced result is compared with the sum of the ranks' oracle results.
 """
 import argparse
+import collections
 import json
 import os
 import socket
@@ -372,15 +373,51 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
             handles.append(h); arrs.append(a)
         arrs[0][:] = src; arrs[1][:] = offs
         best_pin, _ = run(*arrs)
+        # the same items as two bit planes (ntk_canonical_kmers_batch_planes): the records are uploaded as they lie, 1/4 byte per
+        # sequence byte comes back, the host iterator walks the bits (reference src/kmer.rs:114-129 needs nothing else)
+        cap_w = c_reads * read_len // 16 + c_reads + 1
+        hp = [pinned(nb, dt_) for nb, dt_ in (((c_reads + 1) * 8, np.uint64), (cap_w * 2, np.uint16), (cap_w * 2, np.uint16))]
+        rec_bit, v16, r16 = (a for _, a in hp)
+        nw, tot = C.c_uint64(0), C.c_uint64(0)
+        best_pl = None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            L.check(L.lib().ntk_canonical_kmers_batch_planes(ctx._h, C.cast(arrs[0].ctypes.data, C.c_char_p), arrs[1].ctypes.data, c_reads, 21,
+                                                             rec_bit.ctypes.data, v16.ctypes.data, r16.ctypes.data, cap_w, C.byref(nw), C.byref(tot)),
+                    "ntk_canonical_kmers_batch_planes")
+            dt = time.perf_counter() - t0
+            best_pl = dt if best_pl is None else min(best_pl, dt)
+        popc = lambda a: int(np.unpackbits(a[: nw.value].view(np.uint8)).sum())
+        if not (tot.value == popc(v16) == ref["n_total"] and popc(r16) == ref["n_rc"]):
+            raise SystemExit("secondary: the bit-plane compat face differs from the resident scan")
+        # element-wise against the item form on a prefix of the records (both against the oracle in tests/test_gpu_parity.py)
+        o = 0
+        for i in range(2000):
+            n_i = int(arrs[2][i])
+            b0 = int(rec_bit[i])
+            bits = np.unpackbits(v16[b0 >> 4: (b0 + read_len + 15) >> 4].astype(">u2").view(np.uint8))[b0 & 15: (b0 & 15) + read_len - 20]
+            rbits = np.unpackbits(r16[b0 >> 4: (b0 + read_len + 15) >> 4].astype(">u2").view(np.uint8))[b0 & 15: (b0 & 15) + read_len - 20]
+            pos_i = np.flatnonzero(bits)
+            if not (np.array_equal(pos_i, arrs[3][o:o + n_i].astype(np.int64)) and np.array_equal(rbits[pos_i], arrs[4][o:o + n_i])):
+                raise SystemExit("secondary: the bit planes and the item arrays disagree on record %d" % i)
+            o += n_i
+        for h, _ in hp:
+            L.lib().ntk_pinned_free(h)
         for h in handles:
             L.lib().ntk_pinned_free(h)
-        del arrs, handles, src, offs
-        out["compat_batch_face_k21"] = {"call": "ntk_canonical_kmers_batch", "records": c_reads, "items": items,
-                                        "seconds": round(best_pin, 4), "Gbases_s": round(c_reads * read_len / best_pin / 1e9, 2),
-                                        "Mitems_s": round(items / best_pin / 1e6, 1), "bytes_out_per_item": 9,
-                                        "GB_s_out": round(items * 9 / best_pin / 1e9, 1),
-                                        "note": "page-locked host arrays in and out (ntk_pinned_alloc), PCIe-inclusive; chunks of 16 MiB, up to three in flight",
-                                        "pageable_arrays": {"seconds": round(best_pg, 4), "Gbases_s": round(c_reads * read_len / best_pg / 1e9, 2)}}
+        del arrs, handles, src, offs, hp, rec_bit, v16, r16
+        out["compat_batch_face_k21"] = {"call": "ntk_canonical_kmers_batch_planes", "records": c_reads, "items": items,
+                                        "seconds": round(best_pl, 4), "Gbases_s": round(c_reads * read_len / best_pl / 1e9, 2),
+                                        "Mitems_s": round(items / best_pl / 1e6, 1), "bytes_out_per_base": 0.25,
+                                        "GB_s_in": round(c_reads * read_len / best_pl / 1e9, 1),
+                                        "note": "valid / is_rc bit planes per window start + rec_bit[]; records uploaded as they lie (no packing pass), "
+                                                "page-locked host arrays (ntk_pinned_alloc), PCIe-inclusive: bound by the upload",
+                                        "item_arrays_form": {"call": "ntk_canonical_kmers_batch", "seconds": round(best_pin, 4),
+                                                             "Gbases_s": round(c_reads * read_len / best_pin / 1e9, 2),
+                                                             "Mitems_s": round(items / best_pin / 1e6, 1), "bytes_out_per_item": 9,
+                                                             "GB_s_out": round(items * 9 / best_pin / 1e9, 1),
+                                                             "pageable_arrays": {"seconds": round(best_pg, 4),
+                                                                                 "Gbases_s": round(c_reads * read_len / best_pg / 1e9, 2)}}}
     except (nt.NtkError, AttributeError) as e:  # pragma: no cover
         out["compat_batch_face_k21"] = {"error": str(e)}
     ctx.accum_reset()
@@ -432,42 +469,103 @@ class phase_deadline:
         return False
 
 
-def pmc_traffic(args, n_bytes):
-    """HBM bytes per scan-kernel launch from rocprofv3's TCC counters, collected live: one child run of this script per counter
-    (--pmc only, no trace domains), 5 steps each.  FETCH_SIZE counts 64-byte units of 128-byte requests on gfx950: a wide
-    coalesced streaming read shows up at exactly half its bytes (MI355X_MICROARCH.md, HBM) -> doubled; both counters are in KB.
-    Returns (bytes, source) or (None, None) when rocprofv3 is missing or a pass fails (the caller then falls back to the
-    profiles/ number and says so)."""
+def pmc_passes(args, n_bytes):
+    """Counters of the scan kernel, collected live: one child run of this script per pass under `rocprofv3 --pmc` (no trace domains),
+    5 steps each, per scan-kernel launch.  Pass 1 / 2: FETCH_SIZE / WRITE_SIZE (they do not fit one pass) -> HBM bytes; FETCH_SIZE counts
+    64-byte units of 128-byte requests on gfx950: a wide coalesced streaming read shows up at exactly half its bytes
+    (MI355X_MICROARCH.md, HBM) -> doubled; both counters are in KB.  Pass 3: SQ_INSTS_VALU / SALU / LDS, SQ_ACTIVE_INST_VALU,
+    GRBM_GUI_ACTIVE -> instructions per tile and shader cycles per tile per SIMD.  The kernel's NAME is taken from the counter rows
+    (the scan2_kernel instantiation with the most dispatches), not assumed.  Returns a dict; keys are missing for what could not be
+    collected (no rocprofv3, a failed pass)."""
     import csv
     import glob
     import shutil
     import tempfile
     tool = shutil.which("rocprofv3")
     if not tool:
-        return None, None
-    got = {}
+        return {}
     env = dict(os.environ, NTK_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--preheat-ms", "5", "--no-verify", "--no-cpu-baseline",
              "--no-secondary", "--no-pmc", "--reads", str(args.reads or 10_000_000), "--read-len", str(args.read_len), "--k", str(args.k),
              "--n-per-1024", str(args.n_per_1024), "--blocks", str(args.blocks), "--threads", str(args.threads)]
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    got, names = {}, collections.Counter()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]):
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
             try:
-                r = subprocess.run([tool, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                r = subprocess.run([tool, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp", env=env,
                                    capture_output=True, text=True, timeout=240)
             except (OSError, subprocess.TimeoutExpired):
-                return None, None
-            vals = []
+                continue
+            vals = collections.defaultdict(list)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "scan2_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or not vals:
-                return None, None
-            got[counter] = sum(vals) / len(vals)
-    read_b, write_b = got["FETCH_SIZE"] * 1024 * 2, got["WRITE_SIZE"] * 1024
-    return read_b + write_b, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this command, "
-                              f"per scan2_kernel launch; read {read_b:.0f} B = FETCH_SIZE KB x 1024 x 2 (gfx950 correction), write {write_b:.0f} B)")
+                    if "scan2_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") in counters:
+                        vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                        names[row["Kernel_Name"]] += 1
+            if r.returncode == 0:
+                for c, v in vals.items():
+                    got[c] = sum(v) / len(v)
+    out = {}
+    if names:
+        out["kernel"] = names.most_common(1)[0][0]
+    if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+        read_b, write_b = got["FETCH_SIZE"] * 1024 * 2, got["WRITE_SIZE"] * 1024
+        out["traffic"] = read_b + write_b
+        out["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this command, "
+                                 f"per scan2_kernel launch; read {read_b:.0f} B = FETCH_SIZE KB x 1024 x 2 (gfx950 correction), write {write_b:.0f} B)")
+    if all(c in got for c in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")):
+        n_tiles = -(-(-(-n_bytes // 16)) // 62)                    # tiles of 62 emitting 16-byte slots (992 bases)
+        cycles = got["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs
+        per_tile = cycles / (n_tiles / 1024.0)                     # 256 CUs x 4 SIMDs
+        ipt = got["SQ_INSTS_VALU"] / n_tiles
+        out["valu"] = {
+            "insts_per_tile": round(ipt, 1),
+            "salu_per_tile": round(got.get("SQ_INSTS_SALU", 0.0) / n_tiles, 1),
+            "lds_per_tile": round(got.get("SQ_INSTS_LDS", 0.0) / n_tiles, 1),
+            "shader_cycles_per_launch": round(cycles),
+            "cycles_per_tile_per_simd": round(per_tile, 1),
+            "cycles_per_inst": round(per_tile / ipt, 3),
+            "port_busy_by_SQ_ACTIVE_INST_VALU_x4": round(got.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (cycles * 1024), 4),
+            "port_busy_note": "SQ_ACTIVE_INST_VALU counts ONE quad-cycle per instruction whatever its issue class (it equals SQ_INSTS_VALU): "
+                              "this ratio is cycles_per_inst / 4 restated, not an occupancy (profiles/r04a/README.md)",
+            "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
+                      "(one child pass, per scan2_kernel launch; tile = 992 bases per wave)",
+        }
+    return out
+
+
+def roofline_bound(pmc, frac, k):
+    """What limits the dominant kernel, from this run's counters: the yardstick of the metric stays the HBM-read roofline (peak / frac),
+    `bound` says what the kernel is actually held by.  HBM-bound would mean running near the HBM rate; this kernel moves
+    1.01 x its algorithmic bytes at ~0.4 of the HBM rate while its waves issue ~175 VALU instructions per 992-base tile: it is bound by
+    VALU issue (half-rate instructions at 4.1 cycles, full-rate at 2.05: profiles/r04a/README.md), and says so."""
+    out = {"bound": "hbm", "kernel": pmc.get("kernel") or f"(not observed: no counter pass ran) ntk::scan2_kernel<{k}, ...>"}
+    valu = pmc.get("valu")
+    if not valu:
+        return out
+    valu = dict(valu)
+    cls_path = os.path.join(ROOT, "profiles", "r04b", f"valu_classes_k{k}.json")
+    if os.path.exists(cls_path):
+        try:
+            with open(cls_path) as fh:
+                cls = json.load(fh)
+            issue = cls["half_rate"] * cls["cycles_half"] + cls["full_rate"] * cls["cycles_full"]
+            valu["issue_classes"] = {"half_rate_per_tile": cls["half_rate"], "full_rate_per_tile": cls["full_rate"],
+                                     "cycles_half": cls["cycles_half"], "cycles_full": cls["cycles_full"],
+                                     "issue_cycles_per_tile": round(issue, 1),
+                                     "issue_share_of_measured_cycles": round(issue / valu["cycles_per_tile_per_simd"], 3),
+                                     "source": "static: " + os.path.relpath(cls_path, ROOT) + " (tools/isa_census.py --json of the shipped build; "
+                                               "class costs measured by tools/ubench*.hip, profiles/r04a/)"}
+        except (OSError, KeyError, ValueError):
+            pass
+    share = valu.get("issue_classes", {}).get("issue_share_of_measured_cycles")
+    if frac < 0.7 and (share is None or share > 0.6):   # (at >= 0.7 of the HBM rate the memory system is the limit whatever the waves do)
+        out["bound"] = "valu-issue"
+        out["bound_note"] = ("the HBM-read roofline stays the yardstick (peak, frac); the kernel itself is held by VALU issue: "
+                             f"{valu['insts_per_tile']} VALU instructions per 992-base tile in {valu['cycles_per_tile_per_simd']} shader cycles per "
+                             "tile per SIMD" + (f", {share:.0%} of which is the instructions' own issue time" if share else ""))
+    out["valu"] = valu
+    return out
 
 
 def free_port():
@@ -704,7 +802,20 @@ def main():
     ctx.enable_timing(False)
     kern_ms, launches = ctx.scan_time_ms()
     kern_avg_ms = kern_ms / max(launches, 1)
+    ar_avg_ms = None
+    if comm is not None:
+        ar_ms, ar_calls = comm.allreduce_time_ms()   # the collective's own duration on this rank (events on the stream it runs on)
+        ar_avg_ms = ar_ms / max(ar_calls, 1)
+    per_rank = None
     if use_dist:
+        # every rank's own numbers, so that a scaling line explains itself: scan kernel and all-reduce per step, wall per step
+        mine = torch.tensor([kern_avg_ms, ar_avg_ms if ar_avg_ms is not None else -1.0, elapsed / args.steps * 1e3, float(my_reads)],
+                            dtype=torch.float64, device="cuda" if rccl else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "reads": int(v[3]), "kernel_ms": round(float(v[0]), 5),
+                     "allreduce_ms": (round(float(v[1]), 5) if float(v[1]) >= 0 else None), "ms_per_step": round(float(v[2]), 5)}
+                    for i, v in enumerate(t_.cpu() for t_ in allr)]
         t = torch.tensor([elapsed, kern_avg_ms], dtype=torch.float64, device="cuda" if rccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
@@ -727,10 +838,13 @@ def main():
                     f"reads (5 scalars + 4096 bins; {verify_s:.1f} s of CPU per rank, untimed)")
 
     traffic, traffic_source = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes is not None else None)
-    if traffic is None and world == 1 and rank == 0 and not args.no_pmc and not os.environ.get("NTK_BENCH_PMC_CHILD"):
-        # measured in THIS run: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a short
-        # child run of this same command, per launch of the scan kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950
-        traffic, traffic_source = pmc_traffic(args, n_bytes)
+    pmc = {}
+    if world == 1 and rank == 0 and not args.no_pmc and not os.environ.get("NTK_BENCH_PMC_CHILD"):
+        # measured in THIS run: three separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; the SQ / GRBM counters) over short child
+        # runs of this same command, per launch of the scan kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950
+        pmc = pmc_passes(args, n_bytes)
+        if traffic is None and "traffic" in pmc:
+            traffic, traffic_source = pmc["traffic"], pmc["traffic_source"]
     if traffic is None and world == 1 and seed == SEED_C2 and (total_reads, args.read_len, args.k, args.n_per_1024) == (10_000_000, 150, 21, 1):
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_scan_kernel.json")))
@@ -772,6 +886,10 @@ def main():
                 "launch": {"blocks": args.blocks or "auto", "threads": args.threads or "auto"},
                 "rccl_ranks": (comm.size if comm is not None else 0),   # ntk_comm_size: ranks the library's communicator spans (0 = none in use)
                 "devices_visible": torch.cuda.device_count(),
+                **({"per_rank": per_rank,
+                    "per_rank_note": "kernel_ms = scan kernel per step, allreduce_ms = ncclAllReduce + xor rebuild per step (hipEvents on the "
+                                     "ctx stream, ntk_comm_allreduce_time_ms; it includes waiting for the slowest rank's scan), ms_per_step = "
+                                     "that rank's wall time per step; value and ms_per_step above use the MAX over ranks"} if per_rank else {}),
                 **({"collective": collective_note} if collective_note else {}),
                 **({"test_mode": f"{args.backend} backend, all ranks on cuda:0 - NOT a measurement"}
                    if (args.single_device or (use_dist and not rccl)) else {}),
@@ -779,8 +897,7 @@ def main():
             "result": {"n_total": res["n_total"], "n_fwd": res["n_fwd"], "sum": hex(res["sum"]), "xor": hex(res["xor"]),
                        "verified": verified},
             "roofline": {
-                "bound": "hbm",
-                "kernel": f"ntk::scan2_kernel<{args.k}, true, true, false, 14, 0, false>",
+                **roofline_bound(pmc, achieved / HBM_PEAK_GBS, args.k),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

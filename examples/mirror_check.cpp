@@ -3,6 +3,7 @@
 // the reference's unit-test literals (src/sequence.rs:363-374) and the oracle.
 #include "needletail_amd.hpp"
 #include <cstdio>
+#include <vector>
 using namespace needletail;
 int main() {
     const uint8_t s[] = "AGCT", q[] = "AAA0";
@@ -18,6 +19,20 @@ int main() {
     printf("%llu\n", (unsigned long long)mi.first);
     const uint8_t ph[] = "#</</BBFFFBF<";                 // reference src/quality.rs:35-40: 2 27 14 27 14 33 33 37 37 37 33 37 27
     for (uint8_t v : decode_phred(Slice(ph, 13), PhredEncoding::Phred33)) printf("%d ", (int)v);
+    printf("\n");
+    // the batched byte-path items as bit planes (CanonicalKmersPlanes), walked per record: three records back to back in one buffer,
+    // the literals of reference src/kmer.rs:182-227 among them ("ACGT" k = 2: every window is its own reverse complement or sorts after it)
+    const uint8_t buf[] = "ACGTAGTCGTCAnACGTACGTN";
+    const std::vector<uint64_t> offs = {0, 4, 12, 22};
+    CanonicalKmersPlanes pl(buf, offs, 2);
+    printf("planes %llu", (unsigned long long)pl.total());
+    for (size_t i = 0; i < 3; i++) {
+        const Slice rec(buf + offs[i], offs[i + 1] - offs[i]);
+        const Bytes rc = Sequence(rec).reverse_complement();
+        pl.for_each(i, rec, Slice(rc.data(), rc.size()), [&](size_t pos, Slice kmer, bool is_rc) {
+            printf(" %zu:%zu:%.*s:%d", i, pos, (int)kmer.size(), (const char *)kmer.data(), (int)is_rc);
+        });
+    }
     printf("\n");
     return 0;
 }

@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define NTK_ABI_VERSION 1
+/* 2 (round 4): + ntk_canonical_kmers_batch_planes, ntk_ctx_trim, ntk_comm_allreduce_time_ms; round 3 had added ntk_device_count,
+ * ntk_pinned_alloc / ntk_pinned_free under version 1.  ntk_abi_version() of the loaded library says what it exports. */
+#define NTK_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -119,7 +121,8 @@ int ntk_ctx_create_on_stream(int device, void *hip_stream, ntk_ctx **out);
 void ntk_ctx_destroy(ntk_ctx *ctx);
 int ntk_ctx_synchronize(ntk_ctx *ctx);
 /* Launch geometry of the scan kernel: blocks (0 = auto: the resident grid) x threads per block (a multiple of 64 up to
- * 1024; 0 = auto: 768 for every reduce-mode scan; materialise mode always runs 256-thread blocks). */
+ * 1024; 0 = auto: the largest of 768 / 640 / 512 that keeps two blocks of a reduce build resident per CU - 768 for every shipped
+ * build; materialise mode always runs 256-thread blocks). */
 int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
 /* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */
@@ -144,6 +147,9 @@ int ntk_comm_size(const ntk_comm *comm);     /* ranks in the communicator */
 /* All ranks (all local ctxs of an init_all communicator): accumulators <- sum over ranks, in place, asynchronous on the
  * ctx streams; ntk_accum_read / ntk_ctx_synchronize order after it.  Call it once, after the last batch of the run. */
 int ntk_allreduce_accumulators(ntk_comm *comm);
+/* Durations of the all-reduces issued while the (first local) ctx had ntk_ctx_enable_timing on, summed since the last call: what a
+ * multi-GPU run pays for the collective on this rank, next to ntk_ctx_scan_time_ms (the scaling bench prints both per rank). */
+int ntk_comm_allreduce_time_ms(ntk_comm *comm, double *total_ms, uint64_t *calls);
 void ntk_comm_destroy(ntk_comm *comm);
 
 /* ---- batch face, reduce mode ----------------------------------------------------------------
@@ -289,6 +295,21 @@ int ntk_bit_kmers_batch(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offset
  * returns chunk i's items (9 or 17 bytes each - the bound of this face) the host packs chunk i + 1 into pinned staging and the
  * GPU scans it.  The caller's arrays may be pageable; page-locked ones (below) take the copies without a staging pass. */
 int ntk_pinned_alloc(uint64_t bytes, void **out);   /* hipHostMalloc: for the arrays handed to the batched calls */
+/* The byte-path items of a batch as TWO BITS per sequence byte instead of (pos, is_rc) per item: what Sequence::canonical_kmers yields
+ * is (pos, buffer[pos..pos+k] or the rc slice, is_rc) (reference src/kmer.rs:114-129), and pos and slice follow from where the window
+ * starts - so the device returns, per window START, "emitted" and "is_rc" as bit planes and the host iterator walks the bits
+ * (include/needletail_amd.hpp CanonicalKmersPlanes, rust/src/amd.rs AmdCanonicalKmersPlanes, needletail_amd.canonical_kmers_planes).
+ * 1/4 byte comes back per input byte where ntk_canonical_kmers_batch returns 9 bytes per item: the call is bound by the upload.
+ * The records are uploaded as they lie in seq (no packing, no break bytes).  Plane position b = bit (15 - b % 16) of word b / 16;
+ * the window starting at byte p of record r sits at b = rec_bit[r] + p, for p in 0 .. len(r) - k (positions past that, and the
+ * padding up to the next 16-position boundary where a new chunk of the batch begins, read 0).  rec_bit has n_records + 1 entries
+ * (the last = 16 * *n_words).  cap_words >= (offsets[n_records] - offsets[0]) / 16 + n_records + 1 always suffices;
+ * NTK_ERR_CAPACITY sets *n_words = needed.  *total = items of the whole batch.  Any k <= 255, raw-byte comparison, ties -> is_rc. */
+int ntk_canonical_kmers_batch_planes(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
+                                     uint64_t *rec_bit, uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words,
+                                     uint64_t *total);
+/* Releases what the batched calls and the compat face keep between calls (staging, device buffers); they are re-made on demand. */
+int ntk_ctx_trim(ntk_ctx *ctx);
 void ntk_pinned_free(void *p);
 
 /* ---- minimizers and quality masking ------------------------------------------------ */

@@ -93,6 +93,38 @@ private:
     Slice s_; Context *c_;
 };
 
+// The items of Sequence::canonical_kmers for a whole batch of records from ONE call, as two bit planes
+// (ntk_canonical_kmers_batch_planes): per window start "emitted" and "is_rc".  for_each(i, buffer, rc, f) walks record i's bits and
+// hands f what the reference iterator yields for it, in its order: (pos, buffer[pos..pos+k] or the rc slice, is_rc)
+// (reference src/kmer.rs:114-129).
+class CanonicalKmersPlanes {
+public:
+    // seq + offsets (n + 1 entries): record i = seq[offsets[i] .. offsets[i + 1]), e.g. a reader's own buffer - uploaded as it lies
+    CanonicalKmersPlanes(const uint8_t *seq, const std::vector<uint64_t> &offsets, uint8_t k, Context &c = Context::global())
+        : k_(k), offsets_(offsets), rec_bit_(offsets.size())
+    {
+        const uint64_t n = offsets.size() - 1, cap = (offsets[n] - offsets[0]) / 16 + n + 1;
+        valid16_.resize(cap); rc16_.resize(cap);
+        uint64_t words = 0;
+        check(ntk_canonical_kmers_batch_planes(c.get(), seq, offsets_.data(), n, k, rec_bit_.data(), valid16_.data(), rc16_.data(), cap,
+                                               &words, &total_), "ntk_canonical_kmers_batch_planes");
+        valid16_.resize(words); rc16_.resize(words);
+    }
+    uint64_t total() const { return total_; }
+    template <class F> void for_each(size_t i, Slice buffer, Slice rc, F &&f) const {
+        const uint64_t len = offsets_[i + 1] - offsets_[i], b0 = rec_bit_[i];
+        if (len < k_) return;
+        for (uint64_t p = 0; p + k_ <= len; p++) {
+            const uint64_t b = b0 + p;
+            if (!((valid16_[b >> 4] >> (15 - (b & 15))) & 1)) continue;
+            if ((rc16_[b >> 4] >> (15 - (b & 15))) & 1) f((size_t)p, rc.substr(rc.size() - p - k_, k_), true);
+            else f((size_t)p, buffer.substr(p, k_), false);
+        }
+    }
+private:
+    uint64_t k_; std::vector<uint64_t> offsets_, rec_bit_; std::vector<uint16_t> valid16_, rc16_; uint64_t total_ = 0;
+};
+
 // QualitySequence (reference src/sequence.rs:273-303) for a (sequence, quality) pair.
 class QualitySequence : public Sequence {
 public:

@@ -20,7 +20,7 @@ ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 # every symbol include/needletail_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
     "ntk_strerror", "ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version", "ntk_device_count",
-    "ntk_comm_init_all", "ntk_comm_unique_id", "ntk_comm_init_rank", "ntk_comm_size", "ntk_allreduce_accumulators", "ntk_comm_destroy",
+    "ntk_comm_init_all", "ntk_comm_unique_id", "ntk_comm_init_rank", "ntk_comm_size", "ntk_allreduce_accumulators", "ntk_comm_allreduce_time_ms", "ntk_comm_destroy",
     "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
     "ntk_ctx_set_launch", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
     "ntk_accum_reset", "ntk_reduce_device", "ntk_reduce_device_quality", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
@@ -28,6 +28,7 @@ SYMBOLS = [
     "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_append_quality", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
     "ntk_batch_release",
     "ntk_normalize", "ntk_strip_returns", "ntk_reverse_complement", "ntk_canonical_kmers", "ntk_bit_kmers", "ntk_canonical_kmers_batch", "ntk_bit_kmers_batch", "ntk_pinned_alloc", "ntk_pinned_free",
+    "ntk_canonical_kmers_batch_planes", "ntk_ctx_trim",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
     "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_position", "ntk_reader_close",
     "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points",
@@ -93,6 +94,7 @@ def lib() -> C.CDLL:
     L.ntk_allreduce_accumulators.argtypes = [vp]
     L.ntk_comm_destroy.restype = None
     L.ntk_comm_destroy.argtypes = [vp]
+    L.ntk_comm_allreduce_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.ntk_ctx_create.argtypes = [i32, pp]
     L.ntk_ctx_create_on_stream.argtypes = [i32, vp, pp]
     L.ntk_ctx_destroy.restype = None
@@ -127,6 +129,8 @@ def lib() -> C.CDLL:
     L.ntk_pinned_alloc.argtypes = [u64, pp]
     L.ntk_pinned_free.restype = None
     L.ntk_pinned_free.argtypes = [vp]
+    L.ntk_canonical_kmers_batch_planes.argtypes = [vp, C.c_char_p, vp, u64, u32, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.ntk_ctx_trim.argtypes = [vp]
     L.ntk_synth_reads_device.argtypes = [vp, u64, u64, u64, u32, u32, vp]
     L.ntk_reverse_complement_records_device.argtypes = [vp, vp, vp, u64, u32, u32]
     L.ntk_reader_open_file.argtypes = [C.c_char_p, pp]

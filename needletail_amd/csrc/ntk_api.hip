@@ -110,6 +110,7 @@ struct ntk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream (kernels, compat-face copies)
     hipStream_t copy_stream = nullptr;  // H2D copies of pinned batches
+    hipStream_t down_stream = nullptr;  // D2H copies of the bit-plane compat face (its uploads keep the copy stream to themselves)
     bool owns_stream = false;
     int n_cu = 256;
     int launch_blocks = 0, launch_threads = 0;   // 0 = automatic
@@ -200,11 +201,10 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
     return NTK_OK;
 }
 
-// The scan kernel build for a mode: k-specialised builds where they exist, the runtime-k build otherwise.
-// Reduce mode, canonical paths: every k runs a scalar-validity variant (k is a template constant there: the window-mask
-// algebra indexes lane masks by k; 64-bit values for k >= 17, 32-bit for k <= 16), -10..20 % against the generic runtime-k build; with a quality stream only k = 21 and
-// 31 (the two k the reference's own programs use) have one.  Materialise mode: only k = 21 has a specialised (per-lane)
-// build (-5 %; for larger k the generic build is as fast).
+// The scan kernel build for a mode.  Reduce mode: every (path, k, quality stream or not) has its own scan2_kernel instantiation (k is
+// a template constant: the window-mask algebra indexes lane masks by k; ntk_scan2.hip).  Materialise mode: the round-1 scan_kernel with
+// k at run time, plus a k = 21 build for the canonical paths (-5 %); it runs at the rate of a plain read-1-write-8 expansion kernel
+// (2.45 ms per 1.51 GB of input against 2.45-2.50 ms, profiles/r04b/wbw.txt), i.e. it is bound by the 8 bytes it writes per position.
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
 
 template <bool REDUCE, bool QM>
@@ -291,9 +291,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     const int waves_per_block = threads / 64;
     const size_t lds = reduce ? 0 : (size_t)waves_per_block * kStageWaveU64 * sizeof(uint64_t);  // materialise staging
     // auto grid: exactly the blocks that are resident at once (work is pulled, so a second round of blocks would only
-    // zero and write out empty histograms: measured +1.5 % at config 2).  Reduce builds, 512-thread blocks (default): 4 per
-    // CU at <= 64 VGPRs, 3 for the 66-VGPR scalar-validity builds (6 waves per SIMD: -5 % against one 1024-thread block);
-    // materialise: 4 x 256 (LDS staging).
+    // zero and write out empty histograms: measured +1.5 % at config 2).  Reduce builds: two blocks of `threads` (768, or 640 / 512
+    // for a build above 80 VGPRs: chosen above) per CU, each with its 64 KiB LDS histogram; materialise: 4 x 256 (LDS staging).
     int per_cu = 0;
     auto it = c->occupancy.find(std::make_pair(fn, threads));
     if (it != c->occupancy.end()) per_cu = it->second;
@@ -346,7 +345,7 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {
             int rc = get_event(c, &e0); if (rc) return rc;
-            rc = get_event(c, &e1); if (rc) return rc;
+            rc = get_event(c, &e1); if (rc) { c->ev_free.push_back(e0); return rc; }
             HIPCHK(hipEventRecord(e0, c->stream));
         }
         void *kargs[] = {(void *)&a};
@@ -405,6 +404,7 @@ int init_ctx(ntk_ctx *c, void *stream, bool borrow)
     if (borrow) { c->stream = (hipStream_t)stream; c->owns_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_acc_own, NTK_ACC_WORDS * sizeof(uint64_t)));
     c->d_acc = c->d_acc_own;
     HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
@@ -474,6 +474,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->owns_stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
     for (auto &p : c->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     for (auto b : c->pool) destroy_batch(b);
@@ -493,6 +494,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
     }
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     delete c;
 }
 
@@ -923,6 +925,29 @@ namespace {
 // c+1 (measured: 3.85 ms per chunk = 2.35 ms of copies + 1.5 ms of packing in series, profiles/r03b/compat_trace.txt).
 // Caller arrays may be pageable or pinned (ntk_pinned_alloc).
 constexpr uint64_t kCompatChunkBytes = (uint64_t)16 << 20;
+// NTK_COMPAT_CHUNK_BYTES is a test hook (many chunks from small batches; the suites switch it between calls, so it is read per call -
+// one getenv against milliseconds of work).  Values below 64 bytes are taken as 64: a stray "1" would cost a launch and an event
+// wait per record.
+uint64_t compat_chunk_bytes()
+{
+    const char *e = getenv("NTK_COMPAT_CHUNK_BYTES");
+    if (!e) return kCompatChunkBytes;
+    const long long x = atoll(e);
+    if (x <= 0) return kCompatChunkBytes;
+    return (uint64_t)(x < 64 ? 64 : x);
+}
+// The banks keep their staging and device buffers between calls (re-allocation costs milliseconds); what a call leaves behind above
+// this many bytes per bank is released when it returns (a single 10-kb-record batch used to pin ~1.2 GiB until ctx_destroy).
+constexpr size_t kBankKeepBytes = (size_t)512 << 20;   // a 16 MiB chunk of the bit path needs ~420 MiB per bank: kept; more than that: released
+void bank_trim(ntk_ctx *c, size_t keep = kBankKeepBytes)
+{
+    for (CompatBank &b : c->bank) {
+        size_t dev = 0;
+        for (const Scratch &s : b.d) dev += s.bytes;
+        if (dev > keep) for (Scratch &s : b.d) { if (s.p) (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+        if (b.h_stage_bytes > keep) { (void)hipHostFree(b.h_stage); b.h_stage = nullptr; b.h_stage_bytes = 0; }
+    }
+}
 
 int bank_scratch(ntk_ctx *c, CompatBank &b, int slot, size_t bytes)
 {
@@ -930,7 +955,7 @@ int bank_scratch(ntk_ctx *c, CompatBank &b, int slot, size_t bytes)
     Scratch &s = b.d[slot];
     if (s.bytes >= bytes) return NTK_OK;
     // (only this bank's own earlier work can still use the buffer, and that was waited for before the bank was re-used)
-    if (s.p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->copy_stream)); HIPCHK(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
+    if (s.p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->copy_stream)); HIPCHK(hipStreamSynchronize(c->down_stream)); HIPCHK(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
     const size_t want = bytes + bytes / 4 + 4096;
     HIPCHK(hipMalloc(&s.p, want));
     s.bytes = want;
@@ -991,9 +1016,20 @@ int compat_stage_a(ntk_ctx *c, CompatBank &b, const CompatJob &j, uint64_t r0, u
     const unsigned nth = (unsigned)std::min<uint64_t>(pack_threads, n / (256 << 10) + 1);   // a thread per 256 KiB at least
     if (nth <= 1) pack(0, nrec);
     else {
+        // a thread that cannot be created (thread / cgroup limit: std::system_error, bad_alloc) must not unwind across the C ABI:
+        // the records it would have packed are packed here instead
         std::vector<std::thread> th;
-        for (unsigned t = 1; t < nth; t++) th.emplace_back(pack, nrec * t / nth, nrec * (t + 1) / nth);
-        pack(0, nrec / nth);
+        uint64_t done_to = nrec / nth;            // [0, done_to) is this thread's own share
+        uint64_t spawned_from = nrec;             // [spawned_from, nrec) went to threads
+        try {
+            th.reserve(nth - 1);
+            for (unsigned t = nth - 1; t >= 1; t--) {   // from the back, so that what is left over stays one contiguous range
+                th.emplace_back(pack, nrec * t / nth, nrec * (t + 1) / nth);
+                spawned_from = nrec * t / nth;
+            }
+        } catch (...) {}
+        pack(0, spawned_from < done_to ? spawned_from : done_to);
+        if (spawned_from > done_to) pack(done_to, spawned_from);
         for (auto &t : th) t.join();
     }
     h_start[nrec] = n;
@@ -1016,7 +1052,7 @@ int compat_stage_a(ntk_ctx *c, CompatBank &b, const CompatJob &j, uint64_t r0, u
         // raw-byte comparison exactly as the reference (src/kmer.rs:84-129): any k <= 255, mixed case compares as bytes
         uint8_t *d_flags = (uint8_t *)b.d[1].p;
         hipLaunchKernelGGL(canonical_bytes_kernel, dim3(grid_for(n, 256)), dim3(256), 0, c->stream,
-                           (const uint8_t *)b.d[0].p, n, j.k, (const uint16_t *)(c->d_lut + 768), d_flags);
+                           (const uint8_t *)b.d[0].p, n, j.k, (const uint16_t *)(c->d_lut + 768), d_flags, (const uint32_t *)nullptr);
         hipLaunchKernelGGL(pack_flags8_kernel, dim3(grid_for((n + 15) / 16, 256)), dim3(256), 0, c->stream, (const uint8_t *)d_flags, n, d_v16, d_r16);
         HIPCHK(hipGetLastError());
     } else {
@@ -1072,8 +1108,8 @@ int compat_batch(ntk_ctx *c, const CompatJob &j, uint64_t n_records, uint64_t *t
     for (CompatBank &b : c->bank) if ((rc = bank_init(c, b))) return rc;
     uint64_t items = 0, r0 = 0;
     int cur = 0, prev = -1;
-    uint64_t chunk_bytes = kCompatChunkBytes;
-    if (const char *e = getenv("NTK_COMPAT_CHUNK_BYTES")) { const long long v = atoll(e); if (v > 0) chunk_bytes = (uint64_t)v; }   // test hook: many chunks from small batches
+    const uint64_t chunk_bytes = compat_chunk_bytes();
+    constexpr int kBanks = (int)(sizeof(c->bank) / sizeof(c->bank[0]));
     while (r0 < n_records && rc == NTK_OK) {
         // the chunk: records up to chunk_bytes packed bytes (at least one record)
         uint64_t r1 = r0 + 1;
@@ -1082,19 +1118,140 @@ int compat_batch(ntk_ctx *c, const CompatJob &j, uint64_t n_records, uint64_t *t
         if (b.busy) { if (hipEventSynchronize(b.ev_done) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = NTK_ERR_HIP; break; } b.busy = false; }
         if ((rc = compat_stage_a(c, b, j, r0, r1 - r0))) break;
         if (prev >= 0 && (rc = compat_stage_b(c, c->bank[prev], j, &items))) break;
-        prev = cur; cur = (cur + 1) % 3; r0 = r1;
+        prev = cur; cur = (cur + 1) % kBanks; r0 = r1;
     }
     if (rc == NTK_OK && prev >= 0) rc = compat_stage_b(c, c->bank[prev], j, &items);
     // the call is synchronous: everything of it has landed (or, after an error, nothing of it is still reading the pinned
     // staging buffers or writing the caller's arrays) when it returns
     const hipError_t e1 = hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->copy_stream);
     for (CompatBank &b : c->bank) b.busy = false;
+    bank_trim(c);
     if (rc != NTK_OK) return rc;
     if (e1 != hipSuccess || e2 != hipSuccess) { g_last_hip = (int)(e1 != hipSuccess ? e1 : e2); return NTK_ERR_HIP; }
     *total = items;
     return items > j.cap ? NTK_ERR_CAPACITY : NTK_OK;
 }
+
+// ---- bit-plane form of the byte-path items -----------------------------------------------------------------------------------
+// Sequence::canonical_kmers yields (pos, slice, is_rc) (reference src/kmer.rs:114-129); slice and pos follow from the window's place,
+// so all the device has to return is, per window start, "emitted?" and "is_rc?": TWO BITS per sequence byte instead of nine bytes per
+// item (the bound of ntk_canonical_kmers_batch: 48 GB/s of items over PCIe = 6.3 Gbases/s).  The caller's bytes are uploaded as they
+// lie (no packing pass, no break bytes: record starts travel as a bitmap built on the device from the offsets), the raw-byte kernel
+// of the compat face marks the windows, and the two planes come back: 1/4 byte per input byte.  Chunks of <= 16 MiB, the same three
+// banks: upload and kernels of chunk i + 1 overlap the download of chunk i.  Each chunk starts on a 16-position word boundary of the
+// planes; rec_bit[r] is the plane position of record r's first byte.
+int compat_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, uint64_t *rec_bit,
+                  uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words, uint64_t *total)
+{
+    for (uint64_t r = 0; r < n_records; r++) if (offsets[r] > offsets[r + 1]) return NTK_ERR_BAD_ARG;
+    const uint64_t chunk_bytes = compat_chunk_bytes();
+    constexpr int kBanks = (int)(sizeof(c->bank) / sizeof(c->bank[0]));
+    // pass 1 (host): the chunks and the words they need
+    struct Chunk { uint64_t r0, r1, wbase, nb; };
+    std::vector<Chunk> chunks;
+    uint64_t words = 0;
+    try {
+        for (uint64_t r0 = 0; r0 < n_records;) {
+            uint64_t r1 = r0 + 1;
+            while (r1 < n_records && offsets[r1 + 1] - offsets[r0] <= chunk_bytes) r1++;
+            const uint64_t nb = offsets[r1] - offsets[r0];
+            chunks.push_back({r0, r1, words, nb});
+            words += (nb + 15) >> 4;
+            r0 = r1;
+        }
+    } catch (...) { return NTK_ERR_NOMEM; }
+    *n_words = words;
+    if (words > cap_words) return NTK_ERR_CAPACITY;
+    int rc = NTK_OK;
+    for (CompatBank &b : c->bank) if ((rc = bank_init(c, b))) return rc;
+    uint64_t items = 0;
+    auto retire = [&](CompatBank &b) -> int {   // the bank's chunk has fully landed: its item total joins the sum
+        if (!b.busy) return NTK_OK;
+        if (hipEventSynchronize(b.ev_done) != hipSuccess) { g_last_hip = (int)hipGetLastError(); return NTK_ERR_HIP; }
+        items += *b.h_total;
+        b.busy = false;
+        return NTK_OK;
+    };
+    // Three stages per chunk on three streams: upload [copy stream] -> bitmap + planes kernel [ctx stream] -> download [down stream]:
+    // the uploads run back to back (the call is bound by them), the kernel and the download of chunk i hide behind the upload of
+    // chunk i + 1.  A bank is re-used every third chunk, after its download has landed (retire()).
+    auto hip_fail = [&](hipError_t e) { g_last_hip = (int)e; return NTK_ERR_HIP; };
+    auto upload = [&](size_t ci) -> int {
+        const Chunk &ch = chunks[ci];
+        CompatBank &b = c->bank[ci % kBanks];
+        int r;
+        if ((r = retire(b))) return r;
+        const uint64_t nrec = ch.r1 - ch.r0, nt = (ch.nb + 15) / 16 * 16;
+        for (uint64_t q = ch.r0; q < ch.r1; q++) rec_bit[q] = ch.wbase * 16 + (offsets[q] - offsets[ch.r0]);
+        if (ch.nb == 0) return NTK_OK;   // only empty records
+        if ((r = bank_scratch(c, b, 0, nt + 16))) return r;
+        if ((r = bank_scratch(c, b, 5, (size_t)(nrec + 1) * 8))) return r;
+        if ((r = bank_scratch(c, b, 2, nt / 8 + 16))) return r;
+        if ((r = bank_scratch(c, b, 3, nt / 8 + 16))) return r;
+        if ((r = bank_scratch(c, b, 4, 64))) return r;
+        if ((r = bank_scratch(c, b, 6, (size_t)((nt >> 5) + 2) * 4))) return r;
+        hipError_t e;
+        if ((e = hipMemcpyAsync(b.d[0].p, seq + offsets[ch.r0], ch.nb, hipMemcpyHostToDevice, c->copy_stream))) return hip_fail(e);
+        if ((e = hipMemcpyAsync(b.d[5].p, offsets + ch.r0, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, c->copy_stream))) return hip_fail(e);
+        if ((e = hipEventRecord(b.ev_total, c->copy_stream))) return hip_fail(e);   // "uploaded"
+        return NTK_OK;
+    };
+    auto compute_and_download = [&](size_t ci) -> int {
+        const Chunk &ch = chunks[ci];
+        CompatBank &b = c->bank[ci % kBanks];
+        if (ch.nb == 0) return NTK_OK;
+        const uint64_t nrec = ch.r1 - ch.r0, nb = ch.nb, nt = (nb + 15) / 16 * 16, nw = nt >> 4, sb_words = (nt >> 5) + 2;
+        hipError_t e;
+        if ((e = hipStreamWaitEvent(c->stream, b.ev_total, 0))) return hip_fail(e);
+        if ((e = hipMemsetAsync(b.d[6].p, 0, (size_t)sb_words * 4, c->stream))) return hip_fail(e);
+        if ((e = hipMemsetAsync(b.d[4].p, 0, 8, c->stream))) return hip_fail(e);
+        hipLaunchKernelGGL(mark_record_starts_kernel, dim3(grid_for(nrec, 256)), dim3(256), 0, c->stream, (const uint64_t *)b.d[5].p, nrec, nb,
+                           (uint32_t *)b.d[6].p);
+        const uint64_t tiles = (nb + kPlTile - 1) / kPlTile;
+        hipLaunchKernelGGL(canonical_bytes_planes_kernel, dim3((unsigned)(tiles < (uint64_t)c->n_cu * 8 ? tiles : (uint64_t)c->n_cu * 8)), dim3(kPlThreads), 0,
+                           c->stream, (const uint8_t *)b.d[0].p, nb, nt + 16, k, (const uint16_t *)(c->d_lut + 768), (const uint32_t *)b.d[6].p, sb_words,
+                           (uint16_t *)b.d[2].p, (uint16_t *)b.d[3].p, (unsigned long long *)b.d[4].p);
+        if ((e = hipGetLastError())) return hip_fail(e);
+        if ((e = hipMemcpyAsync(b.h_total, b.d[4].p, 8, hipMemcpyDeviceToHost, c->stream))) return hip_fail(e);
+        if ((e = hipEventRecord(b.ev_scattered, c->stream))) return hip_fail(e);
+        if ((e = hipStreamWaitEvent(c->down_stream, b.ev_scattered, 0))) return hip_fail(e);
+        if ((e = hipMemcpyAsync(valid16 + ch.wbase, b.d[2].p, (size_t)nw * 2, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
+        if ((e = hipMemcpyAsync(rc16 + ch.wbase, b.d[3].p, (size_t)nw * 2, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
+        if ((e = hipEventRecord(b.ev_done, c->down_stream))) return hip_fail(e);
+        b.busy = true;
+        return NTK_OK;
+    };
+    if (!chunks.empty()) rc = upload(0);
+    for (size_t ci = 0; ci < chunks.size() && rc == NTK_OK; ci++) {
+        if (ci + 1 < chunks.size() && (rc = upload(ci + 1))) break;
+        rc = compute_and_download(ci);
+    }
+    rec_bit[n_records] = words * 16;
+    const hipError_t e0 = hipStreamSynchronize(c->down_stream);
+    const hipError_t e1 = e0 != hipSuccess ? e0 : hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->copy_stream);
+    if (rc == NTK_OK) for (CompatBank &b : c->bank) if ((rc = retire(b))) break;
+    for (CompatBank &b : c->bank) b.busy = false;
+    bank_trim(c);
+    if (rc != NTK_OK) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) { g_last_hip = (int)(e1 != hipSuccess ? e1 : e2); return NTK_ERR_HIP; }
+    *total = items;
+    return NTK_OK;
+}
 }  // namespace
+
+int ntk_canonical_kmers_batch_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
+                                     uint64_t *rec_bit, uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words,
+                                     uint64_t *total)
+{
+    if (!c || !offsets || !rec_bit || !n_words || !total || (!seq && offsets[n_records] > offsets[0])) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 255) return NTK_ERR_BAD_K;
+    *total = 0; *n_words = 0;
+    rec_bit[0] = 0;
+    if (n_records == 0) return NTK_OK;
+    if ((!valid16 || !rc16) && cap_words) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return compat_planes(c, seq, offsets, n_records, k, rec_bit, valid16, rc16, cap_words, n_words, total);
+}
 
 int ntk_bit_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,
                         uint64_t *counts, uint64_t *pos_out, uint64_t *val_out, uint8_t *was_rc_out, uint64_t cap, uint64_t *total)
@@ -1132,6 +1289,20 @@ int ntk_pinned_alloc(uint64_t bytes, void **out)
     return NTK_OK;
 }
 void ntk_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
+/* Gives back what the batched compat calls keep between calls (three banks of pinned staging and device buffers: up to ~180 MiB each
+ * on the byte path, ~420 MiB on the bit path) and the ctx's scratch buffers.  The next call re-allocates. */
+int ntk_ctx_trim(ntk_ctx *c)
+{
+    if (!c) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->down_stream));
+    bank_trim(c, 0);
+    for (Scratch &s : c->scratch) { if (s.p) (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+    return NTK_OK;
+}
 
 /* ---- minimizers, quality mask --------------------------------------------------------------------------------- */
 
@@ -1372,6 +1543,7 @@ struct ntk_comm {
     std::vector<ntk_ctx *> ctxs;     // local contexts (1 for init_rank, n for init_all)
     std::vector<ncclComm_t> comms;   // one communicator handle per local context
     int size = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;   // around each all-reduce on ctxs[0]'s stream while that ctx has timing on
 };
 
 int ntk_comm_unique_id(uint8_t id[NTK_COMM_ID_BYTES])
@@ -1432,6 +1604,14 @@ int ntk_allreduce_accumulators(ntk_comm *m)
     if (!m) return NTK_ERR_BAD_ARG;
     const RcclApi &R = load_rccl();
     if (!R.ok) { g_last_rccl = -1; return NTK_ERR_RCCL; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ntk_ctx *c0 = m->ctxs.empty() ? nullptr : m->ctxs[0];
+    if (c0 && c0->timing) {   // the collective's own duration on this rank (ntk_comm_allreduce_time_ms): events on the stream it runs on
+        HIPCHK(hipSetDevice(c0->device));
+        int rc = get_event(c0, &e0); if (rc) return rc;
+        rc = get_event(c0, &e1); if (rc) { c0->ev_free.push_back(e0); return rc; }
+        HIPCHK(hipEventRecord(e0, c0->stream));
+    }
     RCCLCHK(R.GroupStart());
     for (size_t i = 0; i < m->ctxs.size(); i++) {
         ntk_ctx *c = m->ctxs[i];
@@ -1444,6 +1624,32 @@ int ntk_allreduce_accumulators(ntk_comm *m)
         hipLaunchKernelGGL(xor_from_bit_counters_kernel, dim3(1), dim3(64), 0, c->stream, c->d_acc);
         HIPCHK(hipGetLastError());
     }
+    if (e0) {
+        HIPCHK(hipSetDevice(c0->device));
+        HIPCHK(hipEventRecord(e1, c0->stream));
+        m->ev_used.emplace_back(e0, e1);
+    }
+    return NTK_OK;
+}
+
+/* Sum of the durations of the all-reduces (collective + xor rebuild, on the first local ctx's stream) issued while that ctx had
+ * ntk_ctx_enable_timing on, since the last call; synchronises that stream. */
+int ntk_comm_allreduce_time_ms(ntk_comm *m, double *total_ms, uint64_t *calls)
+{
+    if (!m || !total_ms || m->ctxs.empty()) return NTK_ERR_BAD_ARG;
+    ntk_ctx *c = m->ctxs[0];
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double t = 0;
+    for (auto &p : m->ev_used) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+        t += ms;
+        c->ev_free.push_back(p.first); c->ev_free.push_back(p.second);
+    }
+    if (calls) *calls = m->ev_used.size();
+    m->ev_used.clear();
+    *total_ms = t;
     return NTK_OK;
 }
 

@@ -1116,13 +1116,36 @@ __global__ __launch_bounds__(kCompactThreads) void compact_write_kernel(const ui
         if (!(m[i] & 0x200)) out[w++] = (uint8_t)m[i];
 }
 
+// Record starts as one bit per byte position (LSB-first u32 words, zeroed before): one thread per record.  The records of a batch
+// then need no break byte between them (ntk_canonical_kmers_batch_planes uploads the caller's bytes as they lie).
+__global__ void mark_record_starts_kernel(const uint64_t *offsets, uint64_t n_records, uint64_t n, uint32_t *startbits)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = offsets[r] - offsets[0];
+        if (p < n) atomicOr(&startbits[p >> 5], 1u << (p & 31));
+    }
+}
+// any record start among the byte positions [a, b)?  (b - a <= 255)
+__device__ __forceinline__ bool any_record_start(const uint32_t *startbits, uint64_t a, uint64_t b)
+{
+    while (a < b) {
+        const uint32_t off = (uint32_t)(a & 31), room = 32u - off, left = (uint32_t)(b - a), take = left < room ? left : room;
+        const uint32_t mask = (take == 32u ? 0xFFFFFFFFu : ((1u << take) - 1u)) << off;
+        if (startbits[a >> 5] & mask) return true;
+        a += take;
+    }
+    return false;
+}
+
 // CanonicalKmers with the reference's raw-byte comparison (reference src/kmer.rs:84-129), any k <= 255.
 // One thread per window start; flags8[p]: bit0 = emitted, bit1 = is_rc.  cls: 1 = good base; comp LUT.
-__global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t k, const uint16_t *comp_lut, uint8_t *flags8)
+// startbits (optional): a window must not reach across a record start (no break bytes in the buffer then).
+__global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t k, const uint16_t *comp_lut, uint8_t *flags8,
+                                       const uint32_t *startbits = nullptr)
 {
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
     uint8_t f = 0;
-    if (p + k <= n) {
+    if (p + k <= n && !(startbits && k > 1 && any_record_start(startbits, p + 1, p + k))) {
         bool good = true;
         for (uint32_t i = 0; i < k; i++) {
             const uint8_t c = seq[p + i] & 0xDF;
@@ -1139,6 +1162,79 @@ __global__ void canonical_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t 
     }
     flags8[p] = f;
   }
+}
+
+// The same decision for a whole chunk of records lying back to back WITHOUT break bytes, written as the two bit planes of
+// ntk_canonical_kmers_batch_planes (bit 15 - p % 16 of word p / 16, p = window START): a block stages 2048 + k - 1 bytes and the
+// record-start bits in LDS once; a thread takes 8 consecutive starts and walks their 8 + k - 1 bytes ONCE, keeping the length of the
+// run of bases that ends at each byte (a record start resets it to 1): the window that ends there is emitted iff the run is >= k.
+// (The one-thread-per-start kernel above re-reads k bytes per start from global memory: 40 Gbases/s; this one: see DESIGN.md.)
+constexpr int kPlThreads = 256, kPlPer = 8, kPlTile = kPlThreads * kPlPer;
+__global__ __launch_bounds__(kPlThreads) void canonical_bytes_planes_kernel(const uint8_t *seq, uint64_t n, uint64_t n_readable, uint32_t k,
+                                                                            const uint16_t *comp_lut, const uint32_t *startbits, uint64_t sb_words,
+                                                                            uint16_t *valid16, uint16_t *rc16, unsigned long long *total)
+{
+    __shared__ __align__(16) uint8_t s_b[kPlTile + 256 + 16];
+    __shared__ uint32_t s_sb[(kPlTile + 256) / 32 + 2];
+    __shared__ uint8_t s_v[kPlThreads], s_r[kPlThreads], s_comp[256];
+    __shared__ uint32_t s_cnt[kPlThreads / 64];
+    s_comp[threadIdx.x] = (uint8_t)comp_lut[threadIdx.x];
+    const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile, n_words = (n + 15) >> 4;
+    const uint32_t need = kPlTile + k - 1;
+    uint32_t mine = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * kPlTile;
+        __syncthreads();   // the previous tile's readers are done (and s_comp is written)
+        for (uint32_t v = threadIdx.x; v * 16 < need; v += kPlThreads) {
+            const uint64_t p = t0 + (uint64_t)v * 16;
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (p + 16 <= n_readable) x = *reinterpret_cast<const u32x4 *>(seq + p);
+            *reinterpret_cast<u32x4 *>(&s_b[v * 16]) = x;
+        }
+        for (uint32_t w = threadIdx.x; w < need / 32 + 2; w += kPlThreads) {
+            const uint64_t gw = (t0 >> 5) + w;
+            s_sb[w] = gw < sb_words ? startbits[gw] : 0u;
+        }
+        __syncthreads();
+        const uint32_t s = threadIdx.x * kPlPer;
+        uint32_t run = 0, vmask = 0, rmask = 0;
+        for (uint32_t i = 0; i < kPlPer + k - 1; i++) {
+            const uint32_t idx = s + i;
+            const uint8_t c = s_b[idx], cu = c & 0xDF;
+            const bool good = t0 + idx < n && (cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T');
+            const bool start = (s_sb[idx >> 5] >> (idx & 31)) & 1u;
+            run = good ? (start ? 1u : run + 1u) : 0u;
+            if (i + 1 >= k && run >= k) {
+                const uint32_t j = i + 1 - k, a0 = s + j;   // the window [a0, a0 + k) is emitted; its strand: raw-byte compare, ties -> rc
+                bool is_rc = true;
+                for (uint32_t m = 0; m < k; m++) {
+                    const uint8_t a = s_b[a0 + m], b = s_comp[s_b[a0 + k - 1 - m]];
+                    if (a != b) { is_rc = !(a < b); break; }
+                }
+                vmask |= 0x80u >> j;
+                if (is_rc) rmask |= 0x80u >> j;
+            }
+        }
+        s_v[threadIdx.x] = (uint8_t)vmask; s_r[threadIdx.x] = (uint8_t)rmask;
+        mine += __popc(vmask);
+        __syncthreads();
+        if (threadIdx.x < kPlThreads / 2) {
+            const uint64_t w = (t0 >> 4) + threadIdx.x;
+            if (w < n_words) {
+                valid16[w] = (uint16_t)(((uint32_t)s_v[2 * threadIdx.x] << 8) | s_v[2 * threadIdx.x + 1]);
+                rc16[w] = (uint16_t)(((uint32_t)s_r[2 * threadIdx.x] << 8) | s_r[2 * threadIdx.x + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kPlThreads / 64; w++) t += s_cnt[w];
+        if (t) atomicAdd(total, t);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -69,6 +69,13 @@ class Communicator:
     def allreduce_accumulators(self):
         L.check(L.lib().ntk_allreduce_accumulators(self._h), "ntk_allreduce_accumulators")
 
+    def allreduce_time_ms(self):
+        """(total ms, calls) of the all-reduces issued while the first local ctx had timing enabled, since the last call
+        (ntk_comm_allreduce_time_ms: hipEvents on the stream the collective runs on)."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        L.check(L.lib().ntk_comm_allreduce_time_ms(self._h, C.byref(ms), C.byref(n)), "ntk_comm_allreduce_time_ms")
+        return ms.value, n.value
+
     def close(self):
         if self._h:
             L.lib().ntk_comm_destroy(self._h)

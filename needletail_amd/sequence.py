@@ -150,6 +150,56 @@ def canonical_kmers_batch(records, k: int, ctx: Context = None):
     return counts[: len(records)], pos[: n.value], flg[: n.value]
 
 
+class CanonicalKmersPlanes:
+    """The items of Sequence::canonical_kmers(k, &rc) for a batch of records as two bit planes (ntk_canonical_kmers_batch_planes):
+    per window start "emitted" and "is_rc".  `iter(i, buffer, rc)` walks record i's bits and yields exactly what the reference
+    iterator yields for it - (pos, buffer[pos:pos+k] or the rc slice, is_rc), reference src/kmer.rs:114-129 - and `arrays(i)` the
+    (pos, is_rc) arrays.  One quarter of a byte crosses PCIe per sequence byte (ntk_canonical_kmers_batch: nine bytes per item)."""
+
+    def __init__(self, k, lengths, rec_bit, valid16, rc16, total):
+        self.k, self.lengths, self.rec_bit, self.valid16, self.rc16, self.total = k, lengths, rec_bit, valid16, rc16, total
+
+    def _bits(self, plane, i):
+        n = int(self.lengths[i]) - self.k + 1
+        if n <= 0:
+            return np.zeros(0, dtype=np.uint8)
+        b0 = int(self.rec_bit[i])
+        w0, w1 = b0 >> 4, (b0 + n + 15) >> 4
+        # bit (15 - b % 16) of word b / 16: big-endian bit order inside each 16-bit word
+        bits = np.unpackbits(plane[w0:w1].astype(">u2").view(np.uint8))
+        return bits[b0 - 16 * w0: b0 - 16 * w0 + n]
+
+    def arrays(self, i):
+        v = self._bits(self.valid16, i)
+        pos = np.flatnonzero(v).astype(np.uint64)
+        return pos, self._bits(self.rc16, i)[pos.astype(np.int64)]
+
+    def count(self, i):
+        return int(self._bits(self.valid16, i).sum())
+
+    def iter(self, i, buffer: bytes, rc: bytes):
+        k, n = self.k, len(rc)
+        pos, flg = self.arrays(i)
+        for p, f in zip(pos.tolist(), flg.tolist()):
+            yield (p, rc[n - p - k: n - p], True) if f else (p, buffer[p: p + k], False)
+
+
+def canonical_kmers_planes(records, k: int, ctx: Context = None) -> CanonicalKmersPlanes:
+    """Sequence::canonical_kmers for a whole batch of records in one device pass, bit-plane result (see CanonicalKmersPlanes)."""
+    c = _ctx(ctx)
+    if k < 1 or k > 255:
+        raise ValueError("k must be 1..255")
+    seq, offs = _pack_records(records)
+    cap = int(offs[-1]) // 16 + len(records) + 1
+    rec_bit = np.zeros(len(records) + 1, dtype=np.uint64)
+    valid16 = np.zeros(cap, dtype=np.uint16)
+    rc16 = np.zeros(cap, dtype=np.uint16)
+    nw, tot = C.c_uint64(0), C.c_uint64(0)
+    L.check(L.lib().ntk_canonical_kmers_batch_planes(c._h, seq, offs.ctypes.data, len(records), k, rec_bit.ctypes.data, valid16.ctypes.data,
+                                                     rc16.ctypes.data, cap, C.byref(nw), C.byref(tot)), "ntk_canonical_kmers_batch_planes")
+    return CanonicalKmersPlanes(k, np.diff(offs.astype(np.int64)), rec_bit, valid16[: nw.value], rc16[: nw.value], tot.value)
+
+
 def minimizer(seq: bytes, length: int, ctx: Context = None) -> bytes:
     """sequence::minimizer (reference src/sequence.rs:139-152)."""
     c = _ctx(ctx)

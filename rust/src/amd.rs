@@ -57,6 +57,7 @@ extern "C" {
     pub fn ntk_comm_init_rank(ctx: *mut NtkCtx, n_ranks: c_int, rank: c_int, id: *const u8, out: *mut *mut NtkComm) -> c_int;
     pub fn ntk_comm_size(comm: *const NtkComm) -> c_int;
     pub fn ntk_allreduce_accumulators(comm: *mut NtkComm) -> c_int;
+    pub fn ntk_comm_allreduce_time_ms(comm: *mut NtkComm, total_ms: *mut f64, calls: *mut u64) -> c_int;
     pub fn ntk_comm_destroy(comm: *mut NtkComm);
     pub fn ntk_accum_reset(ctx: *mut NtkCtx) -> c_int;
     pub fn ntk_reduce_device(ctx: *mut NtkCtx, d_seq: *const u8, n_bytes: u64, p: *const NtkParams) -> c_int;
@@ -91,6 +92,8 @@ extern "C" {
     pub fn ntk_canonical_kmers_batch(ctx: *mut NtkCtx, seq: *const u8, offsets: *const u64, n_records: u64, k: u32, counts: *mut u64, pos_out: *mut u64, is_rc_out: *mut u8, cap: u64, total: *mut u64) -> c_int;
     pub fn ntk_bit_kmers_batch(ctx: *mut NtkCtx, seq: *const u8, offsets: *const u64, n_records: u64, k: u32, canonical: c_int, counts: *mut u64, pos_out: *mut u64, val_out: *mut u64, was_rc_out: *mut u8, cap: u64, total: *mut u64) -> c_int;
     pub fn ntk_pinned_alloc(bytes: u64, out: *mut *mut c_void) -> c_int;
+    pub fn ntk_canonical_kmers_batch_planes(ctx: *mut NtkCtx, seq: *const u8, offsets: *const u64, n_records: u64, k: u32, rec_bit: *mut u64, valid16: *mut u16, rc16: *mut u16, cap_words: u64, n_words: *mut u64, total: *mut u64) -> c_int;
+    pub fn ntk_ctx_trim(ctx: *mut NtkCtx) -> c_int;
     pub fn ntk_pinned_free(p: *mut c_void);
     pub fn ntk_minimizers_reduce_device(ctx: *mut NtkCtx, d_seq: *const u8, n_bytes: u64, p: *const NtkParams, w: u32) -> c_int;
     pub fn ntk_minimizer(ctx: *mut NtkCtx, seq: *const u8, n: u64, m: u32, out: *mut u8) -> c_int;
@@ -154,6 +157,33 @@ impl AmdCanonicalKmersBatch {
         (self.starts[i]..self.starts[i + 1]).map(move |j| {
             let (p, f) = (self.pos[j] as usize, self.is_rc[j] != 0);
             if f { (p, &rc[n - p - k..n - p], true) } else { (p, &buffer[p..p + k], false) }
+        })
+    }
+}
+
+/// The same items as two BIT PLANES (ntk_canonical_kmers_batch_planes): per window start "emitted" and "is_rc" - a quarter of a byte
+/// per sequence byte crosses PCIe instead of nine bytes per item, and the records are uploaded as they lie in one contiguous buffer.
+/// `iter(i, buffer, rc)` walks record i's bits and yields what `CanonicalKmers` yields (src/kmer.rs:114-129).
+pub struct AmdCanonicalKmersPlanes { k: usize, lens: Vec<usize>, rec_bit: Vec<u64>, valid16: Vec<u16>, rc16: Vec<u16>, pub total: u64 }
+impl AmdCanonicalKmersPlanes {
+    /// `seq` + `offsets` (n + 1 entries): record i = seq[offsets[i]..offsets[i + 1]] - e.g. the reader's own buffer, no copy
+    pub fn new(ctx: &AmdContext, seq: &[u8], offsets: &[u64], k: u8) -> Result<Self, AmdError> {
+        let n = offsets.len() - 1;
+        let cap = (offsets[n] - offsets[0]) / 16 + n as u64 + 1;
+        let (mut rec_bit, mut valid16, mut rc16) = (vec![0u64; n + 1], vec![0u16; cap as usize], vec![0u16; cap as usize]);
+        let (mut words, mut total) = (0u64, 0u64);
+        check(unsafe { ntk_canonical_kmers_batch_planes(ctx.0, seq.as_ptr(), offsets.as_ptr(), n as u64, k as u32, rec_bit.as_mut_ptr(),
+                                                         valid16.as_mut_ptr(), rc16.as_mut_ptr(), cap, &mut words, &mut total) })?;
+        valid16.truncate(words as usize); rc16.truncate(words as usize);
+        let lens = (0..n).map(|i| (offsets[i + 1] - offsets[i]) as usize).collect();
+        Ok(Self { k: k as usize, lens, rec_bit, valid16, rc16, total })
+    }
+    #[inline] fn bit(plane: &[u16], b: u64) -> bool { (plane[(b >> 4) as usize] >> (15 - (b & 15))) & 1 != 0 }
+    pub fn iter<'a>(&'a self, i: usize, buffer: &'a [u8], rc: &'a [u8]) -> impl Iterator<Item = (usize, &'a [u8], bool)> + 'a {
+        let (k, n, b0) = (self.k, rc.len(), self.rec_bit[i]);
+        let windows = (self.lens[i] + 1).saturating_sub(k);
+        (0..windows).filter(move |&p| Self::bit(&self.valid16, b0 + p as u64)).map(move |p| {
+            if Self::bit(&self.rc16, b0 + p as u64) { (p, &rc[n - p - k..n - p], true) } else { (p, &buffer[p..p + k], false) }
         })
     }
 }

@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_strerror():
     from needletail_amd import _lib
     L = _lib.lib()
-    assert L.ntk_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "needletail_amd.h")).read()
+    assert L.ntk_abi_version() == int(re.search(r"#define NTK_ABI_VERSION (\d+)", hdr).group(1)) == 2   # 2: round 4 added entry points
     assert _lib.strerror(0) == "ok"
     assert "k" in _lib.strerror(1)
 
@@ -127,6 +128,14 @@ def test_cpp_mirror_quality_and_minimizers_on_gpu():
     assert (int(lines[2]), int(lines[3])) == (cv, int(crc))
     assert int(lines[4]) == O.bit_minimizer(0x1B, 4, 2)
     assert [int(x) for x in lines[5:18]] == [2, 27, 14, 27, 14, 33, 33, 37, 37, 37, 33, 37, 27]
+    # CanonicalKmersPlanes: three records in one buffer, every item as the reference iterator yields it (oracle = its restatement)
+    recs = [b"ACGT", b"AGTCGTCA", b"nACGTACGTN"]
+    want = []
+    for i, rec in enumerate(recs):
+        rc = O.reverse_complement(rec)
+        want += [f"{i}:{p}:{kmer.decode()}:{int(f)}" for p, kmer, f in O.canonical_kmers(rec, rc, 2)]
+    assert lines[18] == "planes" and int(lines[19]) == len(want)
+    assert lines[20:20 + len(want)] == want
 
 
 def _c_smoke():

@@ -1065,12 +1065,33 @@ def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, 
             assert np.array_equal(pos[o:o + n], p_) and np.array_equal(flg[o:o + n], f_)
             o += n
         assert o == len(pos)
+    # the same items as bit planes (ntk_canonical_kmers_batch_planes): the records are uploaded as they lie (no break bytes: windows
+    # must not reach across a record start), a chunk begins on a word boundary of the planes, empty records share a position
+    for k in (1, 2, 4, 21, 33, 70, 255):
+        pl = nt.canonical_kmers_planes(records, k, ctx)
+        tot = 0
+        for i, r in enumerate(records):
+            p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), k)
+            gp, gf = pl.arrays(i)
+            assert np.array_equal(gp, p_) and np.array_equal(gf, f_), (k, i, len(r))
+            tot += len(p_)
+        assert pl.total == tot and int(pl.rec_bit[-1]) == 16 * len(pl.valid16)
+        # nothing is set outside the records' own windows (padding bits, the last k - 1 starts of a record)
+        allbits = int(np.unpackbits(pl.valid16.astype(">u2").view(np.uint8)).sum())
+        assert allbits == tot and int(np.unpackbits((pl.rc16 & ~pl.valid16).astype(">u2").view(np.uint8)).sum()) == 0
+    it = list(nt.canonical_kmers_planes(records[:8], 4, ctx).iter(4, records[4], O.reverse_complement(records[4])))
+    assert it == O.canonical_kmers(records[4], O.reverse_complement(records[4]), 4)
     # capacity protocol: too small a buffer reports the needed count and fills what fits
     import ctypes as C
     from needletail_amd import _lib as L
     seq = b"".join(records)
     offs = np.zeros(len(records) + 1, dtype=np.uint64)
     np.cumsum([len(r) for r in records], out=offs[1:])
+    rb = np.zeros(len(records) + 1, dtype=np.uint64); nw = C.c_uint64(0); tt = C.c_uint64(0)
+    v16 = np.zeros(4, dtype=np.uint16); r16 = np.zeros(4, dtype=np.uint16)
+    rc = L.lib().ntk_canonical_kmers_batch_planes(ctx._h, seq, offs.ctypes.data, len(records), 21, rb.ctypes.data, v16.ctypes.data, r16.ctypes.data,
+                                                  4, C.byref(nw), C.byref(tt))
+    assert rc == 5 and nw.value >= len(seq) // 16 and not v16.any()
     want_counts, want_pos, want_val, want_flg = nt.bit_kmers_batch(records, 21, True, ctx)
     cap = 100
     cnt = np.zeros(len(records), dtype=np.uint64); p2 = np.zeros(cap, dtype=np.uint64); v2 = np.zeros(cap, dtype=np.uint64)

@@ -58,7 +58,35 @@ for m, c in cnt.items():
         cls["VMEM"] += c
     elif m.startswith("s_"):
         cls["SALU (incl. branches, waitcnt, nop)"] += c
+# issue classes measured in round 4 (profiles/r04a/README.md): 2 cycles per wave-instruction for the plain 32-bit ALU ops below when they
+# carry no DPP / SDWA modifier and no SGPR operand (a literal is fine; vcc as the v_cndmask mask is fine), 4 cycles for everything else
+FULL_RATE = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32",
+             "v_mov_b32", "v_bitop3_b32", "v_cndmask_b32", "v_min_u16", "v_add_u16", "v_add_f32"}
+def issue_class(line):
+    toks = line.split()
+    m = toks[0]
+    base = re.sub(r"_(e32|e64)$", "", m)
+    if base.endswith(("_dpp", "_sdwa")) or base not in FULL_RATE:
+        return "half"
+    ops = " ".join(toks[1:])
+    ops = re.sub(r"\bvcc(_lo|_hi)?\b", "", ops)
+    return "half" if re.search(r"\bs\d+\b|\bs\[\d+:\d+\]", ops) else "full"
+valu_lines = []
+for b in blocks:
+    if any("v_cmp_gt_i64" in l for l in b):
+        continue
+    valu_lines += [l.strip() for l in b if l.strip().startswith("v_")]
+classes = collections.Counter(issue_class(l) for l in valu_lines)
+if "--json" in sys.argv:
+    import json
+    print(json.dumps({"kernel": f"scan2_kernel<{K}, true, true, false, 14, 0, false>", "valu_per_tile": sum(classes.values()),
+                      "half_rate": classes["half"], "full_rate": classes["full"], "salu_per_tile": cls["SALU (incl. branches, waitcnt, nop)"],
+                      "lds_per_tile": cls["LDS"], "cycles_half": 4.1, "cycles_full": 2.05,
+                      "source": "tools/isa_census.py --json (ISA listing of the tile loop; classes: profiles/r04a/README.md)"}))
+    sys.exit(0)
 print(f"scan2_kernel<{K}, true, true, false, 14, 0> {os.environ.get('NTK_CENSUS_FLAGS', '')}: tile loop, instructions per 992-base tile (steady state)")
+print(f"  issue classes (profiles/r04a): {classes['half']} half-rate (4.1 cycles) + {classes['full']} full-rate (2.05 cycles) = "
+      f"{classes['half'] * 4.1 + classes['full'] * 2.05:.0f} cycles of VALU issue per tile")
 for k_, v in sorted(cls.items()):
     print(f"  {k_:40s} {v}")
 for m, c in cnt.most_common():

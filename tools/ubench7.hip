@@ -1,0 +1,202 @@
+// ubench4.hip - how do full-rate and half-rate VALU instructions share a SIMD on gfx950?
+// (round 4: the scan2 kernel runs 175 VALU instructions per tile at 4.04 cycles each although 55 of them are "full-rate"
+//  ones that a pure stream issues every 2.45 cycles: where do the 1.3 cycles go?)
+// Every kernel runs ITERS trips of a 16-instruction pattern over 16 independent register chains (8 for the full-rate op,
+// 8 for the half-rate op), with 1 .. 8 waves per SIMD.  Per wave: s_memtime at both ends, the SIMD it ran on (HW_ID, XCC_ID);
+// the host groups waves by SIMD and reports cycles per wave-instruction per SIMD = span of the SIMD's waves * clock / instructions.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <map>
+#include <algorithm>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define F(i) "v_xor_b32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define G(i) "v_add_u32 %[b" #i "], %[b" #i "], %[a" #i "]\n"
+#define H(i) "v_alignbit_b32 %[c" #i "], %[c" #i "], %[d" #i "], 7\n"
+#define C(i) "v_cmp_lt_u32 vcc, %[c" #i "], %[d" #i "]\n"
+#define S(i) "s_and_b64 s[20:21], s[22:23], s[24:25]\n"
+#define L(i) "v_and_b32 %[a" #i "], 0xfffc, %[a" #i "]\n"
+#define R(i) "v_lshrrev_b32 %[b" #i "], 1, %[b" #i "]\n"
+#define B3(i) "v_bitop3_b32 %[a" #i "], %[a" #i "], %[b" #i "], %[c" #i "] bitop3:0x96\n"
+#define X64(i) "v_xor_b32_e64 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define M(i) "v_mov_b32 %[a" #i "], %[b" #i "]\n"
+#define DPPF(i) "v_xor_b32_dpp %[a" #i "], %[a" #i "], %[b" #i "] row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define SDWAF(i) "v_and_b32_sdwa %[a" #i "], %[a" #i "], %[b" #i "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define ASHR(i) "v_ashrrev_i32 %[a" #i "], 3, %[b" #i "]\n"
+#define SUBF(i) "v_sub_u32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define OR2(i) "v_or_b32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define NOT1(i) "v_not_b32 %[a" #i "], %[b" #i "]\n"
+#define ADDC(i) "v_addc_co_u32 %[a" #i "], vcc, %[a" #i "], %[b" #i "], vcc\n"
+#define PKMOV(i) "v_pk_mov_b32 %[q" #i "], %[q" #i "], %[q" #i "]\n"
+#define LSHLADD(i) "v_lshl_add_u32 %[a" #i "], %[a" #i "], 2, %[b" #i "]\n"
+#define ADDLSHL(i) "v_add_lshl_u32 %[a" #i "], %[a" #i "], %[b" #i "], 2\n"
+#define MAX3(i) "v_max3_u32 %[a" #i "], %[a" #i "], %[b" #i "], %[c" #i "]\n"
+#define MED3(i) "v_med3_u32 %[a" #i "], %[a" #i "], %[b" #i "], %[c" #i "]\n"
+#define BFI(i) "v_bfi_b32 %[a" #i "], %[a" #i "], %[b" #i "], %[c" #i "]\n"
+#define SUBREV(i) "v_subrev_u32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define XNOR(i) "v_xnor_b32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define MBCNT(i) "v_mbcnt_lo_u32_b32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define CNDV(i) "v_cndmask_b32 %[a" #i "], %[a" #i "], %[b" #i "], vcc\n"
+#define MINU16(i) "v_min_u16 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define ADDU16(i) "v_add_u16 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define PKADDF32(i) "v_pk_add_f32 %[q" #i "], %[q" #i "], %[q" #i "]\n"
+#define ADDF32(i) "v_add_f32 %[a" #i "], %[a" #i "], %[b" #i "]\n"
+#define CVT(i) "v_cvt_f32_ubyte0 %[a" #i "], %[b" #i "]\n"
+#define MADU64(i) "v_mad_u64_u32 %[q" #i "], vcc, %[a" #i "], 1, %[q" #i "]\n"
+#define LSHLADD64(i) "v_lshl_add_u64 %[q" #i "], %[q" #i "], 0, %[q" #i "]\n"
+
+#define NOP(i) "s_nop 0\n"
+#define PKMIN(i) "v_pk_min_u16 %[c" #i "], %[c" #i "], %[d" #i "]\n"
+#define PERM(i) "v_perm_b32 %[c" #i "], %[c" #i "], %[d" #i "], %[d" #i "]\n"
+#define DSADD(i) "ds_add_u32 %[d" #i "], %[c" #i "]\n"
+#define BAR(i) "s_barrier\n"
+#define SLP0(i) "s_sleep 0\n"
+#define SLP1(i) "s_sleep 1\n"
+#define NOP7(i) "s_nop 7\n"
+#define WAIT0(i) "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+#define PRIO(i) "s_setprio 1\n s_setprio 0\n"
+#define VNOP(i) "v_nop\n"
+#define MEMT(i) "s_memtime s[26:27]\n s_waitcnt lgkmcnt(0)\n"
+#define GETREG(i) "s_getreg_b32 s26, hwreg(HW_REG_HW_ID)\n"
+#define DSRD(i) "ds_read_b32 %[c7], %[d7]\n s_waitcnt lgkmcnt(0)\n"
+#define RFL(i) "v_readfirstlane_b32 s26, %[a7]\n"
+#define BRN(i) "s_cmp_eq_u32 s26, s26\n s_cbranch_scc0 1f\n 1:\n"
+#define BRT(i) "s_branch 1f\n s_nop 0\n 1:\n"
+#define EXECW(i) "s_mov_b64 exec, -1\n"
+#define SETH(i) "s_sethalt 0\n"
+#define WAKE(i) "s_wakeup\n"
+#define ICINV(i) "s_nop 0\n"
+#define OPS                                                                                                                          \
+    : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]), [a6] "+v"(a[6]), [a7] "+v"(a[7]), \
+      [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [b3] "+v"(b[3]), [b4] "+v"(b[4]), [b5] "+v"(b[5]), [b6] "+v"(b[6]), [b7] "+v"(b[7]), \
+      [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]), [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), \
+      [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [d4] "+v"(d[4]), [d5] "+v"(d[5]), [d6] "+v"(d[6]), [d7] "+v"(d[7]), \
+      [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]), [q4] "+v"(q[4]), [q5] "+v"(q[5]), [q6] "+v"(q[6]), [q7] "+v"(q[7])  \
+    : : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27"
+
+#define ALL8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int PAT>
+__global__ __launch_bounds__(1024) void ub(uint64_t *out, uint32_t seed, int iters)
+{
+    __shared__ uint32_t lds[4096];
+    uint32_t a[8], b[8], c[8], d[8];
+    uint64_t q[8];
+    for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x * (2 * i + 1); b[i] = a[i] ^ (0x1234u + i); c[i] = a[i] * 3u; d[i] = (b[i] * 5u) & 0x3FFCu; q[i] = ((uint64_t)a[i] << 32) | b[i]; }
+    lds[threadIdx.x] = 0; __syncthreads();
+    const uint64_t c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; it++) {
+        if constexpr (PAT == 0) asm volatile(".rept 8\n" F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) ".endr\n" OPS);
+        else if constexpr (PAT == 1) asm volatile(".rept 8\n" H(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 2) asm volatile(".rept 8\n" H(0) BAR(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 3) asm volatile(".rept 8\n" H(0) SLP0(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 4) asm volatile(".rept 8\n" H(0) SLP1(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 5) asm volatile(".rept 8\n" H(0) NOP7(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 6) asm volatile(".rept 8\n" H(0) WAIT0(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 7) asm volatile(".rept 8\n" H(0) PRIO(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 8) asm volatile(".rept 8\n" H(0) VNOP(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 9) asm volatile(".rept 8\n" H(0) MEMT(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 10) asm volatile(".rept 8\n" H(0) GETREG(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 11) asm volatile(".rept 8\n" H(0) DSRD(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 12) asm volatile(".rept 8\n" H(0) RFL(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 13) asm volatile(".rept 8\n" H(0) BRN(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 14) asm volatile(".rept 8\n" H(0) BRT(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 15) asm volatile(".rept 8\n" H(0) EXECW(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 16) asm volatile(".rept 8\n" H(0) WAKE(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 17) asm volatile(".rept 8\n" H(0) H(1) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 18) asm volatile(".rept 8\n" H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 19) asm volatile(".rept 8\n" H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) BAR(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 20) asm volatile(".rept 8\n" H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) SLP0(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 21) asm volatile(".rept 8\n" H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) DSRD(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 22) asm volatile(".rept 8\n" H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+        else if constexpr (PAT == 23) asm volatile(".rept 8\n" H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) H(0) H(1) H(2) H(3) H(4) H(5) H(6) H(7) BAR(0) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) ".endr\n" OPS);
+    }
+    const uint64_t c1 = clock64(), w1 = wall_clock64();
+    uint32_t acc = 0;
+    acc += lds[threadIdx.x & 4095];
+    for (int i = 0; i < 8; i++) acc += a[i] + b[i] + c[i] + d[i] + (uint32_t)q[i] + (uint32_t)(q[i] >> 32);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        out[w * 4 + 0] = w0; out[w * 4 + 1] = w1; out[w * 4 + 2] = c1 - c0; out[w * 4 + 3] = ((uint64_t)(xcc & 0xF) << 32) | hwid | ((uint64_t)(acc == 0x12345u) << 63);
+    }
+}
+
+struct Pat { int id; const char *name; void (*fn)(uint64_t *, uint32_t, int); int nvalu; };
+
+int main(int argc, char **argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 2048;
+    uint64_t *d; CHK(hipMalloc(&d, 512 * 16 * 32 + 4096));
+    Pat pats[] = {
+        {0, "pure F", ub<0>, 264},
+        {1, "H + 32 F", ub<1>, 264},
+        {2, "H + BAR + 32 F", ub<2>, 264},
+        {3, "H + SLP0 + 32 F", ub<3>, 264},
+        {4, "H + SLP1 + 32 F", ub<4>, 264},
+        {5, "H + NOP7 + 32 F", ub<5>, 264},
+        {6, "H + WAIT0 + 32 F", ub<6>, 264},
+        {7, "H + PRIO + 32 F", ub<7>, 264},
+        {8, "H + VNOP + 32 F", ub<8>, 264},
+        {9, "H + MEMT + 32 F", ub<9>, 264},
+        {10, "H + GETREG + 32 F", ub<10>, 264},
+        {11, "H + DSRD + 32 F", ub<11>, 264},
+        {12, "H + RFL + 32 F", ub<12>, 264},
+        {13, "H + BRN + 32 F", ub<13>, 264},
+        {14, "H + BRT + 32 F", ub<14>, 264},
+        {15, "H + EXECW + 32 F", ub<15>, 264},
+        {16, "H + WAKE + 32 F", ub<16>, 264},
+        {17, "H H + 32 F", ub<17>, 272},
+        {18, "8 H + 32 F", ub<18>, 320},
+        {19, "8 H + BAR + 32 F", ub<19>, 320},
+        {20, "8 H + SLP0 + 32 F", ub<20>, 320},
+        {21, "8 H + DSRD + 32 F", ub<21>, 320},
+        {22, "32 H + 32 F", ub<22>, 512},
+        {23, "32 H + BAR + 32 F", ub<23>, 512},
+    };
+    struct Geo { int blocks, threads; } geos[] = {{256, 128}, {256, 512}, {512, 768}, {512, 1024}};
+    printf("cycles per wave-instruction per SIMD (median over SIMDs; [waves per SIMD seen: min..max]); columns = launch geometry\n");
+    printf("%-44s", "pattern");
+    for (auto &g : geos) printf("  %4dx%-4d      ", g.blocks, g.threads);
+    printf("\n");
+    for (auto &p : pats) {
+        printf("%-44s", p.name);
+        const bool full = true;
+        for (auto &g : geos) {
+            if (!full && !(g.blocks == 512 && g.threads == 1024) && !(g.blocks == 256 && g.threads == 256)) { printf("  %-14s", "-"); continue; }
+            const int waves = g.blocks * (g.threads / 64);
+            for (int rep = 0; rep < 2; rep++) {   // first run warms the clocks
+                hipLaunchKernelGGL(p.fn, dim3(g.blocks), dim3(g.threads), 0, 0, d, 1u + rep, iters);
+                CHK(hipDeviceSynchronize());
+            }
+            std::vector<uint64_t> h((size_t)waves * 4);
+            CHK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+            struct Simd { uint64_t w0 = ~0ull, w1 = 0; double cyc = 0, wall = 0; int n = 0; };
+            std::map<uint64_t, Simd> simds;
+            for (int w = 0; w < waves; w++) {
+                const uint64_t id = h[w * 4 + 3] & 0x7FFFFFFFFFFFFFFFull;
+                const uint64_t key = ((id >> 32) << 16) | ((uint32_t)id & 0xFF30u);   // xcc | se, sh, cu, simd
+                Simd &s = simds[key];
+                s.w0 = std::min(s.w0, h[w * 4 + 0]); s.w1 = std::max(s.w1, h[w * 4 + 1]);
+                s.cyc += (double)h[w * 4 + 2]; s.wall += (double)(h[w * 4 + 1] - h[w * 4 + 0]); s.n++;
+            }
+            std::vector<double> cpi; int nmin = 1 << 30, nmax = 0;
+            for (auto &kv : simds) {
+                const Simd &s = kv.second;
+                const double ghz = s.cyc / (s.wall * 10.0);                // shader cycles per 10 ns tick of the 100 MHz wall clock
+                const double span_cycles = (double)(s.w1 - s.w0) * 10.0 * ghz;
+                cpi.push_back(span_cycles / ((double)s.n * iters * p.nvalu));
+                nmin = std::min(nmin, s.n); nmax = std::max(nmax, s.n);
+            }
+            std::sort(cpi.begin(), cpi.end());
+            printf("  %5.2f [%d..%d]%s", cpi[cpi.size() / 2], nmin, nmax, nmax > 9 ? "" : " ");
+        }
+        printf("\n");
+    }
+    return 0;
+}
