@@ -589,9 +589,102 @@ struct DevMasks2 {
     // forward count is s_and (F with the window's validity, which is exec) + s_bcnt1 + s_add.  (Measured, k = 31, profiles/r03a/wide_ab.txt: the
     // select inside the region with separate sums of the lo and hi words costs 16 more VALU instructions per tile and is 4-8 % slower;
     // these builds are VALU-bound at 235 instructions per tile - scalar count, LDS count and the round-2 region all run within 1 %.)
+    // Round 4 experiment, NOT shipped (NTK_WIDE_REGION_INSIDE; profiles/r04b/wide_region_ab.txt): the whole position inside the region -
+    // compare into vcc (under the window's exec it is "valid and forward": the count is s_bcnt1 of vcc itself), lo and T selected by two
+    // v_cndmask on vcc (full-rate; the VOP3 select on an SGPR pair the compiler emits is half-rate, and v_min_u32 is), the hi word one
+    // full-rate shift of T, and the (lo : hi) pair for v_lshl_add_u64 built in two PINNED register pairs (v[70:71], v[72:73]; T in v74 /
+    // v75, the cell offset in v76 / v77 - clobbers, so that the asm can name the halves).  3 half-rate + 5 full-rate VALU ops per position
+    // where the shipped form has 5 + 3, i.e. 4 issue cycles fewer by the class costs - and 2.5 % SLOWER (0.559 against 0.545 ms at k = 31):
+    // everything of a position is now one dependent chain under its own exec mask, where the shipped form computes compare, minimum,
+    // select, shift and cell under the full mask, for the scheduler to interleave.  The same selects as a 4-instruction snippet outside
+    // the region (NTK_WIDE_VCC_SELECT: v_cmp -> vcc, two v_cndmask, s_mov of the mask): 1.4 % slower.
     template <bool TIE_RC_, class S>
-    __device__ __forceinline__ void emit_canon_wide(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
+    __device__ __forceinline__ void emit_canon_wide(S &s_, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
                                                     const uint32_t (&rl)[4])
+    {
+#ifndef NTK_WIDE_REGION_INSIDE
+        emit_canon_wide_r3<TIE_RC_>(s_, pos, ft, rt, fl, rl);
+#else
+        static_assert(!kLight && K >= 17, "wide builds");
+        constexpr int SH = 64 - 2 * K;
+        uint32_t cn, nf_grp;
+        const uint32_t kMask = 0xFFFCu;
+#define NTK_W_PAIR(i) NTK_W_PAIR_##i
+#define NTK_W_PAIR_0 "v[70:71]"
+#define NTK_W_PAIR_1 "v[72:73]"
+#define NTK_W_PAIR_2 "v[70:71]"
+#define NTK_W_PAIR_3 "v[72:73]"
+#define NTK_W_LO_0 "v70"
+#define NTK_W_LO_1 "v72"
+#define NTK_W_LO_2 "v70"
+#define NTK_W_LO_3 "v72"
+#define NTK_W_HI_0 "v71"
+#define NTK_W_HI_1 "v73"
+#define NTK_W_HI_2 "v71"
+#define NTK_W_HI_3 "v73"
+#define NTK_W_T_0 "v74"
+#define NTK_W_T_1 "v75"
+#define NTK_W_T_2 "v74"
+#define NTK_W_T_3 "v75"
+#define NTK_W_O_0 "v76"
+#define NTK_W_O_1 "v77"
+#define NTK_W_O_2 "v76"
+#define NTK_W_O_3 "v77"
+#define NTK_W_SUM_0 "%[sumA]"
+#define NTK_W_SUM_1 "%[sumB]"
+#define NTK_W_SUM_2 "%[sumA]"
+#define NTK_W_SUM_3 "%[sumB]"
+#ifdef NTK_ABL_NOLDS
+#define NTK_W_HIST(i) ""
+#else
+#define NTK_W_HIST(i) "ds_add_u32 " NTK_W_O_##i ", %[one]\n"
+#endif
+        // SHIFTED: hi = T >> SH through the T register; K = 32: the hi word IS the chosen T word
+#define NTK_W_POS(i, CMP, SEL_HI, CNT)                                                              \
+        NTK_R_EXEC(i)                                                                               \
+        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                                                      \
+        "v_cndmask_b32 " NTK_W_LO_##i ", %[rl" #i "], %[fl" #i "], vcc\n"                           \
+        SEL_HI(i)                                                                                   \
+        "v_lshl_add_u64 " NTK_W_SUM_##i ", " NTK_W_PAIR_##i ", 0, " NTK_W_SUM_##i "\n"             \
+        "v_xor_b32 %[xh], %[xh], " NTK_W_HI_##i "\n"                                                \
+        "v_xor_b32 %[xlo], %[xlo], " NTK_W_LO_##i "\n"                                              \
+        NTK_W_HIST(i)                                                                               \
+        CNT
+#define NTK_W_SEL_SHIFT(i)                                                                          \
+        "v_cndmask_b32 " NTK_W_T_##i ", %[rt" #i "], %[ft" #i "], vcc\n"                            \
+        "v_lshrrev_b32 " NTK_W_HI_##i ", %[sh], " NTK_W_T_##i "\n"                                  \
+        "v_and_b32_sdwa " NTK_W_O_##i ", %[km], " NTK_W_T_##i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define NTK_W_SEL_K32(i)                                                                            \
+        "v_cndmask_b32 " NTK_W_HI_##i ", %[rt" #i "], %[ft" #i "], vcc\n"                           \
+        "v_and_b32_sdwa " NTK_W_O_##i ", %[km], " NTK_W_HI_##i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define NTK_W_IN(i) [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_R_MASKS(i)
+#define NTK_W_BODY(CMP, SEL) NTK_W_POS(0, CMP, SEL, NTK_R_CNT_FIRST) NTK_W_POS(1, CMP, SEL, NTK_R_CNT) NTK_W_POS(2, CMP, SEL, NTK_R_CNT) NTK_W_POS(3, CMP, SEL, NTK_R_CNT) "s_mov_b64 exec, -1\n"
+#define NTK_W_OPS                                                                                                                        \
+        : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [xh] "+v"(xh), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                        \
+        : NTK_W_IN(0), NTK_W_IN(1), NTK_W_IN(2), NTK_W_IN(3), [one] "v"(one), [km] "s"(kMask), [sh] "n"(SH)                            \
+        : "memory", "vcc", "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77"
+        static_assert(HB == 14, "the wide region forms the cell offset for the 14-bit histogram");
+        if constexpr (SH > 0) {
+            if constexpr (TIE_RC_) asm volatile(NTK_W_BODY("v_cmp_lt_u32", NTK_W_SEL_SHIFT) NTK_W_OPS);
+            else asm volatile(NTK_W_BODY("v_cmp_le_u32", NTK_W_SEL_SHIFT) NTK_W_OPS);
+        } else {
+            if constexpr (TIE_RC_) asm volatile(NTK_W_BODY("v_cmp_lt_u32", NTK_W_SEL_K32) NTK_W_OPS);
+            else asm volatile(NTK_W_BODY("v_cmp_le_u32", NTK_W_SEL_K32) NTK_W_OPS);
+        }
+        nf_s += nf_grp;
+#undef NTK_W_OPS
+#undef NTK_W_BODY
+#undef NTK_W_IN
+#undef NTK_W_SEL_K32
+#undef NTK_W_SEL_SHIFT
+#undef NTK_W_POS
+#undef NTK_W_HIST
+#endif
+    }
+
+    template <bool TIE_RC_, class S>
+    __device__ __forceinline__ void emit_canon_wide_r3(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
+                                                       const uint32_t (&rl)[4])
     {
         static_assert(!kLight && K >= 17, "wide builds");
         constexpr int SH = 64 - 2 * K;
@@ -599,10 +692,20 @@ struct DevMasks2 {
         uint64_t F[4], val[4], fm;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+#ifdef NTK_WIDE_VCC_SELECT   // compare into vcc, both selects on vcc (full-rate), the mask copied out for the count: 1 half-rate + 2 full-rate VALU ops
+            uint32_t T;     // + 1 scalar move where the compiler's form is 3 half-rate ops (VOP3 compare, v_min_u32, VOP3 select)
+            if constexpr (TIE_RC_)
+                asm("v_cmp_lt_u32 vcc, %[ft], %[rt]\n v_cndmask_b32 %[lo], %[rl], %[fl], vcc\n v_cndmask_b32 %[T], %[rt], %[ft], vcc\n s_mov_b64 %[F], vcc"
+                    : [lo] "=&v"(lo[i]), [T] "=&v"(T), [F] "=&s"(F[i]) : [ft] "v"(ft[i]), [rt] "v"(rt[i]), [fl] "v"(fl[i]), [rl] "v"(rl[i]) : "vcc");
+            else
+                asm("v_cmp_le_u32 vcc, %[ft], %[rt]\n v_cndmask_b32 %[lo], %[rl], %[fl], vcc\n v_cndmask_b32 %[T], %[rt], %[ft], vcc\n s_mov_b64 %[F], vcc"
+                    : [lo] "=&v"(lo[i]), [T] "=&v"(T), [F] "=&s"(F[i]) : [ft] "v"(ft[i]), [rt] "v"(rt[i]), [fl] "v"(fl[i]), [rl] "v"(rl[i]) : "vcc");
+#else
             const bool fwd = TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i];
             F[i] = __builtin_amdgcn_ballot_w64(fwd);   // the compare's own SGPR pair
             const uint32_t T = ft[i] < rt[i] ? ft[i] : rt[i];
             lo[i] = fwd ? fl[i] : rl[i];
+#endif
             hi[i] = SH ? T >> SH : T;
             off[i] = cell_offset_hi(T);
             val[i] = ((uint64_t)hi[i] << 32) | lo[i];
