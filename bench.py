@@ -489,7 +489,7 @@ def pmc_passes(args, n_bytes):
              "--no-secondary", "--no-pmc", "--reads", str(args.reads or 10_000_000), "--read-len", str(args.read_len), "--k", str(args.k),
              "--n-per-1024", str(args.n_per_1024), "--blocks", str(args.blocks), "--threads", str(args.threads)]
     got, names = {}, collections.Counter()
-    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]):
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE"]):
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
             try:
                 r = subprocess.run([tool, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp", env=env,
@@ -525,10 +525,16 @@ def pmc_passes(args, n_bytes):
             "shader_cycles_per_launch": round(cycles),
             "cycles_per_tile_per_simd": round(per_tile, 1),
             "cycles_per_inst": round(per_tile / ipt, 3),
+            **({"dual_issued_per_tile": round(got["SQ_ACTIVE_INST_VALU2"] / n_tiles, 1),
+                "issue_slots_per_tile": round(ipt - got["SQ_ACTIVE_INST_VALU2"] / n_tiles, 1),
+                "slot_busy": round((ipt - got["SQ_ACTIVE_INST_VALU2"] / n_tiles) * 4.1 / per_tile, 3),
+                "slot_note": "SQ_ACTIVE_INST_VALU2 = quad-cycles with a SECOND VALU instruction active: two full-rate instructions of two waves share "
+                             "one 4.1-cycle issue slot (profiles/r04a); slots = instructions - pairs; slot_busy = slots x 4.1 cycles / measured cycles"}
+               if "SQ_ACTIVE_INST_VALU2" in got else {}),
             "port_busy_by_SQ_ACTIVE_INST_VALU_x4": round(got.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (cycles * 1024), 4),
             "port_busy_note": "SQ_ACTIVE_INST_VALU counts ONE quad-cycle per instruction whatever its issue class (it equals SQ_INSTS_VALU): "
                               "this ratio is cycles_per_inst / 4 restated, not an occupancy (profiles/r04a/README.md)",
-            "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
+            "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE "
                       "(one child pass, per scan2_kernel launch; tile = 992 bases per wave)",
         }
     return out

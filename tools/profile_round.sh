@@ -13,6 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $BENCH --
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $BENCH --steps 5 --warmup 1 --no-verify --preheat-ms 5 > /dev/null 2> $O/pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -o p -- $BENCH --steps 5 --warmup 1 --no-verify --preheat-ms 5 > /dev/null 2> $O/pmc_sq.err
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- $BENCH --steps 5 --warmup 1 --no-verify --preheat-ms 5 > /dev/null 2> $O/pmc_sq2.err
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq3 -o p -- $BENCH --steps 5 --warmup 1 --no-verify --preheat-ms 5 > /dev/null 2> $O/pmc_sq3.err
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 # one rank through the launcher: the RCCL all-reduce path of the N > 1 runs (communicator of size 1) on configs[3]'s 8-GPU shard size
@@ -32,4 +33,6 @@ python tools/path_sweep.py 1,4,6,8,11,15,16,17,19,21,22,23,24,27,31,32 > $O/path
 python tools/min_grid.py > $O/min_grid.txt 2>&1
 bash tools/path_pmc.sh $TAG > /dev/null 2>&1
 python tools/compat_bench.py > $O/compat_bench.txt 2>&1
+python tools/compat_planes_bench.py >> $O/compat_bench.txt 2>&1
+[ -x tools/wbw ] && ( cd tools; ./wbw ) > $O/wbw.txt 2>&1
 ls $O
