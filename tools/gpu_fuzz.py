@@ -96,7 +96,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     t_end = time.time() + args.seconds
-    counts = {"reduce": 0, "materialize": 0, "minimizers": 0, "quality": 0, "compat_batch": 0}
+    counts = {"reduce": 0, "materialize": 0, "minimizers": 0, "quality": 0, "compat_batch": 0, "compat_planes": 0}
     n_bytes = 0
     it = 0
     while time.time() < t_end:
@@ -174,7 +174,28 @@ def main():
             recs = [buf[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
             if not recs:
                 continue
-            if rng.random() < 0.5:
+            u3 = rng.random()
+            if u3 < 0.34:
+                # the bit-plane form: any k <= 255 (the raw-byte kernel), records uploaded without break bytes
+                kp = int(rng.choice([k, k, int(rng.integers(1, 64)), int(rng.integers(64, 256))]))
+                if rng.random() < 0.5:
+                    os.environ["NTK_COMPAT_CHUNK_BYTES"] = str(int(rng.choice([64, 97, 1000, 4096, 1 << 16])))
+                else:
+                    os.environ.pop("NTK_COMPAT_CHUNK_BYTES", None)
+                pl = nt.canonical_kmers_planes(recs, kp, ctx=ctx)
+                os.environ.pop("NTK_COMPAT_CHUNK_BYTES", None)
+                ok, tot = True, 0
+                for i, r in enumerate(recs):
+                    p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), kp)
+                    gp, gf = pl.arrays(i)
+                    ok = ok and np.array_equal(gp, np.asarray(p_, dtype=np.uint64)) and np.array_equal(gf, np.asarray(f_, dtype=np.uint8))
+                    tot += len(p_)
+                ok = ok and pl.total == tot and int(np.unpackbits(pl.valid16.view(np.uint8)).sum()) == tot
+                if not ok:
+                    print("MISMATCH compat planes", tag, "k", kp); return 1
+                counts["compat_planes"] += 1
+                continue
+            if u3 < 0.67:
                 cnt, pos, flg = nt.canonical_kmers_batch(recs, k, ctx=ctx)
                 wp, wf = [], []
                 for r in recs:
