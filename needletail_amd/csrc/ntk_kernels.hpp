@@ -448,8 +448,23 @@ struct DevMasks2 {
     // Byte offset of a histogram cell = the value's top HB bits, * 4.  (LDS atomics at an address that is not 4-byte aligned raise a
     // memory violation on gfx950 - measured - so the low two bits have to be cleared.)  _hi: the prefix sits in bits 31:16 of T,
     // _lo: in bits 15:0 (the second position of a packed minimum).
+    // NTK_LANE_CELLS (round-4 experiment): the 14-bit cell = the value's top 12 bits (the result bin) + TWO BITS OF THE LANE NUMBER, so that the
+    // lanes of a wave spread over the banks by construction (LDS bank conflicts: 2/3 of the LDS's busy time, profiles/r04c); LIGHT then needs
+    // 2K - 12 <= 32: the canonical builds with 17 <= K <= 22.
+    uint32_t lane_off = 0;   // (lane & 3) << 2
+    uint32_t mask_fff0 = 0xFFF0u;
+#ifdef NTK_LANE_CELLS
+    static constexpr bool kLaneCells = K >= 17 && K <= 22 && HB == 14;
+#else
+    static constexpr bool kLaneCells = false;
+#endif
     __device__ __forceinline__ uint32_t cell_offset_hi(uint32_t T) const
     {
+        if constexpr (kLaneCells) {
+            uint32_t off;
+            asm("v_bitop3_b32 %0, %1, %3, %2 bitop3:0xea" : "=v"(off) : "v"(T >> 16), "v"(lane_off), "v"(mask_fff0));   // ((T >> 16) & 0xFFF0) | lane_off, full-rate (all operands VGPRs)
+            return off;
+        }
         if (HB == 14) {
             uint32_t off;
             const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
@@ -458,7 +473,15 @@ struct DevMasks2 {
         }
         return (T >> 18) & 0x3FFCu;
     }
-    __device__ __forceinline__ uint32_t cell_offset_lo(uint32_t T) const { return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu); }
+    __device__ __forceinline__ uint32_t cell_offset_lo(uint32_t T) const
+    {
+        if constexpr (kLaneCells) {
+            uint32_t off;
+            asm("v_bitop3_b32 %0, %1, %3, %2 bitop3:0xea" : "=v"(off) : "v"(T), "v"(lane_off), "v"(mask_fff0));
+            return off;
+        }
+        return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu);
+    }
 
     // ---- the masked regions ---------------------------------------------------------------------------------------------------
     // One asm block holds the side effects of FOUR positions.  Per position: exec <- VA & VB (the validity of the window ending
@@ -908,7 +931,81 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     DevMasks2<K, HB> mp;
     NoSink sink;
     mp.rep = lane & (uint32_t)(DevMasks2<K, HB>::kWordCopies - 1);
+    mp.lane_off = (lane & 3u) << 2;
+    asm volatile("v_mov_b32 %0, 0xfff0" : "=v"(mp.mask_fff0));   // a VGPR constant: v_bitop3 takes no literal, and an SGPR operand would make it half-rate
 
+#if defined(NTK_XCHUNK) && !defined(NTK_ABL_FLOOR) && !defined(NTK_SV2_PINGPONG)
+    // Round-4 experiment: the first tile of the NEXT chunk is loaded while the last tile of the current one is processed (the plain loop
+    // below starts every chunk with a load it waits for at once: ~1-2 us of HBM latency per 24 tiles and wave).
+    {
+        uint32_t r0 = 0, r1 = 0, voff = 0, pulled = 0;
+        uint64_t tile_byte = 0;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.seq, 0, 0, 0x00020000), rq = rs;
+        u32x4 ta = {0u, 0u, 0u, 0u}, qa = ta;
+        auto enter_chunk = [&](uint32_t nx) {   // sets the chunk's range and descriptors and issues the load of its first tile
+            r0 = shard_begin + nx;
+            r1 = r0 + a.chunk_tiles;
+            if (r1 > shard_end) r1 = shard_end;
+            const uint64_t t0 = a.tile_begin + r0;
+            const uint64_t run_byte = t0 * kTileStride;
+            const uint32_t halo = t0 ? 32u : 0u;
+            const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
+            uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - (run_byte - halo);
+            if (rem > 0xFFFFFF00ull) rem = 0xFFFFFF00ull;
+            const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
+            const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
+            const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
+            rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+            if constexpr (QM) {
+                const uint64_t qbase = (uint64_t)a.qual + run_byte - halo;
+                const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase);
+                const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
+                rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qhi << 32) | qlo), 0, nrec, 0x00020000);
+            }
+            voff = lane * 16u - (32u - halo);
+            tile_byte = run_byte;
+            ta = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            if constexpr (QM) qa = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
+        };
+        uint32_t next = 0;
+        if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+        next = __builtin_amdgcn_readfirstlane(next);
+        if (next < shard_tiles) enter_chunk(next);
+        while (next < shard_tiles) {
+            if (lane == 0) pulled = atomicAdd(ctr, a.chunk_tiles);   // the chunk after this one: in flight while this one is processed
+            const uint32_t r_end = r1;
+            for (uint32_t r = r0; r < r_end; r++) {
+                const bool tail = r >= a.tail_tile_rel;
+                Raw16 raw{ta.x, ta.y, ta.z, ta.w};
+                if constexpr (QM) raw = quality_break16(raw, Raw16{qa.x, qa.y, qa.z, qa.w}, a.q_add, a.q_sel);
+#ifdef NTK_ABL_LOADSONLY
+                mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
+#else
+                const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
+                mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
+#endif
+                // the registers of the tile are free: the next tile - of this chunk or the first one of the next - is loaded into them
+                if (r + 1 < r_end) {
+                    voff += kTileStride; tile_byte += kTileStride;
+                    ta = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+                    if constexpr (QM) qa = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
+                } else {
+                    next = __builtin_amdgcn_readfirstlane(pulled);
+                    if (next < shard_tiles) enter_chunk(next);
+                }
+#ifndef NTK_ABL_LOADSONLY
+                if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
+                else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
+                else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
+                else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
+#endif
+#ifdef NTK_V_CLOCKS
+                dbg_tiles++;
+#endif
+            }
+        }
+    }
+#else
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
     next = __builtin_amdgcn_readfirstlane(next);
@@ -1003,6 +1100,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         next = __builtin_amdgcn_readfirstlane(next);
     }
 
+#endif   // NTK_XCHUNK
 #ifdef NTK_V_CLOCKS
     if ((threadIdx.x & 63) == 0 && a.values) {  // per-wave census (tools/kbench.hip): start, end of the tile loop, shader cycles | tiles << 40, placement
         uint32_t hwid, xcc;
@@ -1023,7 +1121,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     nf = lane == 0 ? mp.nf_s : 0u;          // the wave's forward-strand count lives in a scalar register
     if constexpr (W > 0) nf = mp.nf_bits;   // strand bits of the chosen keys: forward count (TIE_RC) or rc count
     __syncthreads();
-    constexpr int HBE = HB;
+    constexpr int HBE = (DevMasks2<K, HB>::kLaneCells && W == 0) ? 12 : HB;   // bits of the cell index that are value bits
     for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
         uint32_t tot = 0;
         if constexpr (K <= 6) {   // word builds up to 6 bases: cell = copy * 4^K + value, bin = value
