@@ -364,6 +364,89 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     return NTK_OK;
 }
 
+// Generic fused windowed minimizers (ntk_kernels.hpp minimizer_scan_kernel): any k <= 31 and w <= 49 of the canonical paths, with or
+// without a quality stream; the tile geometry depends on w (2 + ceil((w - 1) / 16) non-emitting lanes).
+const void *pick_min_generic(const Mode &m, bool quality)
+{
+#define NTK_PICK_MG(KW, T, U, Q) if (m.kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q) return (const void *)&minimizer_scan_kernel<KW, T, U, Q>;
+#define NTK_PICK_MG4(KW, Q) NTK_PICK_MG(KW, false, false, Q) NTK_PICK_MG(KW, false, true, Q) NTK_PICK_MG(KW, true, false, Q) NTK_PICK_MG(KW, true, true, Q)
+    NTK_PICK_MG4(1, false) NTK_PICK_MG4(2, false) NTK_PICK_MG4(1, true) NTK_PICK_MG4(2, true)
+#undef NTK_PICK_MG4
+#undef NTK_PICK_MG
+    return nullptr;
+}
+
+int run_min_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, uint32_t w, const uint8_t *d_qual)
+{
+    if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
+    const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;
+    const void *fn = pick_min_generic(m, cutoff != 0);
+    if (!fn) return NTK_ERR_BAD_ARG;
+    const int threads = 256;
+    int per_cu = 0;
+    auto it = c->occupancy.find(std::make_pair(fn, threads));
+    if (it != c->occupancy.end()) per_cu = it->second;
+    else {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        c->occupancy[std::make_pair(fn, threads)] = per_cu;
+    }
+    const int blocks_max = c->launch_blocks > 0 ? c->launch_blocks : c->n_cu * per_cu;
+    const int waves_per_block = threads / 64;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    scan_args_set_k(a, p->k);
+    a.seq = d_seq; a.n_bytes = n;
+    if (cutoff) { const QualityCut qc = quality_cut(cutoff); a.qual = d_qual; a.q_add = qc.add; a.q_sel = qc.sel; }
+    a.min_w = w;
+    a.min_halo_lanes = (uint32_t)kHaloLanes + (w - 1 + 15) / 16;
+    {   // a k-mer invalid bit is OR-ed over the w window ends that contain the k-mer: doubling shifts that add up to w - 1
+        uint32_t len = 1;
+        for (int i = 0; i < 6; i++) { const uint32_t sft = len < w ? (len < w - len ? len : w - len) : 0; a.min_smear[i] = sft; len += sft; }
+    }
+    const uint64_t slots = 64 - a.min_halo_lanes, stride = slots * 16;
+    a.n_tiles = ((n + 15) / 16 + slots - 1) / slots;
+    bool zero_first = (p->flags & NTK_FLAG_RESET) != 0;
+    const uint64_t kMaxTilesPerLaunch = (uint64_t)8 << 22;
+    for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
+        const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
+        const uint64_t tiles = te - tb;
+        uint64_t chunk = tiles / ((uint64_t)blocks_max * waves_per_block * 4);
+        chunk = chunk < 1 ? 1 : (chunk > 16 ? 16 : chunk);
+        const uint64_t want_blocks = (tiles + chunk * waves_per_block - 1) / (chunk * waves_per_block);
+        const int blocks = (int)(want_blocks < (uint64_t)blocks_max ? want_blocks : (uint64_t)blocks_max);
+        a.tile_begin = tb; a.tile_end = te;
+        const uint64_t first_tail = n / stride;
+        a.tail_tile_rel = first_tail < tb ? 0u : (first_tail - tb > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)(first_tail - tb));
+        a.n_shards = blocks < kMaxShards ? (uint32_t)blocks : (uint32_t)kMaxShards;
+        a.tiles_per_shard = (uint32_t)((tiles + a.n_shards - 1) / a.n_shards);
+        a.chunk_tiles = (uint32_t)chunk;
+        a.work_counters = c->d_work;
+        a.zero_acc = zero_first ? c->d_acc : nullptr; a.zero_words = NTK_ACC_WORDS;
+        zero_first = false;
+        if (c->work_dirty) HIPCHK(hipMemsetAsync(c->d_work, 0, kMaxShards * 64, c->stream));
+        c->work_dirty = true;
+        int rc = ensure_partials(c, blocks);
+        if (rc) return rc;
+        a.part_hist = c->d_part_hist; a.part_scalars = c->d_part_scalars;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing) {
+            rc = get_event(c, &e0); if (rc) return rc;
+            rc = get_event(c, &e1); if (rc) { c->ev_free.push_back(e0); return rc; }
+            HIPCHK(hipEventRecord(e0, c->stream));
+        }
+        void *kargs[] = {(void *)&a};
+        HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), kargs, 0, c->stream));
+        if (c->timing) { HIPCHK(hipEventRecord(e1, c->stream)); c->ev_used.emplace_back(e0, e1); }
+        hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
+                           (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, c->d_work, (int)a.n_shards);
+        HIPCHK(hipGetLastError());
+        c->work_dirty = false;
+    }
+    return NTK_OK;
+}
+
 void destroy_batch(ntk_batch *b)
 {
     if (b->h_seq) (void)hipHostFree(b->h_seq);
@@ -1326,6 +1409,9 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
         const bool masked = d_qual && quality_cutoff(p);
         if (const void *fn = pick_scan_min(m, p->k, w, masked))
             return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, masked ? d_qual : nullptr, fn);
+        // every other (k <= 31, w <= 49): the generic fused kernel (one pass as well, run-time k and w)
+        if (p->k <= 31 && w <= 49 && !getenv("NTK_MINIMIZERS_NO_GENERIC"))
+            return run_min_scan(c, d_seq, n, p, m, w, masked ? d_qual : nullptr);
     }
     if (p->flags & NTK_FLAG_RESET) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
     if (n == 0) return NTK_OK;

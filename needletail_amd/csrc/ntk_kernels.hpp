@@ -1169,6 +1169,216 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 }
 
 #ifndef NTK_SCAN_TEMPLATES_ONLY   // ntk_scan2.hip instantiates scan2_kernel only; the plain kernels below belong to ntk_api.hip
+// ---------------------------------------------------------------------------------------------
+// Generic fused windowed minimizers (round 4): ANY (k <= 31, w <= 49) of the canonical paths in one pass, nothing written to HBM -
+// what every (k, w) without a register-fused scan2 build ran as materialise + window-min (8.8 ms per 1.5 Gbases, profiles/r04d).
+// Semantics as lane_tile_sv2_min / window_min_reduce_kernel (reference sequence::minimizer, src/sequence.rs:139-152, applied to every
+// window of w + k - 1 good bases): the window ending at byte e holds the w k-mers ending at e-w+1 .. e; its minimizer is the smallest
+// canonical value, the LEFTMOST on ties, reported with that k-mer's strand flag.
+//   * k-mers: the run-time-k tile logic of the round-1 kernel (lane_tile: value, "window of k contains a break" bit, strand per position).
+//   * key = (value << 1) | strand flag.  A minimum that prefers its LEFT operand on ties and ignores the strand bit:
+//         take L  <=>  key_L <= (key_R | 1)          (floor(key_L / 2) <= floor(key_R / 2))
+//   * sliding minimum over w for any run-time w, positions x = 16 * lane + j of the wave's tile, by binary decomposition with FIXED shifts:
+//         M_1 = key;  M_2q[x] = min(M_q[x - q], M_q[x]);      A (length a, the low bits of w so far):  A'[x] = min(A[x - q], M_q[x])  if bit q of w
+//     a shift by q < 16 reads own registers (j >= q) or the previous lane's (DPP wave_shr:1, q imports of two registers), q = 16 / 32 the
+//     previous lane's / the lane before that; everything is unrolled over j and the six possible q, the branches on w are wave-uniform.
+//   * window validity: the k-mer invalid bits of the lane and of the three lanes before it, OR-smeared over the w window ends each k-mer
+//     is part of (w <= 49 keeps that in 64 bits).
+// Tile geometry at run time: ScanArgs::min_halo_lanes non-emitting lanes, stride (64 - that) * 16 bytes.
+// ---------------------------------------------------------------------------------------------
+#ifndef NTK_MINGEN_MINBLOCKS
+// 256-thread blocks per CU the register allocation has to allow.  1 = no constraint: 164 VGPRs, 3 waves per SIMD, (23, 11) 2.2 ms per
+// config-2 batch; 4 (<= 128 VGPRs, ~35 dwords spilled): 4.9 ms; 5 (<= 96, ~70 spilled): 16.7 ms (profiles/r04d/min_generic.txt)
+#define NTK_MINGEN_MINBLOCKS 1
+#endif
+template <int KW>
+struct MinimizerSinkG {
+    uint64_t key[16];
+    uint32_t inval = 0;
+    int64_t base = 0;
+    __device__ __forceinline__ void begin_tile(int64_t lane_base, uint32_t inval16, bool) { base = lane_base; inval = inval16; }
+    __device__ __forceinline__ void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
+    {
+        const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+        key[j] = (v << 1) | (take_fwd ? 0u : 1u);
+    }
+    __device__ __forceinline__ void end_tile() {}
+};
+
+__device__ __forceinline__ uint64_t min_left(uint64_t l, uint64_t r) { return l <= (r | 1ull) ? l : r; }
+__device__ __forceinline__ uint64_t prev_lane64(const DevXL &xl, uint64_t v)
+{
+    return ((uint64_t)xl.prev(0, (uint32_t)(v >> 32)) << 32) | xl.prev(0, (uint32_t)v);
+}
+// X[x] <- min_left(Y[x - Q], X[x]) for the 16 own positions; Y may be X itself (doubling).  In place, descending j; the words that come
+// from the previous lane(s) are fetched first.
+template <int Q>
+__device__ __forceinline__ void min_shifted(const DevXL &xl, uint64_t (&X)[16], const uint64_t (&Y)[16])
+{
+    if constexpr (Q < 16) {
+        uint64_t imp[Q];
+#pragma unroll
+        for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, Y[16 + j - Q]);
+#pragma unroll
+        for (int j = 15; j >= 0; j--) X[j] = min_left(j >= Q ? Y[j - Q] : imp[j], X[j]);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {   // eight at a time: 16 more live registers instead of 32
+            uint64_t imp[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                imp[j] = prev_lane64(xl, Y[8 * h + j]);
+                if constexpr (Q == 32) imp[j] = prev_lane64(xl, imp[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) X[8 * h + j] = min_left(imp[j], X[8 * h + j]);
+        }
+    }
+}
+
+// A[x] <- min_left(A[x - Q], R[x])  (the partial window grows to the left by the Q positions of R's span)
+template <int Q>
+__device__ __forceinline__ void min_shifted_into(const DevXL &xl, uint64_t (&A)[16], const uint64_t (&R)[16])
+{
+    if constexpr (Q < 16) {
+        uint64_t imp[Q];
+#pragma unroll
+        for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, A[16 + j - Q]);
+#pragma unroll
+        for (int j = 15; j >= 0; j--) A[j] = min_left(j >= Q ? A[j - Q] : imp[j], R[j]);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint64_t imp[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                imp[j] = prev_lane64(xl, A[8 * h + j]);
+                if constexpr (Q == 32) imp[j] = prev_lane64(xl, imp[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) A[8 * h + j] = min_left(imp[j], R[8 * h + j]);
+        }
+    }
+}
+
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM>
+__global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kernel(ScanArgs a)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint64_t s_red[4 * 4];
+    if (a.zero_acc && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t shard = blockIdx.x % a.n_shards;
+    const uint32_t launch_tiles = (uint32_t)(a.tile_end - a.tile_begin);
+    const uint32_t shard_begin = shard * a.tiles_per_shard;
+    uint32_t shard_end = shard_begin + a.tiles_per_shard;
+    if (shard_end > launch_tiles) shard_end = launch_tiles;
+    uint32_t *ctr = a.work_counters + shard * 16;
+    const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
+    const uint32_t W = a.min_w, HL = a.min_halo_lanes, stride = (64u - HL) * 16u, halo_bytes = HL * 16u;
+    DevXL xl;
+    MinimizerSinkG<KW> sink;
+    uint64_t sum = 0, xr = 0;
+    uint32_t n_fwd = 0, n_valid = 0;
+
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+    next = __builtin_amdgcn_readfirstlane(next);
+    while (next < shard_tiles) {
+        const uint32_t r0 = shard_begin + next;
+        uint32_t r1 = r0 + a.chunk_tiles;
+        if (r1 > shard_end) r1 = shard_end;
+        if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+        const uint64_t t0 = a.tile_begin + r0;
+        const uint64_t run_byte = t0 * stride;
+        const uint32_t halo = t0 ? halo_bytes : 0u;
+        const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
+        uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - (run_byte - halo);
+        if (rem > 0xFFFFFF00ull) rem = 0xFFFFFF00ull;
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
+        const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+        __amdgpu_buffer_rsrc_t rq = rs;
+        if constexpr (QM) {
+            const uint64_t qbase = (uint64_t)a.qual + run_byte - halo;
+            const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase);
+            const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
+            rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qhi << 32) | qlo), 0, nrec, 0x00020000);
+        }
+        uint32_t voff = lane * 16u - (halo_bytes - halo);   // wraps (out of range -> 0) for the halo lanes of tile 0
+        uint64_t tile_byte = run_byte;                      // first emitting byte of the current tile
+        u32x4 cur = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0), curq = cur;
+        if constexpr (QM) curq = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
+        for (uint32_t r = r0; r < r1; r++) {
+            u32x4 nxt = cur, nxtq = curq;
+            if (r + 1 < r1) {
+                nxt = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + stride, 0, 0);
+                if constexpr (QM) nxtq = __builtin_amdgcn_raw_buffer_load_b128(rq, voff + stride, 0, 0);
+            }
+            const bool tail = r >= a.tail_tile_rel;
+            Raw16 raw{cur.x, cur.y, cur.z, cur.w};
+            if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
+            // lanes 0 and 1 are the k-mer halo of the tile logic (their k-mers would need bytes before the tile: all invalid)
+            lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane < (uint32_t)kHaloLanes, tail);
+            // window validity: a k-mer that is invalid takes the w windows it is part of with it
+            const uint32_t b1 = xl.prev(0, sink.inval), b2 = xl.prev(0, b1), b3 = xl.prev(0, b2);
+            uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | sink.inval;
+#pragma unroll
+            for (int i = 0; i < 6; i++) bw |= bw >> a.min_smear[i];
+            const uint32_t invw = lane < HL ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+            // sliding minimum over W (see above): M doubles, A collects the set bits of W from the low end
+            uint64_t (&M)[16] = sink.key;
+            uint64_t A[16];
+            bool have_a = false;   // wave-uniform: A holds a partial window already
+#define NTK_MIN_ROUND(Q)                                                                     \
+            if (W >= (Q)) {                                                                  \
+                if (W & (Q)) {                                                               \
+                    if (have_a) min_shifted_into<(Q)>(xl, A, M);                             \
+                    else { _Pragma("unroll") for (int j = 0; j < 16; j++) A[j] = M[j]; }     \
+                    have_a = true;                                                           \
+                }                                                                            \
+                if (W >= 2 * (Q)) min_shifted<(Q)>(xl, M, M);                                \
+            }
+            NTK_MIN_ROUND(1) NTK_MIN_ROUND(2) NTK_MIN_ROUND(4) NTK_MIN_ROUND(8) NTK_MIN_ROUND(16) NTK_MIN_ROUND(32)
+#undef NTK_MIN_ROUND
+            uint32_t vb = invw << 16;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const bool valid = !__builtin_add_overflow(vb, vb, &vb);
+                if (valid) {
+                    const uint64_t v = A[j] >> 1;
+                    sum += v; xr ^= v;
+                    n_fwd += (uint32_t)(~A[j] & 1ull);
+                    n_valid++;
+                    atomicAdd(&s_hist[(uint32_t)(v >> a.bin_shift)], 1u);
+                }
+            }
+            cur = nxt; curq = nxtq; voff += stride; tile_byte += stride;
+        }
+        next = __builtin_amdgcn_readfirstlane(next);
+    }
+    uint64_t nf = n_fwd, nv = n_valid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o, 64); xr ^= __shfl_xor(xr, o, 64); nf += __shfl_xor(nf, o, 64); nv += __shfl_xor(nv, o, 64);
+    }
+    if (lane == 0) { s_red[wave * 4 + 0] = nv; s_red[wave * 4 + 1] = nf; s_red[wave * 4 + 2] = sum; s_red[wave * 4 + 3] = xr; }
+    __syncthreads();
+    uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
+    if (threadIdx.x == 0) {
+        uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) { tv += s_red[w * 4 + 0]; tf += s_red[w * 4 + 1]; ts += s_red[w * 4 + 2]; tx ^= s_red[w * 4 + 3]; }
+        uint64_t *ps = a.part_scalars + (size_t)blockIdx.x * 4;
+        ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
+    }
+}
+
 // Sums the per-block partials into the ctx accumulators (same stream, after the scan kernel).
 // Grid: kFoldBinGroups x kFoldRowGroups blocks sum disjoint (bin range, row subset) pieces and add them with one
 // u64 atomic per bin; one extra block reduces the scalar partials.  (A single pass over <= 8 MiB, a few microseconds.)

@@ -46,6 +46,11 @@ struct ScanArgs {
     // kernel that adds this scan's partials into them runs after the scan in stream order
     uint64_t *zero_acc;
     uint32_t zero_words;
+    // generic fused windowed minimizers (minimizer_scan_kernel): window of w k-mers; the first min_halo_lanes lanes of a tile emit no
+    // window (2 lanes of k-mer halo + ceil((w - 1) / 16) lanes of k-mers that earlier windows need), the tile advances by
+    // (64 - min_halo_lanes) * 16 bytes; min_smear = doubling shifts that OR a "k-mer invalid" bit over the w window ends it is part of
+    uint32_t min_w, min_halo_lanes;
+    uint32_t min_smear[6];
 };
 
 // Fills the k-derived fields (host side).  k must be 1..32.

@@ -1187,6 +1187,56 @@ def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatc
     assert fused["n_total"] > 0
 
 
+def test_generic_fused_minimizers_any_k_w(ctx, monkeypatch):
+    """The generic fused minimizer kernel (run-time k <= 31 and w <= 49; every (k, w) without a register-fused build) against the literal
+    minimizer of every window (oracle: sequence::minimizer, reference src/sequence.rs:139-152, on each window of w + k - 1 good bases):
+    window lengths around the lane (16 / 32 / 48 positions) and the power-of-two boundaries of the sliding minimum, k on both sides of the
+    one-word / two-word values, both tie rules, ragged records, repeats (leftmost rule), with and without a quality stream; and the same
+    buffer through the two-pass path."""
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNU\n", dtype=np.uint8)
+    h = bytes(rng.choice(list(b"ACGT"), size=70).astype(np.uint8))
+    buf = bytes(alphabet[rng.integers(0, len(alphabet), 30_000)]) + h + O.reverse_complement(h) + h + b"A" * 200 + b"AC" * 100 + b"T" * 90 + \
+        O.synth_reads(0x5EED0002, 9, 1500, 150, 8).tobytes() + O.synth_reads(0x5EED0003, 0, 40, 3000, 4).tobytes()
+    t = to_dev(buf)
+    qual = bytes(rng.integers(33, 75, len(buf)).astype(np.uint8))
+    tq = to_dev(qual)
+    pairs = [(k, w) for k in (1, 4, 11, 16, 17, 23, 27, 31) for w in (1, 2, 3, 8, 13, 16, 17, 19, 31, 32, 33, 49)] + [(21, 19), (25, 11), (31, 15), (15, 25)]
+    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
+    monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
+    for i, (k, w) in enumerate(pairs):
+        path, pre, tie, u = ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False))[i & 1]
+        want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
+        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
+        assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie))
+    for k, w, cutoff in ((23, 11, 50), (31, 19, 60), (12, 33, 40)):
+        masked = O.quality_mask(buf, qual, cutoff)
+        want = O.minimizers_reduce(masked, k, w, accept_u=True, tie_rc=True)
+        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w, d_qual=tq, quality_cutoff=cutoff)
+        assert_stats_equal(ctx.accum_read(), want, ("generic fused, quality", k, w, cutoff))
+    # beyond the kernel's range (k = 32, w = 50) and with the kernel switched off: the two-pass path, same results
+    for k, w in ((32, 11), (21, 50)):
+        want = O.minimizers_reduce(buf, k, w, accept_u=False, tie_rc=False)
+        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, nt.PATH_BITS_CANONICAL, nt.PRE_NONE, w=w)
+        assert_stats_equal(ctx.accum_read(), want, ("two-pass fallback", k, w))
+    monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
+    want = O.minimizers_reduce(buf, 23, 11, accept_u=True, tie_rc=True)
+    ctx.accum_reset(); ctx.reduce_device(t, len(buf), 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
+    assert_stats_equal(ctx.accum_read(), want, "two-pass with the generic kernel off")
+    monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
+    # a 2 M-read batch: several launches' worth of tiles per wave, generic fused == two-pass
+    n_reads = 2_000_000
+    big = torch.empty(n_reads * 151 + 1024, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0002, 0, n_reads, 150, 1, big)
+    for k, w in ((23, 11), (31, 19)):
+        ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); fused = ctx.accum_read()
+        monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
+        ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); two = ctx.accum_read()
+        monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
+        assert_stats_equal(fused, two, ("2 M reads", k, w))
+        assert fused["n_total"] > 0
+
+
 def test_reset_flag_starts_a_new_result(ctx, monkeypatch):
     """NTK_FLAG_RESET (ntk_params.flags bit 16): the reduce call zeroes the accumulators inside its own launch - same result as
     ntk_accum_reset + the call, on every route that takes it (plain, quality-masked, fused and two-pass minimizers, empty input,

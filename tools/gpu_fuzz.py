@@ -141,8 +141,13 @@ def main():
                 print("MISMATCH materialize", tag); return 1
             counts["materialize"] += 1
         elif what < 8 and canon and path == nt.PATH_BYTES_CANONICAL and pre == nt.PRE_NORMALIZE:
-            w = int(rng.choice([1, 2, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
-            kk = k if rng.random() < 0.5 else int(rng.choice([15, 16, 17, 18, 19, 20, 21, 22]))
+            u4 = rng.random()
+            if u4 < 0.4:     # the register-fused grid and its edges
+                w = int(rng.choice([1, 2, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
+                kk = k if rng.random() < 0.5 else int(rng.choice([15, 16, 17, 18, 19, 20, 21, 22]))
+            else:            # anything: the generic fused kernel (k <= 31, w <= 49), the two-pass path beyond it
+                w = int(rng.integers(1, 52)) if rng.random() < 0.8 else int(rng.choice([15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 64]))
+                kk = int(rng.integers(1, 33))
             ctx.accum_reset(); ctx.reduce_device(t, n, kk, path, pre, w=w)
             if not stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, kk, w, True, True)):
                 print("MISMATCH minimizers", tag, "w", w, "kk", kk); return 1
