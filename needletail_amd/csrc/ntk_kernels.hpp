@@ -1346,23 +1346,25 @@ __global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kern
             }
             NTK_MIN_ROUND(1) NTK_MIN_ROUND(2) NTK_MIN_ROUND(4) NTK_MIN_ROUND(8) NTK_MIN_ROUND(16) NTK_MIN_ROUND(32)
 #undef NTK_MIN_ROUND
+            // the window's minimizer = key >> 1, its strand flag = key & 1.  xor and the flag count are taken on the keys (xor commutes
+            // with the shift; n_fwd = windows - flags) and the window count from the validity mask: 16 instructions per tile fewer each
             uint32_t vb = invw << 16;
+            n_valid += __popc(~invw & 0xFFFFu);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const bool valid = !__builtin_add_overflow(vb, vb, &vb);
                 if (valid) {
-                    const uint64_t v = A[j] >> 1;
-                    sum += v; xr ^= v;
-                    n_fwd += (uint32_t)(~A[j] & 1ull);
-                    n_valid++;
-                    atomicAdd(&s_hist[(uint32_t)(v >> a.bin_shift)], 1u);
+                    sum += A[j] >> 1; xr ^= A[j];
+                    n_fwd += (uint32_t)A[j] & 1u;   // counts the rc flags here
+                    atomicAdd(&s_hist[(uint32_t)(A[j] >> (a.bin_shift + 1))], 1u);
                 }
             }
             cur = nxt; curq = nxtq; voff += stride; tile_byte += stride;
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }
-    uint64_t nf = n_fwd, nv = n_valid;
+    uint64_t nf = n_valid - n_fwd, nv = n_valid;   // (n_fwd counted the rc flags)
+    xr >>= 1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         sum += __shfl_xor(sum, o, 64); xr ^= __shfl_xor(xr, o, 64); nf += __shfl_xor(nf, o, 64); nv += __shfl_xor(nv, o, 64);

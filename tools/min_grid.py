@@ -32,4 +32,4 @@ for k in range(15, 23):
         if k + w - 1 <= 32:
             run(k, w, False)
 run(21, 11, True); run(15, 10, True)
-run(23, 11, False)   # no fused build: the two-pass path, for scale
+run(23, 11, False)   # no register-fused build: the generic fused kernel (round 4; tools/min_generic_bench.py times it against the two-pass path)
