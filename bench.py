@@ -310,6 +310,14 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
             raise SystemExit("secondary: fused minimizers differ from the oracle on the prefix")
         ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)), 10)
         out["minimizers_w11_k21_resident"] = {"kernel_ms": round(ms, 4), "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
+        # a (k, w) outside the register-fused grid: the generic fused kernel (run-time k <= 31, w <= 49; one pass as well)
+        ctx.accum_reset()
+        ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 31, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=19)
+        if not stats_equal(ctx.accum_read(), O.minimizers_reduce(hs, 31, 19, True, True)):
+            raise SystemExit("secondary: generic fused minimizers differ from the oracle on the prefix")
+        ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 31, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=19)), 6)
+        out["minimizers_w19_k31_generic_resident"] = {"kernel": "minimizer_scan_kernel (any k <= 31, w <= 49)", "kernel_ms": round(ms, 4),
+                                                       "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
     except nt.NtkError as e:  # pragma: no cover
         out["minimizers_w11_k21_resident"] = {"error": str(e)}
 
