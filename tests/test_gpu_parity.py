@@ -1081,6 +1081,20 @@ def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, 
         assert allbits == tot and int(np.unpackbits((pl.rc16 & ~pl.valid16).astype(">u2").view(np.uint8)).sum()) == 0
     it = list(nt.canonical_kmers_planes(records[:8], 4, ctx).iter(4, records[4], O.reverse_complement(records[4])))
     assert it == O.canonical_kmers(records[4], O.reverse_complement(records[4]), 4)
+    # offsets need not start at 0 (a slice of a reader's buffer), and an empty batch is fine
+    import ctypes as C_
+    from needletail_amd import _lib as L_
+    flat = b"ACGTN" + b"".join(records[:40])
+    offs2 = np.zeros(41, dtype=np.uint64); np.cumsum([len(r) for r in records[:40]], out=offs2[1:]); offs2 += 5
+    capw = int(offs2[-1] - offs2[0]) // 16 + 41
+    rb2 = np.zeros(41, dtype=np.uint64); v2 = np.zeros(capw, dtype=np.uint16); r2 = np.zeros(capw, dtype=np.uint16)
+    nw2, tt2 = C_.c_uint64(0), C_.c_uint64(0)
+    L_.check(L_.lib().ntk_canonical_kmers_batch_planes(ctx._h, flat, offs2.ctypes.data, 40, 21, rb2.ctypes.data, v2.ctypes.data, r2.ctypes.data, capw,
+                                                      C_.byref(nw2), C_.byref(tt2)), "planes with offsets[0] = 5")
+    ref = nt.canonical_kmers_planes(records[:40], 21, ctx)
+    assert tt2.value == ref.total and np.array_equal(v2[: nw2.value], ref.valid16) and np.array_equal(r2[: nw2.value], ref.rc16) and np.array_equal(rb2, ref.rec_bit)
+    e = nt.canonical_kmers_planes([], 21, ctx)
+    assert e.total == 0 and len(e.valid16) == 0
     # capacity protocol: too small a buffer reports the needed count and fills what fits
     import ctypes as C
     from needletail_amd import _lib as L
