@@ -841,9 +841,14 @@ def test_minimizers_in_chunks(monkeypatch):
         t = to_dev(buf)
         for k, w in ((21, 11), (31, 2), (17, 16), (5, 64), (12, 256), (32, 1)):
             for path, accept_u, tie_rc in ((nt.PATH_BYTES_CANONICAL, True, True), (nt.PATH_BITS_CANONICAL, False, False)):
-                c.accum_reset()
-                c.minimizers_reduce_device(t, len(buf), k, w, path, nt.PRE_NORMALIZE if accept_u else nt.PRE_NONE)
-                assert_stats_equal(c.accum_read(), O.minimizers_reduce(buf, k, w, accept_u, tie_rc), (k, w, "chunked"))
+                want = O.minimizers_reduce(buf, k, w, accept_u, tie_rc)
+                for two_pass in (False, True):   # the default route (a fused kernel where one serves the pair), then the chunked two-pass path
+                    if two_pass:
+                        monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1"); monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
+                    c.accum_reset()
+                    c.minimizers_reduce_device(t, len(buf), k, w, path, nt.PRE_NORMALIZE if accept_u else nt.PRE_NONE)
+                    assert_stats_equal(c.accum_read(), want, (k, w, "chunked two-pass" if two_pass else "default route"))
+                    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False); monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
 
 
 def test_compressed_inputs_through_the_pipeline(ctx, golden_dir, tmp_path):
