@@ -31,6 +31,7 @@ if [ -x tools/kb_s2_hb14 ]; then   # tools/build_kbench.sh; 2 x 768 threads per 
 fi
 python tools/path_sweep.py 1,4,6,8,11,15,16,17,19,21,22,23,24,27,31,32 > $O/path_sweep.txt 2>&1
 python tools/min_grid.py > $O/min_grid.txt 2>&1
+python tools/min_generic_bench.py 2>&1 | grep "k=" > $O/min_generic.txt
 bash tools/path_pmc.sh $TAG > /dev/null 2>&1
 python tools/compat_bench.py > $O/compat_bench.txt 2>&1
 python tools/compat_planes_bench.py >> $O/compat_bench.txt 2>&1
