@@ -1063,6 +1063,10 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
             mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
             after_encode();
+#ifdef NTK_SCHED_ALT   // round-4 experiment: ask the scheduler to deal the scalar mask algebra out among the vector ops, one by one
+#pragma unroll
+            for (int i = 0; i < NTK_SCHED_ALT; i++) { __builtin_amdgcn_sched_group_barrier(0x2, 1, 0); __builtin_amdgcn_sched_group_barrier(0x4, 1, 0); }
+#endif
             if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
