@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneedletail_amd.so")
+LIB_PATH = os.environ.get("NEEDLETAIL_AMD_LIB") or os.path.join(_HERE, "libneedletail_amd.so")   # (the override: A/B builds, tools/)
 
 NTK_OK = 0
 PATH_BYTES_CANONICAL, PATH_BITS, PATH_BITS_CANONICAL = 0, 1, 2

@@ -366,11 +366,13 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
 
 // Generic fused windowed minimizers (ntk_kernels.hpp minimizer_scan_kernel): any k <= 31 and w <= 49 of the canonical paths, with or
 // without a quality stream; the tile geometry depends on w (2 + ceil((w - 1) / 16) non-emitting lanes).
-const void *pick_min_generic(const Mode &m, bool quality)
+const void *pick_min_generic(const Mode &m, bool quality, bool f64)   // f64: k <= 25 (one v_min_f64 per minimum, ntk_kernels.hpp)
 {
-#define NTK_PICK_MG(KW, T, U, Q) if (m.kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q) return (const void *)&minimizer_scan_kernel<KW, T, U, Q>;
-#define NTK_PICK_MG4(KW, Q) NTK_PICK_MG(KW, false, false, Q) NTK_PICK_MG(KW, false, true, Q) NTK_PICK_MG(KW, true, false, Q) NTK_PICK_MG(KW, true, true, Q)
-    NTK_PICK_MG4(1, false) NTK_PICK_MG4(2, false) NTK_PICK_MG4(1, true) NTK_PICK_MG4(2, true)
+#define NTK_PICK_MG(KW, T, U, Q, F) if (m.kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q && f64 == F) return (const void *)&minimizer_scan_kernel<KW, T, U, Q, F>;
+#define NTK_PICK_MG4(KW, Q, F) NTK_PICK_MG(KW, false, false, Q, F) NTK_PICK_MG(KW, false, true, Q, F) NTK_PICK_MG(KW, true, false, Q, F) NTK_PICK_MG(KW, true, true, Q, F)
+    NTK_PICK_MG4(1, false, true) NTK_PICK_MG4(2, false, true) NTK_PICK_MG4(1, true, true) NTK_PICK_MG4(2, true, true)
+    NTK_PICK_MG4(2, false, false) NTK_PICK_MG4(2, true, false)   // 26 <= k <= 31
+    NTK_PICK_MG4(1, false, false) NTK_PICK_MG4(1, true, false)   // (only under NTK_MINGEN_NO_F64, the A/B switch)
 #undef NTK_PICK_MG4
 #undef NTK_PICK_MG
     return nullptr;
@@ -380,7 +382,7 @@ int run_min_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params 
 {
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;
-    const void *fn = pick_min_generic(m, cutoff != 0);
+    const void *fn = pick_min_generic(m, cutoff != 0, p->k <= 25 && !getenv("NTK_MINGEN_NO_F64"));
     if (!fn) return NTK_ERR_BAD_ARG;
     const int threads = 256;
     int per_cu = 0;
@@ -1407,7 +1409,8 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     // fused build (one pass, nothing written to HBM) where one exists - with a quality stream: the quality-masked builds
     if (n && !getenv("NTK_MINIMIZERS_TWO_PASS")) {
         const bool masked = d_qual && quality_cutoff(p);
-        if (const void *fn = pick_scan_min(m, p->k, w, masked))
+        const void *fn = getenv("NTK_MINIMIZERS_NO_REGFUSED") ? nullptr : pick_scan_min(m, p->k, w, masked);   // (A/B switch)
+        if (fn)
             return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, masked ? d_qual : nullptr, fn);
         // every other (k <= 31, w <= 49): the generic fused kernel (one pass as well, run-time k and w)
         if (p->k <= 31 && w <= 49 && !getenv("NTK_MINIMIZERS_NO_GENERIC"))

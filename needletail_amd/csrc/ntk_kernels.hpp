@@ -1191,32 +1191,51 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 // Tile geometry at run time: ScanArgs::min_halo_lanes non-emitting lanes, stride (64 - that) * 16 bytes.
 // ---------------------------------------------------------------------------------------------
 #ifndef NTK_MINGEN_MINBLOCKS
-// 256-thread blocks per CU the register allocation has to allow.  1 = no constraint: 164 VGPRs, 3 waves per SIMD, (23, 11) 2.2 ms per
-// config-2 batch; 4 (<= 128 VGPRs, ~35 dwords spilled): 4.9 ms; 5 (<= 96, ~70 spilled): 16.7 ms (profiles/r04d/min_generic.txt)
+// 256-thread blocks per CU the register allocation has to allow, general keys (26 <= k <= 31).  1 = no constraint: 164 VGPRs, 3 waves per
+// SIMD; 4 (<= 128 VGPRs) and 5 spill inside the tile loop there (4.9 / 16.7 ms per config-2 batch against 2.2).
 #define NTK_MINGEN_MINBLOCKS 1
 #endif
-template <int KW>
+#ifndef NTK_MINGEN_MINBLOCKS_F64
+// ... and with the v_min_f64 keys (k <= 25): 148 VGPRs unconstrained; 4 blocks fit in 128 without scratch but run 5 % SLOWER
+// ((23, 11) 1.87 against 1.77 ms, profiles/r04f), 5 spill
+#define NTK_MINGEN_MINBLOCKS_F64 1
+#endif
+// F64 (k <= 25): key = bit 62 | value << 11 | (tile position x = 16 * lane + j) << 1 | strand flag - unique per position and ordered by
+// (value, position), bit 61 clear: a positive NORMAL double whose order is its bit pattern's, so ONE v_min_f64 is the leftmost minimum
+// (the general form below needs v_or + v_mov + v_cmp_gt_u64 + two v_cndmask per minimum: the compiler has to build the pair (r | 1)).
+template <int KW, bool F64>
 struct MinimizerSinkG {
     uint64_t key[16];
-    uint32_t inval = 0;
+    uint32_t inval = 0, lane16 = 0;   // lane16 = 16 * lane
     int64_t base = 0;
     __device__ __forceinline__ void begin_tile(int64_t lane_base, uint32_t inval16, bool) { base = lane_base; inval = inval16; }
     __device__ __forceinline__ void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
     {
         const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
-        key[j] = (v << 1) | (take_fwd ? 0u : 1u);
+        if constexpr (F64) key[j] = (1ull << 62) | (v << 11) | ((uint64_t)(lane16 + (uint32_t)j) << 1) | (take_fwd ? 0u : 1u);
+        else key[j] = (v << 1) | (take_fwd ? 0u : 1u);
     }
     __device__ __forceinline__ void end_tile() {}
 };
 
-__device__ __forceinline__ uint64_t min_left(uint64_t l, uint64_t r) { return l <= (r | 1ull) ? l : r; }
+template <bool F64>
+__device__ __forceinline__ uint64_t min_left(uint64_t l, uint64_t r)
+{
+    if constexpr (F64) {
+        uint64_t m;
+        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(l), "v"(r));
+        return m;
+    } else {
+        return l <= (r | 1ull) ? l : r;
+    }
+}
 __device__ __forceinline__ uint64_t prev_lane64(const DevXL &xl, uint64_t v)
 {
     return ((uint64_t)xl.prev(0, (uint32_t)(v >> 32)) << 32) | xl.prev(0, (uint32_t)v);
 }
 // X[x] <- min_left(Y[x - Q], X[x]) for the 16 own positions; Y may be X itself (doubling).  In place, descending j; the words that come
 // from the previous lane(s) are fetched first.
-template <int Q>
+template <int Q, bool F64>
 __device__ __forceinline__ void min_shifted(const DevXL &xl, uint64_t (&X)[16], const uint64_t (&Y)[16])
 {
     if constexpr (Q < 16) {
@@ -1224,7 +1243,7 @@ __device__ __forceinline__ void min_shifted(const DevXL &xl, uint64_t (&X)[16], 
 #pragma unroll
         for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, Y[16 + j - Q]);
 #pragma unroll
-        for (int j = 15; j >= 0; j--) X[j] = min_left(j >= Q ? Y[j - Q] : imp[j], X[j]);
+        for (int j = 15; j >= 0; j--) X[j] = min_left<F64>(j >= Q ? Y[j - Q] : imp[j], X[j]);
     } else {
 #pragma unroll
         for (int h = 0; h < 2; h++) {   // eight at a time: 16 more live registers instead of 32
@@ -1235,13 +1254,13 @@ __device__ __forceinline__ void min_shifted(const DevXL &xl, uint64_t (&X)[16], 
                 if constexpr (Q == 32) imp[j] = prev_lane64(xl, imp[j]);
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) X[8 * h + j] = min_left(imp[j], X[8 * h + j]);
+            for (int j = 0; j < 8; j++) X[8 * h + j] = min_left<F64>(imp[j], X[8 * h + j]);
         }
     }
 }
 
-// A[x] <- min_left(A[x - Q], R[x])  (the partial window grows to the left by the Q positions of R's span)
-template <int Q>
+// A[x] <- min_left<F64>(A[x - Q], R[x])  (the partial window grows to the left by the Q positions of R's span)
+template <int Q, bool F64>
 __device__ __forceinline__ void min_shifted_into(const DevXL &xl, uint64_t (&A)[16], const uint64_t (&R)[16])
 {
     if constexpr (Q < 16) {
@@ -1249,7 +1268,7 @@ __device__ __forceinline__ void min_shifted_into(const DevXL &xl, uint64_t (&A)[
 #pragma unroll
         for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, A[16 + j - Q]);
 #pragma unroll
-        for (int j = 15; j >= 0; j--) A[j] = min_left(j >= Q ? A[j - Q] : imp[j], R[j]);
+        for (int j = 15; j >= 0; j--) A[j] = min_left<F64>(j >= Q ? A[j - Q] : imp[j], R[j]);
     } else {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -1260,13 +1279,13 @@ __device__ __forceinline__ void min_shifted_into(const DevXL &xl, uint64_t (&A)[
                 if constexpr (Q == 32) imp[j] = prev_lane64(xl, imp[j]);
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) A[8 * h + j] = min_left(imp[j], R[8 * h + j]);
+            for (int j = 0; j < 8; j++) A[8 * h + j] = min_left<F64>(imp[j], R[8 * h + j]);
         }
     }
 }
 
-template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM>
-__global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kernel(ScanArgs a)
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM, bool F64>
+__global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MINBLOCKS) void minimizer_scan_kernel(ScanArgs a)
 {
     __shared__ uint32_t s_hist[kHistBins];
     __shared__ uint64_t s_red[4 * 4];
@@ -1285,9 +1304,11 @@ __global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kern
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
     const uint32_t W = a.min_w, HL = a.min_halo_lanes, stride = (64u - HL) * 16u, halo_bytes = HL * 16u;
     DevXL xl;
-    MinimizerSinkG<KW> sink;
+    MinimizerSinkG<KW, F64> sink;
+    sink.lane16 = lane * 16u;
     uint64_t sum = 0, xr = 0;
     uint32_t n_fwd = 0, n_valid = 0;
+    const uint32_t hist_shift = a.bin_shift + 11 - 2;   // (F64 keys: the bin's BYTE offset - the value's top bits, bit 62 masked off with the bins)
 
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
@@ -1342,11 +1363,11 @@ __global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kern
 #define NTK_MIN_ROUND(Q)                                                                     \
             if (W >= (Q)) {                                                                  \
                 if (W & (Q)) {                                                               \
-                    if (have_a) min_shifted_into<(Q)>(xl, A, M);                             \
+                    if (have_a) min_shifted_into<(Q), F64>(xl, A, M);                        \
                     else { _Pragma("unroll") for (int j = 0; j < 16; j++) A[j] = M[j]; }     \
                     have_a = true;                                                           \
                 }                                                                            \
-                if (W >= 2 * (Q)) min_shifted<(Q)>(xl, M, M);                                \
+                if (W >= 2 * (Q)) min_shifted<(Q), F64>(xl, M, M);                           \
             }
             NTK_MIN_ROUND(1) NTK_MIN_ROUND(2) NTK_MIN_ROUND(4) NTK_MIN_ROUND(8) NTK_MIN_ROUND(16) NTK_MIN_ROUND(32)
 #undef NTK_MIN_ROUND
@@ -1358,9 +1379,14 @@ __global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kern
             for (int j = 0; j < 16; j++) {
                 const bool valid = !__builtin_add_overflow(vb, vb, &vb);
                 if (valid) {
-                    sum += A[j] >> 1; xr ^= A[j];
                     n_fwd += (uint32_t)A[j] & 1u;   // counts the rc flags here
-                    atomicAdd(&s_hist[(uint32_t)(A[j] >> (a.bin_shift + 1))], 1u);
+                    if constexpr (F64) {   // raw keys: bit 62 and the low 11 bits are taken out of sum / xor after the loop
+                        sum += A[j] >> 11; xr ^= A[j];
+                        atomicAdd((uint32_t *)((char *)s_hist + ((uint32_t)(A[j] >> hist_shift) & (uint32_t)(4 * kHistBins - 4))), 1u);
+                    } else {
+                        sum += A[j] >> 1; xr ^= A[j];
+                        atomicAdd(&s_hist[(uint32_t)(A[j] >> (a.bin_shift + 1))], 1u);
+                    }
                 }
             }
             cur = nxt; curq = nxtq; voff += stride; tile_byte += stride;
@@ -1368,7 +1394,8 @@ __global__ __launch_bounds__(256, NTK_MINGEN_MINBLOCKS) void minimizer_scan_kern
         next = __builtin_amdgcn_readfirstlane(next);
     }
     uint64_t nf = n_valid - n_fwd, nv = n_valid;   // (n_fwd counted the rc flags)
-    xr >>= 1;
+    if constexpr (F64) { sum -= (uint64_t)n_valid << 51; xr = (xr >> 11) & ((1ull << 51) - 1); }
+    else xr >>= 1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         sum += __shfl_xor(sum, o, 64); xr ^= __shfl_xor(xr, o, 64); nf += __shfl_xor(nf, o, 64); nv += __shfl_xor(nv, o, 64);

@@ -1228,6 +1228,18 @@ def test_generic_fused_minimizers_any_k_w(ctx, monkeypatch):
         want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
         ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
         assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie))
+    # k = 25 / 26: the last k of the v_min_f64 keys (value << 11 | position | strand) and the first of the general keys; the general keys
+    # below 26 as well (NTK_MINGEN_NO_F64), and the generic kernel on pairs that have a register-fused build (NTK_MINIMIZERS_NO_REGFUSED)
+    for k, w, env in ((24, 7, None), (25, 49, None), (26, 49, None), (25, 12, None), (26, 12, None), (25, 33, "NTK_MINGEN_NO_F64"), (16, 20, "NTK_MINGEN_NO_F64"),
+                      (9, 5, "NTK_MINGEN_NO_F64"), (21, 11, "NTK_MINIMIZERS_NO_REGFUSED"), (17, 16, "NTK_MINIMIZERS_NO_REGFUSED")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
+            want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
+            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
+            assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie, env))
+        if env:
+            monkeypatch.delenv(env)
     for k, w, cutoff in ((23, 11, 50), (31, 19, 60), (12, 33, 40)):
         masked = O.quality_mask(buf, qual, cutoff)
         want = O.minimizers_reduce(masked, k, w, accept_u=True, tie_rc=True)

@@ -30,9 +30,9 @@ for k, w in pairs:
     ms, r = run(k, w)
     line = f"k={k:2d} w={w:2d}: default path {ms:7.3f} ms = {reads * L / ms / 1e6:7.1f} Gbases/s"
     if (k, w) == (21, 11):
-        os.environ["NTK_MINIMIZERS_TWO_PASS"] = "1"     # skip the register-fused build: the generic kernel on a pair that has one
+        os.environ["NTK_MINIMIZERS_NO_REGFUSED"] = "1"     # skip the register-fused build: the generic kernel on a pair that has one
         ms_g, r_g = run(k, w)
-        os.environ.pop("NTK_MINIMIZERS_TWO_PASS")
+        os.environ.pop("NTK_MINIMIZERS_NO_REGFUSED")
         assert all(r[x] == r_g[x] for x in ("n_total", "n_fwd", "sum", "xor"))
         line += f"   generic kernel on the same pair {ms_g:7.3f} ms"
     os.environ["NTK_MINIMIZERS_NO_GENERIC"] = "1"
