@@ -316,8 +316,15 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
         if not stats_equal(ctx.accum_read(), O.minimizers_reduce(hs, 31, 19, True, True)):
             raise SystemExit("secondary: generic fused minimizers differ from the oracle on the prefix")
         ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 31, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=19)), 6)
-        out["minimizers_w19_k31_generic_resident"] = {"kernel": "minimizer_scan_kernel (any k <= 31, w <= 49)", "kernel_ms": round(ms, 4),
-                                                       "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
+        out["minimizers_w19_k31_generic_resident"] = {"kernel": "minimizer_scan_kernel (any k <= 31, w <= 49; 26 <= k: keys value << 1 | strand)",
+                                                       "kernel_ms": round(ms, 4), "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
+        ctx.accum_reset()
+        ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
+        if not stats_equal(ctx.accum_read(), O.minimizers_reduce(hs, 23, 11, True, True)):
+            raise SystemExit("secondary: generic fused minimizers (k = 23) differ from the oracle on the prefix")
+        ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)), 6)
+        out["minimizers_w11_k23_generic_resident"] = {"kernel": "minimizer_scan_kernel (k <= 25: one v_min_f64 per minimum on (value, position, strand) keys)",
+                                                       "kernel_ms": round(ms, 4), "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
     except nt.NtkError as e:  # pragma: no cover
         out["minimizers_w11_k21_resident"] = {"error": str(e)}
 

@@ -1175,12 +1175,12 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #ifndef NTK_SCAN_TEMPLATES_ONLY   // ntk_scan2.hip instantiates scan2_kernel only; the plain kernels below belong to ntk_api.hip
 // ---------------------------------------------------------------------------------------------
 // Generic fused windowed minimizers (round 4): ANY (k <= 31, w <= 49) of the canonical paths in one pass, nothing written to HBM -
-// what every (k, w) without a register-fused scan2 build ran as materialise + window-min (8.8 ms per 1.5 Gbases, profiles/r04d).
+// what every (k, w) without a register-fused scan2 build ran as materialise + window-min (8.8 ms per 1.5 Gbases, profiles/r04f).
 // Semantics as lane_tile_sv2_min / window_min_reduce_kernel (reference sequence::minimizer, src/sequence.rs:139-152, applied to every
 // window of w + k - 1 good bases): the window ending at byte e holds the w k-mers ending at e-w+1 .. e; its minimizer is the smallest
 // canonical value, the LEFTMOST on ties, reported with that k-mer's strand flag.
 //   * k-mers: the run-time-k tile logic of the round-1 kernel (lane_tile: value, "window of k contains a break" bit, strand per position).
-//   * key = (value << 1) | strand flag.  A minimum that prefers its LEFT operand on ties and ignores the strand bit:
+//   * key (26 <= k; k <= 25: the F64 form at MinimizerSinkG) = (value << 1) | strand flag.  A minimum that prefers its LEFT operand on ties and ignores the strand bit:
 //         take L  <=>  key_L <= (key_R | 1)          (floor(key_L / 2) <= floor(key_R / 2))
 //   * sliding minimum over w for any run-time w, positions x = 16 * lane + j of the wave's tile, by binary decomposition with FIXED shifts:
 //         M_1 = key;  M_2q[x] = min(M_q[x - q], M_q[x]);      A (length a, the low bits of w so far):  A'[x] = min(A[x - q], M_q[x])  if bit q of w
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 // Tile geometry at run time: ScanArgs::min_halo_lanes non-emitting lanes, stride (64 - that) * 16 bytes.
 // ---------------------------------------------------------------------------------------------
 #ifndef NTK_MINGEN_MINBLOCKS
-// 256-thread blocks per CU the register allocation has to allow, general keys (26 <= k <= 31).  1 = no constraint: 164 VGPRs, 3 waves per
+// 256-thread blocks per CU the register allocation has to allow, general keys (26 <= k <= 31).  1 = no constraint: 134-138 VGPRs, 3 waves per
 // SIMD; 4 (<= 128 VGPRs) and 5 spill inside the tile loop there (4.9 / 16.7 ms per config-2 batch against 2.2).
 #define NTK_MINGEN_MINBLOCKS 1
 #endif
