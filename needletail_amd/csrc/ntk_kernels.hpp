@@ -1284,6 +1284,20 @@ __device__ __forceinline__ void min_shifted_into(const DevXL &xl, uint64_t (&A)[
     }
 }
 
+// A[x] <- min_left(M[x - S], M[x]) for ANY shift 0 < S <= 31: two overlapping windows of M's span cover span + S positions
+template <int S, bool F64>
+__device__ __forceinline__ void min_overlap(const DevXL &xl, uint64_t (&A)[16], const uint64_t (&M)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint64_t l;
+        if (j >= S) l = M[j - S];
+        else if (j - S + 16 >= 0) l = prev_lane64(xl, M[j - S + 16]);
+        else l = prev_lane64(xl, prev_lane64(xl, M[j - S + 32]));
+        A[j] = min_left<F64>(l, M[j]);
+    }
+}
+
 template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM, bool F64>
 __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MINBLOCKS) void minimizer_scan_kernel(ScanArgs a)
 {
@@ -1356,9 +1370,10 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
 #pragma unroll
             for (int i = 0; i < 6; i++) bw |= bw >> a.min_smear[i];
             const uint32_t invw = lane < HL ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
-            // sliding minimum over W (see above): M doubles, A collects the set bits of W from the low end
+            // sliding minimum over W (see above): M doubles while 2q <= W, then two overlapping windows of q make W
             uint64_t (&M)[16] = sink.key;
             uint64_t A[16];
+#ifdef NTK_MINGEN_BINARY   // (the first version, A/B: A collects the set bits of W from the low end - popcount(W) - 1 more array minima)
             bool have_a = false;   // wave-uniform: A holds a partial window already
 #define NTK_MIN_ROUND(Q)                                                                     \
             if (W >= (Q)) {                                                                  \
@@ -1371,6 +1386,21 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
             }
             NTK_MIN_ROUND(1) NTK_MIN_ROUND(2) NTK_MIN_ROUND(4) NTK_MIN_ROUND(8) NTK_MIN_ROUND(16) NTK_MIN_ROUND(32)
 #undef NTK_MIN_ROUND
+#else
+            if (W >= 2) min_shifted<1, F64>(xl, M, M);
+            if (W >= 4) min_shifted<2, F64>(xl, M, M);
+            if (W >= 8) min_shifted<4, F64>(xl, M, M);
+            if (W >= 16) min_shifted<8, F64>(xl, M, M);
+            if (W >= 32) min_shifted<16, F64>(xl, M, M);
+            switch (a.min_overlap) {   // W - (M's span): 0 .. 17 for W <= 49
+#define NTK_MIN_CASE(S) case S: min_overlap<S, F64>(xl, A, M); break;
+                NTK_MIN_CASE(1) NTK_MIN_CASE(2) NTK_MIN_CASE(3) NTK_MIN_CASE(4) NTK_MIN_CASE(5) NTK_MIN_CASE(6) NTK_MIN_CASE(7) NTK_MIN_CASE(8)
+                NTK_MIN_CASE(9) NTK_MIN_CASE(10) NTK_MIN_CASE(11) NTK_MIN_CASE(12) NTK_MIN_CASE(13) NTK_MIN_CASE(14) NTK_MIN_CASE(15)
+                NTK_MIN_CASE(16) NTK_MIN_CASE(17)
+#undef NTK_MIN_CASE
+                default: _Pragma("unroll") for (int j = 0; j < 16; j++) A[j] = M[j];
+            }
+#endif
             // the window's minimizer = key >> 1, its strand flag = key & 1.  xor and the flag count are taken on the keys (xor commutes
             // with the shift; n_fwd = windows - flags) and the window count from the validity mask: 16 instructions per tile fewer each
             uint32_t vb = invw << 16;

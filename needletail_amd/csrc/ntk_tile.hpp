@@ -51,6 +51,7 @@ struct ScanArgs {
     // (64 - min_halo_lanes) * 16 bytes; min_smear = doubling shifts that OR a "k-mer invalid" bit over the w window ends it is part of
     uint32_t min_w, min_halo_lanes;
     uint32_t min_smear[6];
+    uint32_t min_overlap;    // w - 2^floor(log2 w): the shift between the two overlapping power-of-two windows that make a window of w
 };
 
 // Fills the k-derived fields (host side).  k must be 1..32.
