@@ -1182,22 +1182,22 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 //   * k-mers: the run-time-k tile logic of the round-1 kernel (lane_tile: value, "window of k contains a break" bit, strand per position).
 //   * key (26 <= k; k <= 25: the F64 form at MinimizerSinkG) = (value << 1) | strand flag.  A minimum that prefers its LEFT operand on ties and ignores the strand bit:
 //         take L  <=>  key_L <= (key_R | 1)          (floor(key_L / 2) <= floor(key_R / 2))
-//   * sliding minimum over w for any run-time w, positions x = 16 * lane + j of the wave's tile, by binary decomposition with FIXED shifts:
-//         M_1 = key;  M_2q[x] = min(M_q[x - q], M_q[x]);      A (length a, the low bits of w so far):  A'[x] = min(A[x - q], M_q[x])  if bit q of w
-//     a shift by q < 16 reads own registers (j >= q) or the previous lane's (DPP wave_shr:1, q imports of two registers), q = 16 / 32 the
-//     previous lane's / the lane before that; everything is unrolled over j and the six possible q, the branches on w are wave-uniform.
+//   * sliding minimum over w for any run-time w, positions x = 16 * lane + j of the wave's tile, with FIXED shifts: doubling
+//         M_1 = key;  M_2q[x] = min(M_q[x - q], M_q[x])  while 2q <= w;      window[x] = min(M_q[x - (w - q)], M_q[x])
+//     (two overlapping windows of q make w: ceil(log2 w) array minima).  A shift by s < 16 reads own registers (j >= s) or the previous
+//     lane's (DPP wave_shr:1, s imports of two registers), 16 <= s < 32 the previous lane's / the lane before that; the doubling rounds sit
+//     behind wave-uniform branches on w, the last step is a switch over the shift (ScanArgs::min_overlap, 0..17).
 //   * window validity: the k-mer invalid bits of the lane and of the three lanes before it, OR-smeared over the w window ends each k-mer
 //     is part of (w <= 49 keeps that in 64 bits).
 // Tile geometry at run time: ScanArgs::min_halo_lanes non-emitting lanes, stride (64 - that) * 16 bytes.
 // ---------------------------------------------------------------------------------------------
 #ifndef NTK_MINGEN_MINBLOCKS
-// 256-thread blocks per CU the register allocation has to allow, general keys (26 <= k <= 31).  1 = no constraint: 134-138 VGPRs, 3 waves per
-// SIMD; 4 (<= 128 VGPRs) and 5 spill inside the tile loop there (4.9 / 16.7 ms per config-2 batch against 2.2).
+// 256-thread blocks per CU the register allocation has to allow, general keys (26 <= k <= 31).  1 = no constraint: 102 VGPRs, 4 waves per SIMD
 #define NTK_MINGEN_MINBLOCKS 1
 #endif
 #ifndef NTK_MINGEN_MINBLOCKS_F64
-// ... and with the v_min_f64 keys (k <= 25): 148 VGPRs unconstrained; 4 blocks fit in 128 without scratch but run 5 % SLOWER
-// ((23, 11) 1.87 against 1.77 ms, profiles/r04f), 5 spill
+// ... and with the v_min_f64 keys (k <= 25): 116 VGPRs unconstrained = 4 waves per SIMD; 5 blocks fit in 96 without scratch and change
+// nothing ((23, 11) 1.50 against 1.49 ms, profiles/r04f/min_generic_5blocks.txt)
 #define NTK_MINGEN_MINBLOCKS_F64 1
 #endif
 // F64 (k <= 25): key = bit 62 | value << 11 | (tile position x = 16 * lane + j) << 1 | strand flag - unique per position and ordered by
