@@ -92,6 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--minimizers-only", action="store_true", help="windowed minimizers only, byte path (ties -> rc, U) and bit path (ties -> fwd)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
@@ -111,6 +112,9 @@ def main():
             t[:n] = torch.from_numpy(a).cuda()
         buf = a.tobytes()
         what = rng.integers(0, 10)
+        if args.minimizers_only:
+            what = 6
+            path, pre, canon, tie, u = MODES[int(rng.integers(0, 2))]
         # launch geometry: mostly the library's choice, sometimes forced (few / many blocks, small / large blocks: the shard, chunk
         # and work-counter arithmetic of the scan must not depend on it)
         if rng.random() < 0.3:
@@ -140,7 +144,7 @@ def main():
                     and got_xor == int(want["xor"])):
                 print("MISMATCH materialize", tag); return 1
             counts["materialize"] += 1
-        elif what < 8 and canon and path == nt.PATH_BYTES_CANONICAL and pre == nt.PRE_NORMALIZE:
+        elif what < 8 and canon and (path, pre) in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE)):
             u4 = rng.random()
             if u4 < 0.4:     # the register-fused grid and its edges
                 w = int(rng.choice([1, 2, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
@@ -149,7 +153,7 @@ def main():
                 w = int(rng.integers(1, 52)) if rng.random() < 0.8 else int(rng.choice([15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 64]))
                 kk = int(rng.integers(1, 33))
             ctx.accum_reset(); ctx.reduce_device(t, n, kk, path, pre, w=w)
-            if not stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, kk, w, True, True)):
+            if not stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, kk, w, accept_u=u, tie_rc=tie)):
                 print("MISMATCH minimizers", tag, "w", w, "kk", kk); return 1
             counts["minimizers"] += 1
         elif what < 9:
