@@ -14,7 +14,8 @@ for path, pre, ks in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, (4, 11, 16, 21
             ctx.reduce_device(seq, n, k, path, pre, reset=True)
 for _ in range(4):
     ctx.reduce_device(seq, n, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, d_qual=qual, quality_cutoff=35, reset=True)
-for k, w in ((21, 11), (15, 10)):
+# (23, 11) / (31, 11): the generic fused minimizer kernel, f64 keys / general keys (two instantiations, w = 11: 61 emitting lanes per tile)
+for k, w in ((21, 11), (15, 10), (23, 11), (31, 11)):
     for _ in range(4):
         ctx.reduce_device(seq, n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w, reset=True)
 torch.cuda.synchronize()
