@@ -401,13 +401,7 @@ int run_min_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params 
     scan_args_set_k(a, p->k);
     a.seq = d_seq; a.n_bytes = n;
     if (cutoff) { const QualityCut qc = quality_cut(cutoff); a.qual = d_qual; a.q_add = qc.add; a.q_sel = qc.sel; }
-    a.min_w = w;
-    a.min_halo_lanes = (uint32_t)kHaloLanes + (w - 1 + 15) / 16;
-    { uint32_t q = 1; while (2 * q <= w) q *= 2; a.min_overlap = w - q; }
-    {   // a k-mer invalid bit is OR-ed over the w window ends that contain the k-mer: doubling shifts that add up to w - 1
-        uint32_t len = 1;
-        for (int i = 0; i < 6; i++) { const uint32_t sft = len < w ? (len < w - len ? len : w - len) : 0; a.min_smear[i] = sft; len += sft; }
-    }
+    scan_args_set_window(a, w);   // halo lanes, the validity smear, the overlap of the two power-of-two windows (ntk_tile.hpp)
     const uint64_t slots = 64 - a.min_halo_lanes, stride = slots * 16;
     a.n_tiles = ((n + 15) / 16 + slots - 1) / slots;
     bool zero_first = (p->flags & NTK_FLAG_RESET) != 0;

@@ -23,6 +23,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kDppWaveShr1 = 0x138;
 struct DevXL {
     __device__ __forceinline__ uint32_t prev_and(int s, uint32_t x, uint32_t mask) const { return prev(s, x) & mask; }
+    __device__ __forceinline__ uint32_t prev_auto(uint32_t x) const { return prev(0, x); }   // (the host emulation numbers these call sites itself)
     __device__ __forceinline__ uint32_t prev(int, uint32_t x) const
     {
 #ifdef NTK_XL_BPERMUTE   // experiment: the cross-lane move on the LDS pipe (ds_bpermute_b32) instead of the VALU (lane 0 gets lane 63's value: a halo lane)
@@ -1200,104 +1201,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 // nothing ((23, 11) 1.50 against 1.49 ms, profiles/r04f/min_generic_5blocks.txt)
 #define NTK_MINGEN_MINBLOCKS_F64 1
 #endif
-// F64 (k <= 25): key = bit 62 | value << 11 | (tile position x = 16 * lane + j) << 1 | strand flag - unique per position and ordered by
-// (value, position), bit 61 clear: a positive NORMAL double whose order is its bit pattern's, so ONE v_min_f64 is the leftmost minimum
-// (the general form below needs v_or + v_mov + v_cmp_gt_u64 + two v_cndmask per minimum: the compiler has to build the pair (r | 1)).
-template <int KW, bool F64>
-struct MinimizerSinkG {
-    uint64_t key[16];
-    uint32_t inval = 0, lane16 = 0;   // lane16 = 16 * lane
-    int64_t base = 0;
-    __device__ __forceinline__ void begin_tile(int64_t lane_base, uint32_t inval16, bool) { base = lane_base; inval = inval16; }
-    __device__ __forceinline__ void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
-    {
-        const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
-        if constexpr (F64) key[j] = (1ull << 62) | (v << 11) | ((uint64_t)(lane16 + (uint32_t)j) << 1) | (take_fwd ? 0u : 1u);
-        else key[j] = (v << 1) | (take_fwd ? 0u : 1u);
-    }
-    __device__ __forceinline__ void end_tile() {}
-};
-
-template <bool F64>
-__device__ __forceinline__ uint64_t min_left(uint64_t l, uint64_t r)
-{
-    if constexpr (F64) {
-        uint64_t m;
-        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(l), "v"(r));
-        return m;
-    } else {
-        return l <= (r | 1ull) ? l : r;
-    }
-}
-__device__ __forceinline__ uint64_t prev_lane64(const DevXL &xl, uint64_t v)
-{
-    return ((uint64_t)xl.prev(0, (uint32_t)(v >> 32)) << 32) | xl.prev(0, (uint32_t)v);
-}
-// X[x] <- min_left(Y[x - Q], X[x]) for the 16 own positions; Y may be X itself (doubling).  In place, descending j; the words that come
-// from the previous lane(s) are fetched first.
-template <int Q, bool F64>
-__device__ __forceinline__ void min_shifted(const DevXL &xl, uint64_t (&X)[16], const uint64_t (&Y)[16])
-{
-    if constexpr (Q < 16) {
-        uint64_t imp[Q];
-#pragma unroll
-        for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, Y[16 + j - Q]);
-#pragma unroll
-        for (int j = 15; j >= 0; j--) X[j] = min_left<F64>(j >= Q ? Y[j - Q] : imp[j], X[j]);
-    } else {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {   // eight at a time: 16 more live registers instead of 32
-            uint64_t imp[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                imp[j] = prev_lane64(xl, Y[8 * h + j]);
-                if constexpr (Q == 32) imp[j] = prev_lane64(xl, imp[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) X[8 * h + j] = min_left<F64>(imp[j], X[8 * h + j]);
-        }
-    }
-}
-
-// A[x] <- min_left<F64>(A[x - Q], R[x])  (the partial window grows to the left by the Q positions of R's span)
-template <int Q, bool F64>
-__device__ __forceinline__ void min_shifted_into(const DevXL &xl, uint64_t (&A)[16], const uint64_t (&R)[16])
-{
-    if constexpr (Q < 16) {
-        uint64_t imp[Q];
-#pragma unroll
-        for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, A[16 + j - Q]);
-#pragma unroll
-        for (int j = 15; j >= 0; j--) A[j] = min_left<F64>(j >= Q ? A[j - Q] : imp[j], R[j]);
-    } else {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            uint64_t imp[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                imp[j] = prev_lane64(xl, A[8 * h + j]);
-                if constexpr (Q == 32) imp[j] = prev_lane64(xl, imp[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) A[8 * h + j] = min_left<F64>(imp[j], R[8 * h + j]);
-        }
-    }
-}
-
-// A[x] <- min_left(M[x - S], M[x]) for ANY shift 0 < S <= 31: two overlapping windows of M's span cover span + S positions
-template <int S, bool F64>
-__device__ __forceinline__ void min_overlap(const DevXL &xl, uint64_t (&A)[16], const uint64_t (&M)[16])
-{
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        uint64_t l;
-        if (j >= S) l = M[j - S];
-        else if (j - S + 16 >= 0) l = prev_lane64(xl, M[j - S + 16]);
-        else l = prev_lane64(xl, prev_lane64(xl, M[j - S + 32]));
-        A[j] = min_left<F64>(l, M[j]);
-    }
-}
-
+// (keys, the left-preferring minimum and the sliding minimum: ntk_tile.hpp, minimizer_windows - shared with the host emulation)
 template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM, bool F64>
 __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MINBLOCKS) void minimizer_scan_kernel(ScanArgs a)
 {
@@ -1316,10 +1220,8 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
     if (shard_end > launch_tiles) shard_end = launch_tiles;
     uint32_t *ctr = a.work_counters + shard * 16;
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
-    const uint32_t W = a.min_w, HL = a.min_halo_lanes, stride = (64u - HL) * 16u, halo_bytes = HL * 16u;
+    const uint32_t HL = a.min_halo_lanes, stride = (64u - HL) * 16u, halo_bytes = HL * 16u;
     DevXL xl;
-    MinimizerSinkG<KW, F64> sink;
-    sink.lane16 = lane * 16u;
     uint64_t sum = 0, xr = 0;
     uint32_t n_fwd = 0, n_valid = 0;
     const uint32_t hist_shift = a.bin_shift + 11 - 2;   // (F64 keys: the bin's BYTE offset - the value's top bits, bit 62 masked off with the bins)
@@ -1362,45 +1264,10 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
             const bool tail = r >= a.tail_tile_rel;
             Raw16 raw{cur.x, cur.y, cur.z, cur.w};
             if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
-            // lanes 0 and 1 are the k-mer halo of the tile logic (their k-mers would need bytes before the tile: all invalid)
-            lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane < (uint32_t)kHaloLanes, tail);
-            // window validity: a k-mer that is invalid takes the w windows it is part of with it
-            const uint32_t b1 = xl.prev(0, sink.inval), b2 = xl.prev(0, b1), b3 = xl.prev(0, b2);
-            uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | sink.inval;
-#pragma unroll
-            for (int i = 0; i < 6; i++) bw |= bw >> a.min_smear[i];
-            const uint32_t invw = lane < HL ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
-            // sliding minimum over W (see above): M doubles while 2q <= W, then two overlapping windows of q make W
-            uint64_t (&M)[16] = sink.key;
+            // keys of the 16 own k-mers, window validity and the 16 window minima (ntk_tile.hpp)
             uint64_t A[16];
-#ifdef NTK_MINGEN_BINARY   // (the first version, A/B: A collects the set bits of W from the low end - popcount(W) - 1 more array minima)
-            bool have_a = false;   // wave-uniform: A holds a partial window already
-#define NTK_MIN_ROUND(Q)                                                                     \
-            if (W >= (Q)) {                                                                  \
-                if (W & (Q)) {                                                               \
-                    if (have_a) min_shifted_into<(Q), F64>(xl, A, M);                        \
-                    else { _Pragma("unroll") for (int j = 0; j < 16; j++) A[j] = M[j]; }     \
-                    have_a = true;                                                           \
-                }                                                                            \
-                if (W >= 2 * (Q)) min_shifted<(Q), F64>(xl, M, M);                           \
-            }
-            NTK_MIN_ROUND(1) NTK_MIN_ROUND(2) NTK_MIN_ROUND(4) NTK_MIN_ROUND(8) NTK_MIN_ROUND(16) NTK_MIN_ROUND(32)
-#undef NTK_MIN_ROUND
-#else
-            if (W >= 2) min_shifted<1, F64>(xl, M, M);
-            if (W >= 4) min_shifted<2, F64>(xl, M, M);
-            if (W >= 8) min_shifted<4, F64>(xl, M, M);
-            if (W >= 16) min_shifted<8, F64>(xl, M, M);
-            if (W >= 32) min_shifted<16, F64>(xl, M, M);
-            switch (a.min_overlap) {   // W - (M's span): 0 .. 17 for W <= 49
-#define NTK_MIN_CASE(S) case S: min_overlap<S, F64>(xl, A, M); break;
-                NTK_MIN_CASE(1) NTK_MIN_CASE(2) NTK_MIN_CASE(3) NTK_MIN_CASE(4) NTK_MIN_CASE(5) NTK_MIN_CASE(6) NTK_MIN_CASE(7) NTK_MIN_CASE(8)
-                NTK_MIN_CASE(9) NTK_MIN_CASE(10) NTK_MIN_CASE(11) NTK_MIN_CASE(12) NTK_MIN_CASE(13) NTK_MIN_CASE(14) NTK_MIN_CASE(15)
-                NTK_MIN_CASE(16) NTK_MIN_CASE(17)
-#undef NTK_MIN_CASE
-                default: _Pragma("unroll") for (int j = 0; j < 16; j++) A[j] = M[j];
-            }
-#endif
+            uint32_t invw;
+            minimizer_windows<KW, TIE_RC, ACCEPT_U, F64>(a, xl, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane, tail, A, invw);
             // the window's minimizer = key >> 1, its strand flag = key & 1.  xor and the flag count are taken on the keys (xor commutes
             // with the shift; n_fwd = windows - flags) and the window count from the validity mask: 16 instructions per tile fewer each
             uint32_t vb = invw << 16;

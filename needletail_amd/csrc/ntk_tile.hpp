@@ -363,6 +363,150 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generic fused windowed minimizers (minimizer_scan_kernel, ntk_kernels.hpp): the per-lane part - keys of the lane's 16 k-mers, window
+// validity, and the sliding minimum over ANY run-time w <= 49 (k <= 31).  Semantics and scheme: the comment block above the kernel.
+// Cross-lane words go through XL::prev_auto (device: DPP wave_shr:1; host emulation: the call sites of a lane numbered in order).
+//
+// F64 (k <= 25): key = bit 62 | value << 11 | (tile position x = 16 * lane + j) << 1 | strand flag - unique per position and ordered by
+// (value, position), bit 61 clear: a positive NORMAL double whose order is its bit pattern's, so ONE v_min_f64 is the leftmost minimum
+// (the general form needs v_or + v_mov + v_cmp_gt_u64 + two v_cndmask per minimum: the compiler has to build the pair (r | 1)).
+// ---------------------------------------------------------------------------------------------
+template <int KW, bool F64>
+struct MinimizerSinkG {
+    uint64_t key[16];
+    uint32_t inval = 0, lane16 = 0;   // lane16 = 16 * lane
+    int64_t base = 0;
+    NTK_HD void begin_tile(int64_t lane_base, uint32_t inval16, bool) { base = lane_base; inval = inval16; }
+    NTK_HD void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
+    {
+        const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
+        if constexpr (F64) key[j] = (1ull << 62) | (v << 11) | ((uint64_t)(lane16 + (uint32_t)j) << 1) | (take_fwd ? 0u : 1u);
+        else key[j] = (v << 1) | (take_fwd ? 0u : 1u);
+    }
+    NTK_HD void end_tile() {}
+};
+
+// the minimum that prefers its LEFT operand on value ties and never lets the strand flag decide
+template <bool F64>
+NTK_HD uint64_t min_left(uint64_t l, uint64_t r)
+{
+    if constexpr (F64) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t m;
+        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(l), "v"(r));
+        return m;
+#else
+        return l < r ? l : r;   // (keys are unique per position; positive normal doubles order like their patterns)
+#endif
+    } else {
+        return l <= (r | 1ull) ? l : r;
+    }
+}
+template <class XL>
+NTK_HD uint64_t prev_lane64(XL &xl, uint64_t v)
+{
+    const uint32_t hi = xl.prev_auto((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | xl.prev_auto((uint32_t)v);
+}
+// X[x] <- min_left(Y[x - Q], X[x]) for the 16 own positions, Q = 1, 2, 4, 8, 16; Y may be X itself (doubling).  In place, descending j;
+// the words that come from the previous lane are fetched first.
+template <int Q, bool F64, class XL>
+NTK_HD void min_shifted(XL &xl, uint64_t (&X)[16], const uint64_t (&Y)[16])
+{
+    if constexpr (Q < 16) {
+        uint64_t imp[Q];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, Y[16 + j - Q]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 15; j >= 0; j--) X[j] = min_left<F64>(j >= Q ? Y[j - Q] : imp[j], X[j]);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int h = 0; h < 2; h++) {   // eight at a time: 16 more live registers instead of 32
+            uint64_t imp[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 8; j++) imp[j] = prev_lane64(xl, Y[8 * h + j]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 8; j++) X[8 * h + j] = min_left<F64>(imp[j], X[8 * h + j]);
+        }
+    }
+}
+// A[x] <- min_left(M[x - S], M[x]) for ANY shift 0 < S <= 31: two overlapping windows of M's span cover span + S positions
+template <int S, bool F64, class XL>
+NTK_HD void min_overlap(XL &xl, uint64_t (&A)[16], const uint64_t (&M)[16])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 16; j++) {
+        uint64_t l;
+        if (j >= S) l = M[j - S];
+        else if (j - S + 16 >= 0) l = prev_lane64(xl, M[j - S + 16]);
+        else l = prev_lane64(xl, prev_lane64(xl, M[j - S + 32]));
+        A[j] = min_left<F64>(l, M[j]);
+    }
+}
+
+// One lane of one tile: A[j] = key of the minimizer of the window ending at own byte j (value, strand flag: see the key forms), invw bit
+// 15 - j set = that window is not emitted (a k-mer of it is invalid, or a halo lane).  Lanes 0 and 1 are the k-mer halo of lane_tile,
+// lanes below a.min_halo_lanes hold k-mers that the first emitting lanes' windows need.
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64, class XL>
+NTK_HD void minimizer_windows(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, uint64_t (&A)[16], uint32_t &invw)
+{
+    MinimizerSinkG<KW, F64> sink;
+    sink.lane16 = lane * 16u;
+    lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, lane_base, lane < (uint32_t)kHaloLanes, tail_tile);
+    // window validity: a k-mer that is invalid takes the w windows it is part of with it
+    const uint32_t b1 = xl.prev_auto(sink.inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
+    uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | sink.inval;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 6; i++) bw |= bw >> a.min_smear[i];
+    invw = lane < a.min_halo_lanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    // sliding minimum over W: M doubles while 2q <= W, then two overlapping windows of q make W (every branch is wave-uniform)
+    const uint32_t W = a.min_w;
+    uint64_t (&M)[16] = sink.key;
+    if (W >= 2) min_shifted<1, F64>(xl, M, M);
+    if (W >= 4) min_shifted<2, F64>(xl, M, M);
+    if (W >= 8) min_shifted<4, F64>(xl, M, M);
+    if (W >= 16) min_shifted<8, F64>(xl, M, M);
+    if (W >= 32) min_shifted<16, F64>(xl, M, M);
+    switch (a.min_overlap) {   // W - (M's span): 0 .. 17 for W <= 49
+#define NTK_MIN_CASE(S) case S: min_overlap<S, F64>(xl, A, M); break;
+        NTK_MIN_CASE(1) NTK_MIN_CASE(2) NTK_MIN_CASE(3) NTK_MIN_CASE(4) NTK_MIN_CASE(5) NTK_MIN_CASE(6) NTK_MIN_CASE(7) NTK_MIN_CASE(8)
+        NTK_MIN_CASE(9) NTK_MIN_CASE(10) NTK_MIN_CASE(11) NTK_MIN_CASE(12) NTK_MIN_CASE(13) NTK_MIN_CASE(14) NTK_MIN_CASE(15)
+        NTK_MIN_CASE(16) NTK_MIN_CASE(17)
+#undef NTK_MIN_CASE
+        default:
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 16; j++) A[j] = M[j];
+    }
+}
+// host side: the run-time geometry of a window length (ScanArgs::min_*), w = 1..49
+inline void scan_args_set_window(ScanArgs &a, uint32_t w)
+{
+    a.min_w = w;
+    a.min_halo_lanes = (uint32_t)kHaloLanes + (w - 1 + 15) / 16;
+    uint32_t q = 1;
+    while (2 * q <= w) q *= 2;
+    a.min_overlap = w - q;
+    uint32_t len = 1;
+    for (int i = 0; i < 6; i++) { const uint32_t sft = len < w ? (len < w - len ? len : w - len) : 0; a.min_smear[i] = sft; len += sft; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // "sv" variant of the tile logic: window validity lives in SCALAR registers.
 //
 // On the device the 16 per-byte break flags are produced directly as 64-bit lane masks B[i] (bit l = byte i of lane l

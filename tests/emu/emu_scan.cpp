@@ -49,8 +49,25 @@ struct HostSink {
 struct EmuXL {
     uint32_t last[kNumSlots];   // values written by the previous lane
     uint32_t cur[kNumSlots];    // values written by the current lane
+    // prev_auto: call sites without a slot id are numbered in the order a lane reaches them (every lane of a wave runs the same sequence:
+    // the branches around them are wave-uniform)
+    std::vector<uint32_t> last_auto, cur_auto;
+    size_t n_auto = 0;
     bool first_lane = true;
-    void next_lane(bool first) { if (!first) memcpy(last, cur, sizeof(last)); else memset(last, 0, sizeof(last)); first_lane = first; }
+    void next_lane(bool first)
+    {
+        if (!first) memcpy(last, cur, sizeof(last)); else memset(last, 0, sizeof(last));
+        if (!first) last_auto = cur_auto; else last_auto.clear();
+        cur_auto.clear(); n_auto = 0;
+        first_lane = first;
+    }
+    uint32_t prev_auto(uint32_t x)
+    {
+        cur_auto.push_back(x);
+        const uint32_t r = n_auto < last_auto.size() ? last_auto[n_auto] : 0u;   // lane 0 reads 0 (bound_ctrl)
+        n_auto++;
+        return r;
+    }
     uint32_t prev(int slot, uint32_t x) { cur[slot] = x; return last[slot]; }
     uint32_t prev_and(int slot, uint32_t x, uint32_t mask) { return prev(slot, x) & mask; }
     uint32_t select_prev(int slot, bool take, uint32_t a, uint32_t b) { const uint32_t p = prev(slot, b); return take ? a : p; }
@@ -311,6 +328,32 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
     mp.finish(st);
 }
 
+// The generic fused minimizer kernel (minimizer_scan_kernel): the same per-lane source (ntk_tile.hpp minimizer_windows: keys, window validity,
+// doubling + two overlapping windows), the kernel's run-time tile geometry (a.min_halo_lanes non-emitting lanes) and its output stage
+// restated on the decoded keys.
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64>
+void run_min_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st)
+{
+    const uint64_t slots = 64 - a.min_halo_lanes, stride = slots * 16, halo_bytes = a.min_halo_lanes * 16;
+    const uint64_t n_tiles = ((n + 15) / 16 + slots - 1) / slots;
+    for (uint64_t t = 0; t < n_tiles; t++) {
+        const bool tail = (t + 1) * stride > n;
+        EmuXL xl;
+        for (uint32_t l = 0; l < 64; l++) {
+            xl.next_lane(l == 0);
+            const int64_t lane_base = (int64_t)(t * stride) - (int64_t)halo_bytes + l * 16;
+            uint64_t A[16];
+            uint32_t invw;
+            minimizer_windows<KW, TIE_RC, ACCEPT_U, F64>(a, xl, load16q(buf, n_padded, lane_base), lane_base, l, tail, A, invw);
+            for (int j = 0; j < 16; j++) {
+                if ((invw >> (15 - j)) & 1) continue;
+                const uint64_t v = F64 ? (A[j] & ~(1ull << 62)) >> 11 : A[j] >> 1;
+                st->n_total++; st->n_fwd += !(A[j] & 1); st->sum += v; st->xr ^= v; st->hist[v >> a.bin_shift]++;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // The window-mask algebra alone: OK[j] in its two forms (window_masks / window_masks1: the finished masks; *_ab: the masks with
@@ -419,6 +462,30 @@ int emu_minimizers(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k
     }
     delete st;
     return done ? 0 : -2;
+}
+
+// The generic fused minimizer kernel: any k <= 31, w <= 49; f64 = 1 takes the v_min_f64 key form (k <= 25 only), 0 the general keys.
+// Returns -2 outside those ranges.
+int emu_minimizers_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, uint32_t w, int tie_rc, int accept_u, int f64,
+                           uint64_t *out)
+{
+    if (k < 1 || k > 31 || w < 1 || w > 49 || (f64 && k > 25)) return -2;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    scan_args_set_k(a, k);
+    scan_args_set_window(a, w);
+    a.n_bytes = n;
+    HostStats *st = new HostStats();
+    const int kw = k > 16 ? 2 : 1;
+#define EMU_MG(KW, T, U, F) if (kw == KW && !!tie_rc == T && !!accept_u == U && !!f64 == F) run_min_generic<KW, T, U, F>(buf, n, n_padded, a, st);
+#define EMU_MG4(KW, F) EMU_MG(KW, false, false, F) EMU_MG(KW, false, true, F) EMU_MG(KW, true, false, F) EMU_MG(KW, true, true, F)
+    EMU_MG4(1, false) EMU_MG4(1, true) EMU_MG4(2, false) EMU_MG4(2, true)
+#undef EMU_MG4
+#undef EMU_MG
+    out[0] = st->n_total; out[1] = st->n_fwd; out[2] = st->sum; out[3] = st->xr;
+    memcpy(out + 4, st->hist, sizeof(st->hist));
+    delete st;
+    return 0;
 }
 
 int emu_window_masks(const uint64_t *g16, uint32_t k, uint64_t *ok16, uint64_t *ab16)

@@ -2,9 +2,10 @@
 in numpy and checked against a brute-force window minimum: keys (value << 1) | strand flag, a minimum that prefers its LEFT operand on ties
 and ignores the flag (take L <=> key_L <= key_R | 1), doubling with FIXED shifts and two overlapping power-of-two windows for w
     M_1 = key;  M_2q[x] = min(M_q[x - q], M_q[x]) while 2q <= w;  window[x] = min(M_q[x - (w - q)], M_q[x])
-(the first version of the kernel: A'[x] = min(A[x - q], M_q[x]) for the set bits q of w, low to high - kept as the A/B build and below);
+(the first version of the kernel: A'[x] = min(A[x - q], M_q[x]) for the set bits q of w, low to high - restated below as well);
 for k <= 25 the kernel's keys are bit 62 | value << 11 | position << 1 | flag under a plain minimum (v_min_f64 on the bit patterns).
-No GPU needed: this pins the ALGORITHM (leftmost tie rule, the flag never deciding, every w); the device code is checked by the gpu tests."""
+No GPU needed: this pins the ALGORITHM (leftmost tie rule, the flag never deciding, every w); the kernel's own per-lane source runs under the
+64-lane emulator in test_tile_logic_emu.py, the device code in the gpu tests."""
 import numpy as np
 
 

@@ -303,7 +303,7 @@ def test_emu_fused_minimizers_match_the_literal_minimizer(emu):
     with breaks, reverse-complement palindromes, homopolymer runs (every window ties), both tie rules."""
     rng = np.random.default_rng(5)
     alphabet = np.frombuffer(b"ACGTacgtACGTACGTACGTACGTNU\n", dtype=np.uint8)
-    assert emu_minimizers(emu, b"ACGT", 23, 11, 1, 1, 0) is None     # no fused build: the two-pass path serves it
+    assert emu_minimizers(emu, b"ACGT", 23, 11, 1, 1, 0) is None     # no register-fused build: the generic fused kernel serves it (below)
     for trial in range(40):
         n = int(rng.integers(0, 2600))
         b = bytes(alphabet[rng.integers(0, len(alphabet), n)])
@@ -314,3 +314,61 @@ def test_emu_fused_minimizers_match_the_literal_minimizer(emu):
             for tie, u in ((1, 1), (0, 0)):
                 want = O.minimizers_reduce(b, k, w, accept_u=bool(u), tie_rc=bool(tie))
                 assert_stats_equal(emu_minimizers(emu, b, k, w, tie, u, trial % 2), want, (trial, k, w, tie, u))
+
+
+# ---- the generic fused minimizer kernel (ntk_tile.hpp minimizer_windows; ntk_kernels.hpp minimizer_scan_kernel) ---------------------
+
+def emu_minimizers_generic(L, buf: bytes, k, w, tie_rc, accept_u, f64):
+    n = len(buf)
+    npad = (n + 15) // 16 * 16
+    arr = np.frombuffer(buf + b"\xAA" * (npad - n), dtype=np.uint8).copy()
+    out = np.zeros(4 + 4096, dtype=np.uint64)
+    L.emu_minimizers_generic.restype = C.c_int
+    L.emu_minimizers_generic.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.emu_minimizers_generic(arr.ctypes.data, n, npad, k, w, int(tie_rc), int(accept_u), int(f64), out.ctypes.data)
+    if rc == -2:
+        return None
+    assert rc == 0
+    return {"n_total": int(out[0]), "n_fwd": int(out[1]), "n_rc": int(out[0] - out[1]), "sum": int(out[2]),
+            "xor": int(out[3]), "hist": out[4:].copy()}
+
+
+def test_emu_generic_minimizers_match_the_literal_minimizer(emu):
+    """The per-lane source of the generic fused minimizer kernel (any k <= 31, w <= 49 at run time), lock-step over 64 lanes with the kernel's
+    run-time tile geometry, against sequence::minimizer applied window by window (oracle, reference src/sequence.rs:139-152): both key forms
+    (k <= 25: value, tile position and strand in one ordered double under a plain minimum; the general keys under the left-preferring
+    minimum), every doubling round and every overlap shift (w = 1..49), windows reaching one / two / three lanes back, k on both sides of
+    the one-word / two-word values and of the key forms, both tie rules and alphabets, inverted repeats within a window (equal values on
+    opposite strands: the leftmost rule), homopolymers, ragged records."""
+    rng = np.random.default_rng(29)
+    alphabet = np.frombuffer(b"ACGTacgtACGTACGTACGTACGTNU\n", dtype=np.uint8)
+    assert emu_minimizers_generic(emu, b"ACGT", 32, 11, 1, 1, 0) is None and emu_minimizers_generic(emu, b"ACGT", 21, 50, 1, 1, 0) is None
+    assert emu_minimizers_generic(emu, b"ACGT", 26, 11, 1, 1, 1) is None   # f64 keys hold k <= 25
+    ws = list(range(1, 50))
+    for trial in range(14):
+        n = int(rng.integers(0, 3200))
+        b = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        if trial % 3 == 0:
+            h = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(10, 70))).astype(np.uint8))
+            b = b + h + O.reverse_complement(h) + h + b"A" * 90 + b"AC" * 40 + b"T" * 70 + b[:80]
+        if trial % 5 == 1:
+            b = bytes(rng.choice(list(b"ACGT"), size=2500).astype(np.uint8))   # no breaks: every window of a long run
+        picks = [(int(rng.choice([1, 3, 8, 11, 15, 16, 17, 21, 24, 25, 26, 28, 31])), w) for w in rng.choice(ws, size=7, replace=False)]
+        picks += [(25, 49), (26, 49), (16, 17), (17, 16), (31, 33), (23, 11), (12, 32)][trial % 7: trial % 7 + 2]
+        for k, w in picks:
+            for tie, u in ((1, 1), (0, 0)):
+                want = O.minimizers_reduce(b, k, w, accept_u=bool(u), tie_rc=bool(tie))
+                assert_stats_equal(emu_minimizers_generic(emu, b, k, w, tie, u, 0), want, (trial, k, w, tie, u, "general keys"))
+                if k <= 25:
+                    assert_stats_equal(emu_minimizers_generic(emu, b, k, w, tie, u, 1), want, (trial, k, w, tie, u, "f64 keys"))
+
+
+def test_emu_generic_minimizers_every_window_length(emu):
+    """w = 1..49 one by one (every overlap shift 0..17 behind every doubling depth) on one buffer, k = 19 (two words, f64 keys) and k = 27."""
+    rng = np.random.default_rng(31)
+    h = bytes(rng.choice(list(b"ACGT"), size=50).astype(np.uint8))
+    b = bytes(rng.choice(list(b"ACGT"), size=1500).astype(np.uint8)) + b"N" + h + O.reverse_complement(h) + b"G" * 120 + b"\n" + h[:30] * 4
+    for w in range(1, 50):
+        for k, f64 in ((19, 1), (27, 0)):
+            want = O.minimizers_reduce(b, k, w, accept_u=True, tie_rc=True)
+            assert_stats_equal(emu_minimizers_generic(emu, b, k, w, 1, 1, f64), want, (k, w, f64))
