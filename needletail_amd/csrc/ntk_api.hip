@@ -366,11 +366,12 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
 
 // Generic fused windowed minimizers (ntk_kernels.hpp minimizer_scan_kernel): any k <= 31 and w <= 49 of the canonical paths, with or
 // without a quality stream; the tile geometry depends on w (2 + ceil((w - 1) / 16) non-emitting lanes).
-const void *pick_min_generic(const Mode &m, bool quality, bool f64)   // f64: k <= 25 (one v_min_f64 per minimum, ntk_kernels.hpp)
+const void *pick_min_generic(const Mode &m, bool quality, bool f64)   // f64: k <= 25 (one v_min_f64 per minimum, ntk_tile.hpp)
 {
-#define NTK_PICK_MG(KW, T, U, Q, F) if (m.kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q && f64 == F) return (const void *)&minimizer_scan_kernel<KW, T, U, Q, F>;
+    const int kw = f64 ? 2 : m.kw;   // (the f64 keys are built from the code streams for any k: one instantiation serves both word counts)
+#define NTK_PICK_MG(KW, T, U, Q, F) if (kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q && f64 == F) return (const void *)&minimizer_scan_kernel<KW, T, U, Q, F>;
 #define NTK_PICK_MG4(KW, Q, F) NTK_PICK_MG(KW, false, false, Q, F) NTK_PICK_MG(KW, false, true, Q, F) NTK_PICK_MG(KW, true, false, Q, F) NTK_PICK_MG(KW, true, true, Q, F)
-    NTK_PICK_MG4(1, false, true) NTK_PICK_MG4(2, false, true) NTK_PICK_MG4(1, true, true) NTK_PICK_MG4(2, true, true)
+    NTK_PICK_MG4(2, false, true) NTK_PICK_MG4(2, true, true)
     NTK_PICK_MG4(2, false, false) NTK_PICK_MG4(2, true, false)   // 26 <= k <= 31
     NTK_PICK_MG4(1, false, false) NTK_PICK_MG4(1, true, false)   // (only under NTK_MINGEN_NO_F64, the A/B switch)
 #undef NTK_PICK_MG4

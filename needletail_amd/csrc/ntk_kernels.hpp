@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
             for (int j = 0; j < 16; j++) {
                 const bool valid = !__builtin_add_overflow(vb, vb, &vb);
                 if (valid) {
-                    n_fwd += (uint32_t)A[j] & 1u;   // counts the rc flags here
+                    n_fwd += (uint32_t)A[j] & 1u;   // the keys' strand bits (their meaning: the epilogue)
                     if constexpr (F64) {   // raw keys: bit 62 and the low 11 bits are taken out of sum / xor after the loop
                         sum += A[j] >> 11; xr ^= A[j];
                         atomicAdd((uint32_t *)((char *)s_hist + ((uint32_t)(A[j] >> hist_shift) & (uint32_t)(4 * kHistBins - 4))), 1u);
@@ -1290,7 +1290,8 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }
-    uint64_t nf = n_valid - n_fwd, nv = n_valid;   // (n_fwd counted the rc flags)
+    // n_fwd counted the keys' bit 0: "reverse complement" - except for the f64 keys under TIE_RC, where the tie-winning strand (rc) carries 0
+    uint64_t nf = (F64 && TIE_RC) ? n_fwd : n_valid - n_fwd, nv = n_valid;
     if constexpr (F64) { sum -= (uint64_t)n_valid << 51; xr = (xr >> 11) & ((1ull << 51) - 1); }
     else xr >>= 1;
 #pragma unroll

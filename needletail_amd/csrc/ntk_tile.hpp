@@ -463,6 +463,75 @@ NTK_HD void min_overlap(XL &xl, uint64_t (&A)[16], const uint64_t (&M)[16])
     }
 }
 
+// The f64 keys of a lane's 16 k-mers (k <= 25) straight from the code streams, both strands, no compare and no select: the key of a strand is
+// two stream windows with constant fields merged in, and the strand choice is the same v_min_f64 as everything after it.
+//     key = bit 62 | value << 11 | tag,   tag = tile position (16 * lane + j) << 1 | strand bit
+//   * lo word = the 32 stream bits that start 11 bits below the value's end, low 11 bits replaced by the tag (one funnel shift + one
+//     v_bitop3); forward positions j >= 10 would need bits of the NEXT lane there and shift the window word up instead;
+//   * hi word = the 32 stream bits 21 above the value's end, cut to the value's remaining 2k - 21 bits, bit 30 set (funnel shift + v_bitop3);
+//   * the reverse-complement stream is first right-aligned to the value (R >> (64 - 2k), four words: the run-time k is all in that shift);
+//   * strand bit: the strand that wins a tie (equal values at the same position) carries 0 - reverse complement under TIE_RC (reference
+//     src/kmer.rs:124-128), forward otherwise (src/bitkmer.rs:138-142); so bit 0 of a key says "forward" under TIE_RC and "reverse
+//     complement" otherwise.
+// Against the lane_tile route (values of both strands, 64-bit compare into an SGPR pair, three selects, then the key): 697 instead of 863
+// issue cycles per tile by the class costs, and no SGPR-writing VALU op.
+template <bool TIE_RC, bool ACCEPT_U, class XL>
+NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, uint64_t (&key)[16], uint32_t &inval)
+{
+    Enc en = encode16<ACCEPT_U>(raw);
+    if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
+        const int64_t keep = (int64_t)a.n_bytes - lane_base;
+        en.bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
+    }
+    const uint32_t c1 = xl.prev_auto(en.code), c2 = xl.prev_auto(c1);
+    const uint32_t r1 = xl.prev_auto(en.rcode);
+    const uint32_t b1 = xl.prev_auto(en.bad), b2 = xl.prev_auto(b1);
+    uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;   // windows of k containing a break (as lane_tile)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+    inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    // Q = (rcode : r1 : r2 : r3) >> (64 - 2k), Q[3] the least significant word; the value whose top group is own base j sits at Q bits
+    // [34 + 2j, 34 + 2j + 2k)
+    const uint32_t sh = 64u - 2u * a.k;   // 14 .. 62
+    uint32_t Q[4];
+    if (sh < 32u) {
+        Q[0] = en.rcode >> sh; Q[1] = alignbit(en.rcode, r1, sh); Q[2] = xl.prev_auto(Q[1]); Q[3] = xl.prev_auto(Q[2]);
+    } else {
+        Q[0] = 0u; Q[1] = en.rcode >> (sh - 32u); Q[2] = alignbit(en.rcode, r1, sh - 32u); Q[3] = xl.prev_auto(Q[2]);
+    }
+    const uint32_t vbits = 2u * a.k;
+    const uint32_t mask_lo = vbits >= 21u ? 0xFFFFF800u : (((1u << vbits) - 1u) << 11);
+    const uint32_t mask_hi = vbits > 21u ? (1u << (vbits - 21u)) - 1u : 0u;
+    const uint32_t marker = 0x40000000u;
+    const uint32_t lane32 = lane << 5;
+    constexpr uint32_t fbitF = TIE_RC ? 1u : 0u, fbitR = TIE_RC ? 0u : 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 16; j++) {
+        // forward: the value ends (LSB) at stream bit e = 30 - 2j of (c2 : c1 : code)
+        uint32_t fL, fH;
+        if (j <= 9) {
+            fL = alignbit(c1, en.code, 19 - 2 * j);            // stream bits [e - 11, e + 21)
+            fH = alignbit(c2, c1, 19 - 2 * j);                 // stream bits [e + 21, e + 53)
+        } else {
+            const uint32_t fl = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
+            fL = fl << 11;
+            fH = alignbit(c1, en.code, 51 - 2 * j);
+        }
+        // reverse complement: the value's LSB at Q bit p0 = 34 + 2j; lo window starts at p0 - 11 = 23 + 2j, hi window at p0 + 21 = 55 + 2j
+        const int sL = 23 + 2 * j, sH = 55 + 2 * j;
+        const uint32_t rL = sL < 32 ? alignbit(Q[2], Q[3], sL) : alignbit(Q[1], Q[2], sL - 32);
+        const uint32_t rH = sH < 64 ? alignbit(Q[1], Q[2], sH - 32) : alignbit(Q[0], Q[1], sH - 64);
+        const uint32_t tag = lane32 | (uint32_t)(2 * j);
+        const uint64_t kf = ((uint64_t)and_or(fH, mask_hi, marker) << 32) | and_or(fL, mask_lo, tag | fbitF);
+        const uint64_t kr = ((uint64_t)and_or(rH, mask_hi, marker) << 32) | and_or(rL, mask_lo, tag | fbitR);
+        key[j] = min_left<true>(kf, kr);
+    }
+}
+
 // One lane of one tile: A[j] = key of the minimizer of the window ending at own byte j (value, strand flag: see the key forms), invw bit
 // 15 - j set = that window is not emitted (a k-mer of it is invalid, or a halo lane).  Lanes 0 and 1 are the k-mer halo of lane_tile,
 // lanes below a.min_halo_lanes hold k-mers that the first emitting lanes' windows need.
@@ -470,8 +539,12 @@ template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64, class XL>
 NTK_HD void minimizer_windows(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, uint64_t (&A)[16], uint32_t &invw)
 {
     MinimizerSinkG<KW, F64> sink;
-    sink.lane16 = lane * 16u;
-    lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, lane_base, lane < (uint32_t)kHaloLanes, tail_tile);
+    if constexpr (F64) {
+        minimizer_keys_f64<TIE_RC, ACCEPT_U>(a, xl, raw, lane_base, lane, tail_tile, sink.key, sink.inval);
+    } else {
+        sink.lane16 = lane * 16u;
+        lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, lane_base, lane < (uint32_t)kHaloLanes, tail_tile);
+    }
     // window validity: a k-mer that is invalid takes the w windows it is part of with it
     const uint32_t b1 = xl.prev_auto(sink.inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
     uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | sink.inval;

@@ -348,7 +348,8 @@ void run_min_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs
             for (int j = 0; j < 16; j++) {
                 if ((invw >> (15 - j)) & 1) continue;
                 const uint64_t v = F64 ? (A[j] & ~(1ull << 62)) >> 11 : A[j] >> 1;
-                st->n_total++; st->n_fwd += !(A[j] & 1); st->sum += v; st->xr ^= v; st->hist[v >> a.bin_shift]++;
+                const bool is_rc = (F64 && TIE_RC) ? !(A[j] & 1) : (A[j] & 1);   // f64 keys: the tie-winning strand carries 0
+                st->n_total++; st->n_fwd += !is_rc; st->sum += v; st->xr ^= v; st->hist[v >> a.bin_shift]++;
             }
         }
     }
