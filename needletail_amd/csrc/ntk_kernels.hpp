@@ -1180,8 +1180,10 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 // Semantics as lane_tile_sv2_min / window_min_reduce_kernel (reference sequence::minimizer, src/sequence.rs:139-152, applied to every
 // window of w + k - 1 good bases): the window ending at byte e holds the w k-mers ending at e-w+1 .. e; its minimizer is the smallest
 // canonical value, the LEFTMOST on ties, reported with that k-mer's strand flag.
-//   * k-mers: the run-time-k tile logic of the round-1 kernel (lane_tile: value, "window of k contains a break" bit, strand per position).
-//   * key (26 <= k; k <= 25: the F64 form at MinimizerSinkG) = (value << 1) | strand flag.  A minimum that prefers its LEFT operand on ties and ignores the strand bit:
+//   * k <= 25 (F64): key = bit 62 | value << 11 | tile position << 1 | strand bit, built for both strands straight from the code streams
+//     (ntk_tile.hpp minimizer_keys_f64); ONE v_min_f64 is the strand choice and every leftmost minimum after it.
+//   * 26 <= k <= 31: the run-time-k tile logic of the round-1 kernel (lane_tile: value, "window of k contains a break" bit, strand per
+//     position), key = (value << 1) | strand flag and a minimum that prefers its LEFT operand on ties and ignores the strand bit:
 //         take L  <=>  key_L <= (key_R | 1)          (floor(key_L / 2) <= floor(key_R / 2))
 //   * sliding minimum over w for any run-time w, positions x = 16 * lane + j of the wave's tile, with FIXED shifts: doubling
 //         M_1 = key;  M_2q[x] = min(M_q[x - q], M_q[x])  while 2q <= w;      window[x] = min(M_q[x - (w - q)], M_q[x])
@@ -1197,8 +1199,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #define NTK_MINGEN_MINBLOCKS 1
 #endif
 #ifndef NTK_MINGEN_MINBLOCKS_F64
-// ... and with the v_min_f64 keys (k <= 25): 116 VGPRs unconstrained = 4 waves per SIMD; 5 blocks fit in 96 without scratch and change
-// nothing ((23, 11) 1.50 against 1.49 ms, profiles/r04f/min_generic_5blocks.txt)
+// ... and with the v_min_f64 keys (k <= 25): 128 VGPRs unconstrained = 4 waves per SIMD (with the keys built from the values of lane_tile:
+// 116; 5 blocks fit in 96 there without scratch and changed nothing: (23, 11) 1.50 against 1.49 ms, profiles/r04f/min_generic_5blocks.txt)
 #define NTK_MINGEN_MINBLOCKS_F64 1
 #endif
 // (keys, the left-preferring minimum and the sliding minimum: ntk_tile.hpp, minimizer_windows - shared with the host emulation)
