@@ -34,5 +34,13 @@ int main() {
         });
     }
     printf("\n");
+    // sequence::minimizer for a reader batch in one call: the reference's literal (src/sequence.rs:363-367: "ATTTCG", 3 -> "AAA") and two more
+    const uint8_t mb[] = "ATTTCGACGTTTGGCA";
+    const std::vector<uint64_t> moffs = {0, 6, 10, 16};
+    std::vector<uint64_t> mpos; std::vector<uint8_t> mrc;
+    const std::vector<Bytes> mins = minimizer_batch(Slice(mb, 16), moffs, 3, Context::global(), &mpos, &mrc);
+    printf("minimizer_batch");
+    for (size_t i = 0; i < mins.size(); i++) printf(" %.*s:%llu:%d", (int)mins[i].size(), (const char *)mins[i].data(), (unsigned long long)mpos[i], (int)mrc[i]);
+    printf("\n");
     return 0;
 }

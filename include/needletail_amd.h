@@ -320,6 +320,15 @@ void ntk_pinned_free(void *p);
 int ntk_minimizers_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p, uint32_t w);
 /* sequence::minimizer (reference src/sequence.rs:139-152) for one sequence; out holds m bytes; n >= m >= 1. */
 int ntk_minimizer(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint32_t m, uint8_t *out);
+/* sequence::minimizer (reference src/sequence.rs:139-152) for every record of a reader batch in one call: record r = the bytes
+ * offsets[r] .. offsets[r+1] of seq (host arrays, as in ntk_canonical_kmers_batch); out + r * m receives its m bytes.  Optional
+ * (may be NULL): pos_out[r] = the winning window's start in ITS strand's string (the sequence, or its reverse complement),
+ * is_rc_out[r] = 1 when it was drawn from the reverse complement; among equal byte strings the window the reference's loop meets
+ * first wins (forward window i, then reverse-complement window i, i ascending: src/sequence.rs:143-150).  A record shorter than m
+ * (the reference panics there, :141) fails the call with NTK_ERR_BAD_ARG before anything is computed; *bad_record (may be NULL)
+ * = its index, ~0 otherwise.  Synchronous. */
+int ntk_minimizer_batch(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t m, uint8_t *out,
+                        uint64_t *pos_out, uint8_t *is_rc_out, uint64_t *bad_record);
 /* sequence::canonical (reference src/sequence.rs:110-134): the lexicographically lower of seq and its reverse complement
  * (raw-byte order, complement as ntk_reverse_complement); out holds n bytes; *was_rc = 1 when the reverse complement won. */
 int ntk_canonical(ntk_ctx *ctx, const uint8_t *seq, uint64_t n, uint8_t *out, int *was_rc);

@@ -159,6 +159,21 @@ inline Bytes minimizer(Slice seq, size_t length, Context &c = Context::global())
     check(ntk_minimizer(c.get(), seq.data(), seq.size(), (uint32_t)length, out.data()), "ntk_minimizer");
     return out;
 }
+// ... for every record of a reader batch in one call (record r = seq[offsets[r] .. offsets[r+1])); a record shorter than `length` throws
+// (the reference panics there).  pos / is_rc (optional): the winning window's start on its strand's string, and its strand.
+inline std::vector<Bytes> minimizer_batch(Slice seq, const std::vector<uint64_t> &offsets, size_t length, Context &c = Context::global(),
+                                          std::vector<uint64_t> *pos = nullptr, std::vector<uint8_t> *is_rc = nullptr) {
+    const size_t n = offsets.empty() ? 0 : offsets.size() - 1;
+    Bytes flat(n * length, 0);
+    if (pos) pos->assign(n, 0);
+    if (is_rc) is_rc->assign(n, 0);
+    uint64_t bad = 0;
+    if (n) check(ntk_minimizer_batch(c.get(), seq.data(), offsets.data(), n, (uint32_t)length, flat.data(), pos ? pos->data() : nullptr,
+                                     is_rc ? is_rc->data() : nullptr, &bad), "ntk_minimizer_batch");
+    std::vector<Bytes> out(n);
+    for (size_t r = 0; r < n; r++) out[r].assign(flat.begin() + r * length, flat.begin() + (r + 1) * length);
+    return out;
+}
 // sequence::canonical (reference src/sequence.rs:110-134)
 inline Bytes canonical(Slice seq, Context &c = Context::global()) {
     Bytes out(seq.size(), 0);

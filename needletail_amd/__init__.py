@@ -11,7 +11,7 @@ from .parser import (FastxReader, NeedletailError, Record, decode_phred, parse_f
                      scan_file_parallel)
 from .sequence import (bit_kmers, bit_kmers_arrays, bit_kmers_batch, canonical_kmers, canonical_kmers_arrays,
                        canonical_kmers_batch, canonical_kmers_planes, CanonicalKmersPlanes, kmers, normalize,
-                       normalize_opt, normalize_seq, reverse_complement, strip_returns, minimizer, canonical, mask_header_tabs,
+                       normalize_opt, normalize_seq, reverse_complement, strip_returns, minimizer, minimizer_batch, canonical, mask_header_tabs,
                        mask_header_utf8, bit_minimizers, quality_mask, bit_reverse_complement, bit_canonical,
                        bitmer_to_bytes, bytes_to_bitmer)
 
@@ -21,7 +21,7 @@ __all__ = [
     "PRE_NONE", "PRE_STRIP_RETURNS", "PRE_NORMALIZE", "PRE_NORMALIZE_IUPAC",
     "parse_fastx_file", "parse_fastx_stdin", "decode_phred", "write_fasta", "write_fastq", "parse_fastx_string", "FastxReader", "Record", "NeedletailError", "scan_file", "scan_file_parallel",
     "normalize", "normalize_opt", "normalize_seq", "strip_returns", "reverse_complement",
-    "minimizer", "canonical", "mask_header_tabs", "mask_header_utf8", "bit_minimizers", "quality_mask", "bit_reverse_complement", "bit_canonical", "bitmer_to_bytes",
+    "minimizer", "minimizer_batch", "canonical", "mask_header_tabs", "mask_header_utf8", "bit_minimizers", "quality_mask", "bit_reverse_complement", "bit_canonical", "bitmer_to_bytes",
     "bytes_to_bitmer",
     "kmers", "canonical_kmers", "canonical_kmers_arrays", "bit_kmers", "bit_kmers_arrays", "bit_kmers_batch", "canonical_kmers_batch", "canonical_kmers_planes", "CanonicalKmersPlanes",
 ]

@@ -1474,6 +1474,58 @@ int ntk_minimizer(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t m, uint8_
     return NTK_OK;
 }
 
+/* sequence::minimizer for every record of a reader batch in one call: one upload, one wave per record (one block for a record beyond
+ * 64 KiB), one download of n_records x m bytes (+ the optional window starts and strands). */
+int ntk_minimizer_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t m, uint8_t *out, uint64_t *pos_out,
+                        uint8_t *is_rc_out, uint64_t *bad_record)
+{
+    if (!c || !offsets || m < 1 || (n_records && !out)) return NTK_ERR_BAD_ARG;
+    if (bad_record) *bad_record = ~0ull;
+    if (n_records == 0) return NTK_OK;
+    for (uint64_t r = 0; r < n_records; r++) {
+        if (offsets[r] > offsets[r + 1]) return NTK_ERR_BAD_ARG;
+        if (offsets[r + 1] - offsets[r] < m) {   // the reference panics on a sequence shorter than the length asked for (src/sequence.rs:141)
+            if (bad_record) *bad_record = r;
+            return NTK_ERR_BAD_ARG;
+        }
+    }
+    if (!seq) return NTK_ERR_BAD_ARG;   // (every record holds at least m >= 1 bytes)
+    HIPCHK(hipSetDevice(c->device));
+    constexpr uint64_t kLongRecord = 1ull << 16;
+    const uint64_t total = offsets[n_records] - offsets[0];
+    const size_t out_bytes = (size_t)n_records * m;
+    // scratch 1: offsets | window starts | minimizers | strands | bad-record word + the one-block kernel's (index, strand) pair
+    const size_t o_off = 0, o_pos = o_off + (size_t)(n_records + 1) * 8, o_out = o_pos + (size_t)n_records * 8,
+                 o_rc = (o_out + out_bytes + 15) & ~(size_t)15, o_bad = (o_rc + (size_t)n_records + 15) & ~(size_t)15, o_end = o_bad + 32;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, total + 16))) return rc;
+    if ((rc = ensure_scratch(c, 1, o_end))) return rc;
+    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d1 = (uint8_t *)c->scratch[1].p;
+    uint64_t *d_offs = (uint64_t *)(d1 + o_off), *d_pos = (uint64_t *)(d1 + o_pos), *d_bad = (uint64_t *)(d1 + o_bad);
+    uint8_t *d_out = d1 + o_out, *d_rc = d1 + o_rc;
+    const uint16_t *comp = (const uint16_t *)(c->d_lut + 768);
+    HIPCHK(hipMemcpyAsync(d_in, seq + offsets[0], total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_offs, offsets, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_bad, 0xFF, 8, c->stream));
+    const uint64_t blocks = (n_records + 3) / 4;
+    hipLaunchKernelGGL(minimizer_batch_kernel, dim3((unsigned)(blocks < (uint64_t)c->n_cu * 16 ? blocks : (uint64_t)c->n_cu * 16)), dim3(256), 0, c->stream,
+                       (const uint8_t *)d_in, (const uint64_t *)d_offs, n_records, m, kLongRecord, comp, d_out, d_pos, d_rc, (unsigned long long *)d_bad);
+    for (uint64_t r = 0; r < n_records; r++) {   // the rare long record: the one-block kernel of ntk_minimizer, on the uploaded bytes
+        const uint64_t n = offsets[r + 1] - offsets[r];
+        if (n <= kLongRecord) continue;
+        const uint8_t *rec = d_in + (offsets[r] - offsets[0]);
+        hipLaunchKernelGGL(minimizer_bytes_kernel, dim3(1), dim3(1024), 0, c->stream, rec, n, m, comp, d_bad + 1);
+        hipLaunchKernelGGL(minimizer_emit_record_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, rec, n, m, comp, (const uint64_t *)(d_bad + 1), r, d_out,
+                           d_pos, d_rc);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (pos_out) HIPCHK(hipMemcpyAsync(pos_out, d_pos, (size_t)n_records * 8, hipMemcpyDeviceToHost, c->stream));
+    if (is_rc_out) HIPCHK(hipMemcpyAsync(is_rc_out, d_rc, (size_t)n_records, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NTK_OK;
+}
+
 int ntk_canonical(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *out, int *was_rc)
 {
     if (!c || (!seq && n) || (!out && n)) return NTK_ERR_BAD_ARG;

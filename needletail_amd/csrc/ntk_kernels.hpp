@@ -1888,6 +1888,8 @@ __device__ __forceinline__ uint8_t cand_byte(const uint8_t *seq, uint64_t n, con
 {
     return strand ? (uint8_t)comp[seq[n - 1 - (idx + j)]] : seq[idx + j];
 }
+// three-way compare of two candidates (window start ia on strand sa / ib on sb) as raw bytes; a tie goes to the candidate the reference's loop
+// meets first (src/sequence.rs:143-150: forward window i, then reverse-complement window i, i ascending: candidate number 2 i + strand)
 __device__ __forceinline__ bool cand_less(const uint8_t *seq, uint64_t n, const uint16_t *comp, uint32_t m,
                                           uint64_t ia, uint32_t sa, uint64_t ib, uint32_t sb)
 {
@@ -1895,7 +1897,7 @@ __device__ __forceinline__ bool cand_less(const uint8_t *seq, uint64_t n, const 
         const uint8_t a = cand_byte(seq, n, comp, ia, sa, j), b = cand_byte(seq, n, comp, ib, sb, j);
         if (a != b) return a < b;
     }
-    return false;
+    return 2 * ia + sa < 2 * ib + sb;
 }
 __global__ __launch_bounds__(1024) void minimizer_bytes_kernel(const uint8_t *seq, uint64_t n, uint32_t m, const uint16_t *comp, uint64_t *best)
 {
@@ -1920,6 +1922,49 @@ __global__ __launch_bounds__(1024) void minimizer_bytes_kernel(const uint8_t *se
         __syncthreads();
     }
     if (threadIdx.x == 0) { best[0] = s_idx[0]; best[1] = s_str[0]; }
+}
+// sequence::minimizer for every record of a batch (records at offs[r] - offs[0] .. offs[r + 1] - offs[0] of seq): one wave per record, the
+// 2 (n - m + 1) candidates dealt to the lanes, lane bests reduced through the wave; the m bytes of the winner, its window start (on its
+// strand) and its strand are written per record.  Records shorter than m: the lowest such index is left in *bad (the reference panics
+// there, src/sequence.rs:141); records longer than long_record are skipped here (the host runs the one-block kernel on each).
+__global__ __launch_bounds__(256) void minimizer_batch_kernel(const uint8_t *seq, const uint64_t *offs, uint64_t n_records, uint32_t m, uint64_t long_record,
+                                                              const uint16_t *comp, uint8_t *out, uint64_t *pos_out, uint8_t *rc_out, unsigned long long *bad)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_records; r += waves) {
+        const uint64_t b0 = offs[r] - offs[0], n = offs[r + 1] - offs[r];
+        if (n < m) { if (lane == 0) atomicMin(bad, (unsigned long long)r); continue; }
+        if (n > long_record) continue;
+        const uint8_t *rec = seq + b0;
+        const uint64_t ncand2 = 2 * (n - m + 1);
+        uint64_t bc = lane;                       // candidate number 2 i + strand; lanes beyond the candidates hold none (~0)
+        if (bc >= ncand2) bc = ~0ull;
+        for (uint64_t c = (uint64_t)lane + 64; c < ncand2; c += 64)
+            if (cand_less(rec, n, comp, m, c >> 1, (uint32_t)(c & 1), bc >> 1, (uint32_t)(bc & 1))) bc = c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t oc = ((uint64_t)(uint32_t)__shfl_down((int)(bc >> 32), o, 64) << 32) | (uint32_t)__shfl_down((int)(uint32_t)bc, o, 64);
+            if (lane + (uint32_t)o < 64u && oc != ~0ull && (bc == ~0ull || cand_less(rec, n, comp, m, oc >> 1, (uint32_t)(oc & 1), bc >> 1, (uint32_t)(bc & 1)))) bc = oc;
+        }
+        const uint64_t win = ((uint64_t)(uint32_t)__shfl((int)(bc >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bc, 0, 64);
+        for (uint32_t j = lane; j < m; j += 64) out[r * m + j] = cand_byte(rec, n, comp, win >> 1, (uint32_t)(win & 1), j);
+        if (lane == 0) {
+            if (pos_out) pos_out[r] = win >> 1;
+            if (rc_out) rc_out[r] = (uint8_t)(win & 1);
+        }
+    }
+}
+// (the one-block kernel's result for record r of a batch, written like the wave kernel writes its own)
+__global__ void minimizer_emit_record_kernel(const uint8_t *rec, uint64_t n, uint32_t m, const uint16_t *comp, const uint64_t *best, uint64_t r, uint8_t *out,
+                                             uint64_t *pos_out, uint8_t *rc_out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) out[r * m + j] = cand_byte(rec, n, comp, best[0], (uint32_t)best[1], j);
+    if (j == 0) {
+        if (pos_out) pos_out[r] = best[0];
+        if (rc_out) rc_out[r] = (uint8_t)best[1];
+    }
 }
 __global__ void minimizer_emit_kernel(const uint8_t *seq, uint64_t n, uint32_t m, const uint16_t *comp, const uint64_t *best, uint8_t *out)
 {

@@ -210,6 +210,29 @@ def minimizer(seq: bytes, length: int, ctx: Context = None) -> bytes:
     return out.raw[:length]
 
 
+def minimizer_batch(records, length: int, ctx: Context = None, with_positions: bool = False):
+    """sequence::minimizer (reference src/sequence.rs:139-152) for every record of a batch in one device pass (ntk_minimizer_batch):
+    the list of minimizers; with_positions: (minimizers, window starts on the winning strand's string, is_rc flags).  A record shorter
+    than `length` raises ValueError naming it (the reference panics there)."""
+    c = _ctx(ctx)
+    if length < 1:
+        raise ValueError("length must be >= 1")
+    n = len(records)
+    if n == 0:
+        return ([], np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint8)) if with_positions else []
+    seq, offs = _pack_records(records)
+    out = np.empty(n * length, dtype=np.uint8)
+    pos = np.empty(n, dtype=np.uint64)
+    flg = np.empty(n, dtype=np.uint8)
+    bad = C.c_uint64(0)
+    rc = L.lib().ntk_minimizer_batch(c._h, seq, offs.ctypes.data, n, length, out.ctypes.data, pos.ctypes.data, flg.ctypes.data, C.byref(bad))
+    if rc != L.NTK_OK and bad.value != 0xFFFFFFFFFFFFFFFF:
+        raise ValueError(f"record {bad.value} is shorter than the minimizer length {length}")
+    L.check(rc, "ntk_minimizer_batch")
+    mins = [out[i * length:(i + 1) * length].tobytes() for i in range(n)]
+    return (mins, pos, flg) if with_positions else mins
+
+
 def canonical(seq: bytes, ctx: Context = None) -> bytes:
     """sequence::canonical (reference src/sequence.rs:110-134): the lower of seq and its reverse complement."""
     c = _ctx(ctx)

@@ -97,6 +97,7 @@ extern "C" {
     pub fn ntk_pinned_free(p: *mut c_void);
     pub fn ntk_minimizers_reduce_device(ctx: *mut NtkCtx, d_seq: *const u8, n_bytes: u64, p: *const NtkParams, w: u32) -> c_int;
     pub fn ntk_minimizer(ctx: *mut NtkCtx, seq: *const u8, n: u64, m: u32, out: *mut u8) -> c_int;
+    pub fn ntk_minimizer_batch(ctx: *mut NtkCtx, seq: *const u8, offsets: *const u64, n_records: u64, m: u32, out: *mut u8, pos_out: *mut u64, is_rc_out: *mut u8, bad_record: *mut u64) -> c_int;
     pub fn ntk_canonical(ctx: *mut NtkCtx, seq: *const u8, n: u64, out: *mut u8, was_rc: *mut c_int) -> c_int;
     pub fn ntk_bit_minimizers(ctx: *mut NtkCtx, values: *const u64, n: u64, k: u32, m: u32, out: *mut u64) -> c_int;
     pub fn ntk_bit_canonical(ctx: *mut NtkCtx, values: *const u64, n: u64, k: u32, canonical: c_int, out: *mut u64, was_rc_out: *mut u8) -> c_int;
@@ -210,6 +211,17 @@ impl AmdBitKmersBatch {
     pub fn iter(&self, i: usize) -> impl Iterator<Item = (usize, (u64, u8), bool)> + '_ {
         (self.starts[i]..self.starts[i + 1]).map(move |j| (self.pos[j] as usize, (self.val[j], self.k), self.was_rc[j] != 0))
     }
+}
+
+/// `sequence::minimizer(seq, length)` (reference src/sequence.rs:139-152) for every record of a reader batch in one call
+/// (`ntk_minimizer_batch`): `mins[r * length .. (r + 1) * length]` = record r's minimizer, `pos[r]` the winning window's start on its
+/// strand's string, `is_rc[r]` its strand.  A record shorter than `length` is an error (the reference panics there).
+pub fn minimizer_batch(ctx: &AmdContext, seq: &[u8], offsets: &[u64], length: u32) -> Result<(Vec<u8>, Vec<u64>, Vec<u8>), AmdError> {
+    let n = offsets.len().saturating_sub(1);
+    let (mut mins, mut pos, mut is_rc) = (vec![0u8; n * length as usize], vec![0u64; n], vec![0u8; n]);
+    let mut bad = 0u64;
+    check(unsafe { ntk_minimizer_batch(ctx.0, seq.as_ptr(), offsets.as_ptr(), n as u64, length, mins.as_mut_ptr(), pos.as_mut_ptr(), is_rc.as_mut_ptr(), &mut bad) })?;
+    Ok((mins, pos, is_rc))
 }
 
 /// The fast path: what the README loop (src/lib.rs:15-35) becomes.  Records go into pinned batches; a full batch is

@@ -136,6 +136,21 @@ def test_cpp_mirror_quality_and_minimizers_on_gpu():
         want += [f"{i}:{p}:{kmer.decode()}:{int(f)}" for p, kmer, f in O.canonical_kmers(rec, rc, 2)]
     assert lines[18] == "planes" and int(lines[19]) == len(want)
     assert lines[20:20 + len(want)] == want
+    # minimizer_batch: sequence::minimizer per record (the reference's literal among them), window start and strand of the winner
+    at = 20 + len(want)
+    assert lines[at] == "minimizer_batch"
+    got = lines[at + 1: at + 4]
+    exp = []
+    for rec in (b"ATTTCG", b"ACGT", b"TTGGCA"):
+        rcs = O.reverse_complement(rec)
+        best = None
+        for i in range(len(rec) - 3 + 1):          # the reference's loop order: forward window i, then reverse-complement window i
+            for st, strand in ((0, rec), (1, rcs)):
+                if best is None or strand[i:i + 3] < best[0]:
+                    best = (strand[i:i + 3], i, st)
+        assert best[0] == O.minimizer(rec, 3)
+        exp.append(f"{best[0].decode()}:{best[1]}:{best[2]}")
+    assert got == exp and got[0].startswith("AAA:")
 
 
 def _c_smoke():

@@ -1310,3 +1310,57 @@ def test_reset_flag_starts_a_new_result(ctx, monkeypatch):
         assert bt.append(r, pre)
     bt.submit(21, path, pre, reset=True); bt.wait(); bt.release()
     assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, 21, True, True, True), "reset batch")
+
+
+def _ref_minimizer_with_position(rec: bytes, m: int):
+    """sequence::minimizer restated WITH the winner's window start and strand: the reference's loop order (src/sequence.rs:143-150: forward
+    window i, then reverse-complement window i, i ascending, strict <) decides between equal byte strings."""
+    rcs = O.reverse_complement(rec)
+    best = None
+    for i in range(len(rec) - m + 1):
+        for st, strand in ((0, rec), (1, rcs)):
+            c = strand[i:i + m]
+            if best is None or c < best[0]:
+                best = (c, i, st)
+    return best
+
+
+def test_minimizer_batch_matches_the_reference_function_per_record(ctx):
+    """ntk_minimizer_batch = sequence::minimizer (reference src/sequence.rs:139-152) applied to every record of a reader batch in one call:
+    raw-byte comparison (mixed case, N, IUPAC, U - complement() maps what it maps), homopolymers and repeats (ties: the reference's loop order
+    decides which window is reported), records of exactly m bytes, a record beyond 64 KiB (the one-block kernel), the reference's own literal;
+    a record shorter than m fails the call and names itself; the empty batch."""
+    import ctypes as C
+    from needletail_amd import _lib as L
+    rng = np.random.default_rng(41)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnURYKMSWBDHV", dtype=np.uint8)
+    assert nt.minimizer_batch([b"ATTTCG"], 3, ctx) == [b"AAA"]                      # reference src/sequence.rs:363-367
+    assert nt.minimizer_batch([], 5, ctx) == []
+    for m in (1, 2, 3, 8, 15, 21, 31, 40):
+        recs = [bytes(alphabet[rng.integers(0, len(alphabet), int(n))]) for n in rng.integers(m, 300, 120)]
+        recs += [b"A" * m, b"T" * (m + 5), b"AC" * (m + 3), bytes(rng.choice(list(b"ACGT"), size=m).astype(np.uint8))]
+        h = bytes(rng.choice(list(b"ACGT"), size=m + 20).astype(np.uint8))
+        recs += [h + O.reverse_complement(h), h + b"N" + h]
+        mins, pos, flg = nt.minimizer_batch(recs, m, ctx, with_positions=True)
+        for r, rec in enumerate(recs):
+            want = _ref_minimizer_with_position(rec, m)
+            assert want[0] == O.minimizer(rec, m)
+            assert (mins[r], int(pos[r]), int(flg[r])) == want, (m, r, rec)
+    # a long record goes through the one-block kernel; its neighbours through the wave kernel
+    long_rec = O.synth_reads(0x5EED0003, 0, 1, 70_000, 4).tobytes()[:70_000]
+    recs = [b"GATTACAGATTACA", long_rec, b"TTTTTTTTTTTTTTTTTTTTTTTTT"]
+    mins, pos, flg = nt.minimizer_batch(recs, 12, ctx, with_positions=True)
+    assert mins[0] == O.minimizer(recs[0], 12) and mins[2] == O.minimizer(recs[2], 12)
+    assert mins[1] == O.minimizer(long_rec, 12)
+    rc_long = O.reverse_complement(long_rec)
+    assert (rc_long if flg[1] else long_rec)[int(pos[1]): int(pos[1]) + 12] == mins[1]
+    # offsets that do not start at 0
+    seq = b"NNNNN" + b"".join(recs[:1] + recs[2:])
+    offs = np.array([5, 5 + len(recs[0]), 5 + len(recs[0]) + len(recs[2])], dtype=np.uint64)
+    out = np.zeros(2 * 12, dtype=np.uint8)
+    bad = C.c_uint64(0)
+    L.check(L.lib().ntk_minimizer_batch(ctx._h, seq, offs.ctypes.data, 2, 12, out.ctypes.data, None, None, C.byref(bad)), "ntk_minimizer_batch")
+    assert out[:12].tobytes() == mins[0] and out[12:].tobytes() == mins[2] and bad.value == 2 ** 64 - 1
+    # a record shorter than m: the call fails before computing anything and names the record
+    with pytest.raises(ValueError, match="record 1 "):
+        nt.minimizer_batch([b"ACGTACGT", b"ACG", b"ACGTACGT"], 5, ctx)

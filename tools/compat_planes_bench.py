@@ -49,3 +49,17 @@ for chunk in (4 << 20, 8 << 20, 32 << 20, 64 << 20):
         dt = time.perf_counter() - t0
         b2 = dt if b2 is None else min(b2, dt)
     print(f"   chunk {chunk >> 20:3d} MiB: {b2 * 1e3:.2f} ms = {reads * read_len / b2 / 1e9:.1f} Gbases/s")
+os.environ.pop("NTK_COMPAT_CHUNK_BYTES", None)
+# sequence::minimizer per record for the same batch (ntk_minimizer_batch): one upload, one wave per record, n_records x m bytes back
+for m in (21, 31):
+    mout = pinned(reads * m, np.uint8)
+    mpos, mflg = pinned(reads * 8, np.uint64), pinned(reads, np.uint8)
+    bad = C.c_uint64(0)
+    b3 = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        L.check(L.lib().ntk_minimizer_batch(ctx._h, C.cast(flat.ctypes.data, C.c_char_p), offs.ctypes.data, reads, m, mout.ctypes.data, mpos.ctypes.data,
+                                            mflg.ctypes.data, C.byref(bad)), "ntk_minimizer_batch")
+        dt = time.perf_counter() - t0
+        b3 = dt if b3 is None else min(b3, dt)
+    print(f"minimizer_batch m = {m}: {reads} reads, {b3 * 1e3:.2f} ms = {reads * read_len / b3 / 1e9:.1f} Gbases/s ({reads / b3 / 1e6:.1f} M records/s)")

@@ -183,6 +183,16 @@ def main():
             recs = [buf[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
             if not recs:
                 continue
+            if rng.random() < 0.25:
+                # sequence::minimizer per record (ntk_minimizer_batch) against the oracle's per-record function; records shorter than m dropped
+                mm = int(rng.choice([1, 2, 5, k, 31, 40]))
+                keep = [r for r in recs if len(r) >= mm]
+                if keep:
+                    got = nt.minimizer_batch(keep, mm, ctx)
+                    if any(g != O.minimizer(r, mm) for g, r in zip(got, keep)):
+                        print("MISMATCH minimizer_batch", tag, "m", mm); return 1
+                    counts["minimizer_batch"] = counts.get("minimizer_batch", 0) + 1
+                continue
             u3 = rng.random()
             if u3 < 0.34:
                 # the bit-plane form: any k <= 255 (the raw-byte kernel), records uploaded without break bytes
