@@ -1318,6 +1318,95 @@ int compat_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint6
     *total = items;
     return NTK_OK;
 }
+// sequence::minimizer per record (ntk_minimizer_batch): the same three stages on three streams and three banks as compat_planes - upload
+// [copy stream] -> wave-per-record kernel [ctx stream] -> download of the chunk's minimizers / window starts / strands [down stream].
+int minimizer_batch_impl(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t m, uint8_t *out, uint64_t *pos_out,
+                         uint8_t *is_rc_out)
+{
+    constexpr uint64_t kLongRecord = 1ull << 16;
+    constexpr int kBanks = (int)(sizeof(c->bank) / sizeof(c->bank[0]));
+    const uint64_t chunk_bytes = compat_chunk_bytes();
+    struct Chunk { uint64_t r0, r1, nb; };
+    std::vector<Chunk> chunks;
+    try {
+        for (uint64_t r0 = 0; r0 < n_records;) {
+            uint64_t r1 = r0 + 1;
+            while (r1 < n_records && offsets[r1 + 1] - offsets[r0] <= chunk_bytes) r1++;
+            chunks.push_back({r0, r1, offsets[r1] - offsets[r0]});
+            r0 = r1;
+        }
+    } catch (...) { return NTK_ERR_NOMEM; }
+    int rc = NTK_OK;
+    for (CompatBank &b : c->bank) if ((rc = bank_init(c, b))) return rc;
+    const uint16_t *comp = (const uint16_t *)(c->d_lut + 768);
+    auto hip_fail = [&](hipError_t e) { g_last_hip = (int)e; return NTK_ERR_HIP; };
+    auto retire = [&](CompatBank &b) -> int {
+        if (!b.busy) return NTK_OK;
+        if (hipEventSynchronize(b.ev_done) != hipSuccess) { g_last_hip = (int)hipGetLastError(); return NTK_ERR_HIP; }
+        b.busy = false;
+        return NTK_OK;
+    };
+    auto upload = [&](size_t ci) -> int {
+        const Chunk &ch = chunks[ci];
+        CompatBank &b = c->bank[ci % kBanks];
+        const uint64_t nrec = ch.r1 - ch.r0;
+        int r;
+        if ((r = retire(b))) return r;
+        if ((r = bank_scratch(c, b, 0, ch.nb + 16))) return r;
+        if ((r = bank_scratch(c, b, 5, (size_t)(nrec + 1) * 8))) return r;
+        if ((r = bank_scratch(c, b, 2, (size_t)nrec * m))) return r;
+        if ((r = bank_scratch(c, b, 3, (size_t)nrec * 8))) return r;
+        if ((r = bank_scratch(c, b, 1, (size_t)nrec))) return r;
+        if ((r = bank_scratch(c, b, 4, 64))) return r;
+        hipError_t e;
+        if ((e = hipMemcpyAsync(b.d[0].p, seq + offsets[ch.r0], ch.nb, hipMemcpyHostToDevice, c->copy_stream))) return hip_fail(e);
+        if ((e = hipMemcpyAsync(b.d[5].p, offsets + ch.r0, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, c->copy_stream))) return hip_fail(e);
+        if ((e = hipEventRecord(b.ev_total, c->copy_stream))) return hip_fail(e);
+        return NTK_OK;
+    };
+    auto compute_and_download = [&](size_t ci) -> int {
+        const Chunk &ch = chunks[ci];
+        CompatBank &b = c->bank[ci % kBanks];
+        const uint64_t nrec = ch.r1 - ch.r0;
+        hipError_t e;
+        if ((e = hipStreamWaitEvent(c->stream, b.ev_total, 0))) return hip_fail(e);
+        if ((e = hipMemsetAsync(b.d[4].p, 0xFF, 8, c->stream))) return hip_fail(e);
+        const uint64_t blocks = (nrec + 3) / 4;
+        hipLaunchKernelGGL(minimizer_batch_kernel, dim3((unsigned)(blocks < (uint64_t)c->n_cu * 16 ? blocks : (uint64_t)c->n_cu * 16)), dim3(256), 0, c->stream,
+                           (const uint8_t *)b.d[0].p, (const uint64_t *)b.d[5].p, nrec, m, kLongRecord, comp, (uint8_t *)b.d[2].p, (uint64_t *)b.d[3].p,
+                           (uint8_t *)b.d[1].p, (unsigned long long *)b.d[4].p);
+        for (uint64_t r = ch.r0; r < ch.r1; r++) {   // the rare long record: the one-block kernel of ntk_minimizer, on the uploaded bytes
+            const uint64_t n = offsets[r + 1] - offsets[r];
+            if (n <= kLongRecord) continue;
+            const uint8_t *rec = (const uint8_t *)b.d[0].p + (offsets[r] - offsets[ch.r0]);
+            uint64_t *d_best = (uint64_t *)b.d[4].p + 1;
+            hipLaunchKernelGGL(minimizer_bytes_kernel, dim3(1), dim3(1024), 0, c->stream, rec, n, m, comp, d_best);
+            hipLaunchKernelGGL(minimizer_emit_record_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, rec, n, m, comp, (const uint64_t *)d_best, r - ch.r0,
+                               (uint8_t *)b.d[2].p, (uint64_t *)b.d[3].p, (uint8_t *)b.d[1].p);
+        }
+        if ((e = hipGetLastError())) return hip_fail(e);
+        if ((e = hipEventRecord(b.ev_scattered, c->stream))) return hip_fail(e);
+        if ((e = hipStreamWaitEvent(c->down_stream, b.ev_scattered, 0))) return hip_fail(e);
+        if ((e = hipMemcpyAsync(out + ch.r0 * m, b.d[2].p, (size_t)nrec * m, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
+        if (pos_out && (e = hipMemcpyAsync(pos_out + ch.r0, b.d[3].p, (size_t)nrec * 8, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
+        if (is_rc_out && (e = hipMemcpyAsync(is_rc_out + ch.r0, b.d[1].p, (size_t)nrec, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
+        if ((e = hipEventRecord(b.ev_done, c->down_stream))) return hip_fail(e);
+        b.busy = true;
+        return NTK_OK;
+    };
+    if (!chunks.empty()) rc = upload(0);
+    for (size_t ci = 0; ci < chunks.size() && rc == NTK_OK; ci++) {
+        if (ci + 1 < chunks.size() && (rc = upload(ci + 1))) break;
+        rc = compute_and_download(ci);
+    }
+    const hipError_t e0 = hipStreamSynchronize(c->down_stream);
+    const hipError_t e1 = e0 != hipSuccess ? e0 : hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->copy_stream);
+    for (CompatBank &b : c->bank) b.busy = false;
+    bank_trim(c);
+    if (rc != NTK_OK) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) { g_last_hip = (int)(e1 != hipSuccess ? e1 : e2); return NTK_ERR_HIP; }
+    return NTK_OK;
+}
 }  // namespace
 
 int ntk_canonical_kmers_batch_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
@@ -1474,8 +1563,8 @@ int ntk_minimizer(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint32_t m, uint8_
     return NTK_OK;
 }
 
-/* sequence::minimizer for every record of a reader batch in one call: one upload, one wave per record (one block for a record beyond
- * 64 KiB), one download of n_records x m bytes (+ the optional window starts and strands). */
+/* sequence::minimizer for every record of a reader batch in one call: chunks of <= 16 MiB uploaded back to back, one wave per record (one
+ * block for a record beyond 64 KiB), the chunk's n x m bytes (+ the optional window starts and strands) downloaded behind the next upload. */
 int ntk_minimizer_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t m, uint8_t *out, uint64_t *pos_out,
                         uint8_t *is_rc_out, uint64_t *bad_record)
 {
@@ -1491,39 +1580,7 @@ int ntk_minimizer_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets,
     }
     if (!seq) return NTK_ERR_BAD_ARG;   // (every record holds at least m >= 1 bytes)
     HIPCHK(hipSetDevice(c->device));
-    constexpr uint64_t kLongRecord = 1ull << 16;
-    const uint64_t total = offsets[n_records] - offsets[0];
-    const size_t out_bytes = (size_t)n_records * m;
-    // scratch 1: offsets | window starts | minimizers | strands | bad-record word + the one-block kernel's (index, strand) pair
-    const size_t o_off = 0, o_pos = o_off + (size_t)(n_records + 1) * 8, o_out = o_pos + (size_t)n_records * 8,
-                 o_rc = (o_out + out_bytes + 15) & ~(size_t)15, o_bad = (o_rc + (size_t)n_records + 15) & ~(size_t)15, o_end = o_bad + 32;
-    int rc;
-    if ((rc = ensure_scratch(c, 0, total + 16))) return rc;
-    if ((rc = ensure_scratch(c, 1, o_end))) return rc;
-    uint8_t *d_in = (uint8_t *)c->scratch[0].p, *d1 = (uint8_t *)c->scratch[1].p;
-    uint64_t *d_offs = (uint64_t *)(d1 + o_off), *d_pos = (uint64_t *)(d1 + o_pos), *d_bad = (uint64_t *)(d1 + o_bad);
-    uint8_t *d_out = d1 + o_out, *d_rc = d1 + o_rc;
-    const uint16_t *comp = (const uint16_t *)(c->d_lut + 768);
-    HIPCHK(hipMemcpyAsync(d_in, seq + offsets[0], total, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_offs, offsets, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(d_bad, 0xFF, 8, c->stream));
-    const uint64_t blocks = (n_records + 3) / 4;
-    hipLaunchKernelGGL(minimizer_batch_kernel, dim3((unsigned)(blocks < (uint64_t)c->n_cu * 16 ? blocks : (uint64_t)c->n_cu * 16)), dim3(256), 0, c->stream,
-                       (const uint8_t *)d_in, (const uint64_t *)d_offs, n_records, m, kLongRecord, comp, d_out, d_pos, d_rc, (unsigned long long *)d_bad);
-    for (uint64_t r = 0; r < n_records; r++) {   // the rare long record: the one-block kernel of ntk_minimizer, on the uploaded bytes
-        const uint64_t n = offsets[r + 1] - offsets[r];
-        if (n <= kLongRecord) continue;
-        const uint8_t *rec = d_in + (offsets[r] - offsets[0]);
-        hipLaunchKernelGGL(minimizer_bytes_kernel, dim3(1), dim3(1024), 0, c->stream, rec, n, m, comp, d_bad + 1);
-        hipLaunchKernelGGL(minimizer_emit_record_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, rec, n, m, comp, (const uint64_t *)(d_bad + 1), r, d_out,
-                           d_pos, d_rc);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    if (pos_out) HIPCHK(hipMemcpyAsync(pos_out, d_pos, (size_t)n_records * 8, hipMemcpyDeviceToHost, c->stream));
-    if (is_rc_out) HIPCHK(hipMemcpyAsync(is_rc_out, d_rc, (size_t)n_records, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return NTK_OK;
+    return minimizer_batch_impl(c, seq, offsets, n_records, m, out, pos_out, is_rc_out);
 }
 
 int ntk_canonical(ntk_ctx *c, const uint8_t *seq, uint64_t n, uint8_t *out, int *was_rc)

@@ -1927,28 +1927,58 @@ __global__ __launch_bounds__(1024) void minimizer_bytes_kernel(const uint8_t *se
 // 2 (n - m + 1) candidates dealt to the lanes, lane bests reduced through the wave; the m bytes of the winner, its window start (on its
 // strand) and its strand are written per record.  Records shorter than m: the lowest such index is left in *bad (the reference panics
 // there, src/sequence.rs:141); records longer than long_record are skipped here (the host runs the one-block kernel on each).
+// (a record of up to kMinStage bytes is staged in LDS once, both strands - the candidates' bytes then come from there instead of
+// global loads through the complement table: 3.5 -> 1.x ms per 1 M x 150 bp)
+constexpr uint32_t kMinStage = 1024;
+__device__ __forceinline__ bool staged_less(const uint8_t *fw, const uint8_t *rc, uint32_t m, uint32_t ca, uint32_t cb)   // candidates 2 i + strand
+{
+    const uint8_t *a = ((ca & 1u) ? rc : fw) + (ca >> 1), *b = ((cb & 1u) ? rc : fw) + (cb >> 1);
+    for (uint32_t j = 0; j < m; j++)
+        if (a[j] != b[j]) return a[j] < b[j];
+    return ca < cb;
+}
 __global__ __launch_bounds__(256) void minimizer_batch_kernel(const uint8_t *seq, const uint64_t *offs, uint64_t n_records, uint32_t m, uint64_t long_record,
                                                               const uint16_t *comp, uint8_t *out, uint64_t *pos_out, uint8_t *rc_out, unsigned long long *bad)
 {
-    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ uint8_t s_stage[4][2][kMinStage];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_records; r += waves) {
+    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv; r < n_records; r += waves) {
         const uint64_t b0 = offs[r] - offs[0], n = offs[r + 1] - offs[r];
         if (n < m) { if (lane == 0) atomicMin(bad, (unsigned long long)r); continue; }
         if (n > long_record) continue;
         const uint8_t *rec = seq + b0;
         const uint64_t ncand2 = 2 * (n - m + 1);
-        uint64_t bc = lane;                       // candidate number 2 i + strand; lanes beyond the candidates hold none (~0)
-        if (bc >= ncand2) bc = ~0ull;
-        for (uint64_t c = (uint64_t)lane + 64; c < ncand2; c += 64)
-            if (cand_less(rec, n, comp, m, c >> 1, (uint32_t)(c & 1), bc >> 1, (uint32_t)(bc & 1))) bc = c;
+        uint64_t win;
+        if (n <= kMinStage) {
+            uint8_t *fw = s_stage[wv][0], *rcs = s_stage[wv][1];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the previous record's readers are done: one wave, in-order LDS)
+            for (uint32_t j = lane; j < (uint32_t)n; j += 64) { const uint8_t by = rec[j]; fw[j] = by; rcs[(uint32_t)n - 1 - j] = (uint8_t)comp[by]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t bc = lane < (uint32_t)ncand2 ? lane : ~0u;
+            for (uint32_t c = lane + 64; c < (uint32_t)ncand2; c += 64)
+                if (staged_less(fw, rcs, m, c, bc)) bc = c;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint64_t oc = ((uint64_t)(uint32_t)__shfl_down((int)(bc >> 32), o, 64) << 32) | (uint32_t)__shfl_down((int)(uint32_t)bc, o, 64);
-            if (lane + (uint32_t)o < 64u && oc != ~0ull && (bc == ~0ull || cand_less(rec, n, comp, m, oc >> 1, (uint32_t)(oc & 1), bc >> 1, (uint32_t)(bc & 1)))) bc = oc;
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t oc = (uint32_t)__shfl_down((int)bc, o, 64);
+                if (lane + (uint32_t)o < 64u && oc != ~0u && (bc == ~0u || staged_less(fw, rcs, m, oc, bc))) bc = oc;
+            }
+            win = (uint32_t)__shfl((int)bc, 0, 64);
+            const uint8_t *src = ((win & 1) ? rcs : fw) + (win >> 1);
+            for (uint32_t j = lane; j < m; j += 64) out[r * m + j] = src[j];
+        } else {
+            uint64_t bc = lane;                       // candidate number 2 i + strand; lanes beyond the candidates hold none (~0)
+            if (bc >= ncand2) bc = ~0ull;
+            for (uint64_t c = (uint64_t)lane + 64; c < ncand2; c += 64)
+                if (cand_less(rec, n, comp, m, c >> 1, (uint32_t)(c & 1), bc >> 1, (uint32_t)(bc & 1))) bc = c;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t oc = ((uint64_t)(uint32_t)__shfl_down((int)(bc >> 32), o, 64) << 32) | (uint32_t)__shfl_down((int)(uint32_t)bc, o, 64);
+                if (lane + (uint32_t)o < 64u && oc != ~0ull && (bc == ~0ull || cand_less(rec, n, comp, m, oc >> 1, (uint32_t)(oc & 1), bc >> 1, (uint32_t)(bc & 1)))) bc = oc;
+            }
+            win = ((uint64_t)(uint32_t)__shfl((int)(bc >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bc, 0, 64);
+            for (uint32_t j = lane; j < m; j += 64) out[r * m + j] = cand_byte(rec, n, comp, win >> 1, (uint32_t)(win & 1), j);
         }
-        const uint64_t win = ((uint64_t)(uint32_t)__shfl((int)(bc >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bc, 0, 64);
-        for (uint32_t j = lane; j < m; j += 64) out[r * m + j] = cand_byte(rec, n, comp, win >> 1, (uint32_t)(win & 1), j);
         if (lane == 0) {
             if (pos_out) pos_out[r] = win >> 1;
             if (rc_out) rc_out[r] = (uint8_t)(win & 1);

@@ -1325,13 +1325,16 @@ def _ref_minimizer_with_position(rec: bytes, m: int):
     return best
 
 
-def test_minimizer_batch_matches_the_reference_function_per_record(ctx):
+@pytest.mark.parametrize("chunk_bytes", [None, 97, 4096])
+def test_minimizer_batch_matches_the_reference_function_per_record(ctx, monkeypatch, chunk_bytes):
     """ntk_minimizer_batch = sequence::minimizer (reference src/sequence.rs:139-152) applied to every record of a reader batch in one call:
     raw-byte comparison (mixed case, N, IUPAC, U - complement() maps what it maps), homopolymers and repeats (ties: the reference's loop order
     decides which window is reported), records of exactly m bytes, a record beyond 64 KiB (the one-block kernel), the reference's own literal;
     a record shorter than m fails the call and names itself; the empty batch."""
     import ctypes as C
     from needletail_amd import _lib as L
+    if chunk_bytes:   # the upload / kernel / download pipeline over hundreds of chunks (the default is 16 MiB: one chunk here)
+        monkeypatch.setenv("NTK_COMPAT_CHUNK_BYTES", str(chunk_bytes))
     rng = np.random.default_rng(41)
     alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnURYKMSWBDHV", dtype=np.uint8)
     assert nt.minimizer_batch([b"ATTTCG"], 3, ctx) == [b"AAA"]                      # reference src/sequence.rs:363-367
@@ -1341,6 +1344,8 @@ def test_minimizer_batch_matches_the_reference_function_per_record(ctx):
         recs += [b"A" * m, b"T" * (m + 5), b"AC" * (m + 3), bytes(rng.choice(list(b"ACGT"), size=m).astype(np.uint8))]
         h = bytes(rng.choice(list(b"ACGT"), size=m + 20).astype(np.uint8))
         recs += [h + O.reverse_complement(h), h + b"N" + h]
+        # around the LDS staging limit of the wave kernel (1024 bytes) and well beyond it (candidates read from global memory)
+        recs += [bytes(alphabet[rng.integers(0, len(alphabet), n)]) for n in (1023, 1024, 1025, 3000)] if m in (3, 21) else []
         mins, pos, flg = nt.minimizer_batch(recs, m, ctx, with_positions=True)
         for r, rec in enumerate(recs):
             want = _ref_minimizer_with_position(rec, m)
