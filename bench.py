@@ -416,11 +416,32 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
             if not (np.array_equal(pos_i, arrs[3][o:o + n_i].astype(np.int64)) and np.array_equal(rbits[pos_i], arrs[4][o:o + n_i])):
                 raise SystemExit("secondary: the bit planes and the item arrays disagree on record %d" % i)
             o += n_i
+        # sequence::minimizer (reference src/sequence.rs:139-152) for every record of the same batch in one call (ntk_minimizer_batch);
+        # a prefix against the oracle's per-record function
+        mh = [pinned(nb, dt_) for nb, dt_ in ((c_reads * 21, np.uint8), (c_reads * 8, np.uint64), (c_reads, np.uint8))]
+        m_out, m_pos, m_flg = (a for _, a in mh)
+        bad = C.c_uint64(0)
+        best_mb = None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            L.check(L.lib().ntk_minimizer_batch(ctx._h, C.cast(arrs[0].ctypes.data, C.c_char_p), arrs[1].ctypes.data, c_reads, 21, m_out.ctypes.data,
+                                                m_pos.ctypes.data, m_flg.ctypes.data, C.byref(bad)), "ntk_minimizer_batch")
+            dt = time.perf_counter() - t0
+            best_mb = dt if best_mb is None else min(best_mb, dt)
+        for i in range(500):
+            rec_i = arrs[0][int(arrs[1][i]): int(arrs[1][i + 1])].tobytes()
+            if m_out[i * 21:(i + 1) * 21].tobytes() != O.minimizer(rec_i, 21):
+                raise SystemExit("secondary: ntk_minimizer_batch differs from the oracle's sequence::minimizer on record %d" % i)
+        minimizer_batch_line = {"call": "ntk_minimizer_batch", "records": c_reads, "length": 21, "seconds": round(best_mb, 4),
+                                "Mrecords_s": round(c_reads / best_mb / 1e6, 1), "Gbases_s": round(c_reads * read_len / best_mb / 1e9, 2),
+                                "note": "sequence::minimizer per record, page-locked arrays, PCIe-inclusive (bound by the upload); 500 records checked against the oracle"}
+        for h, _ in mh:
+            L.lib().ntk_pinned_free(h)
         for h, _ in hp:
             L.lib().ntk_pinned_free(h)
         for h in handles:
             L.lib().ntk_pinned_free(h)
-        del arrs, handles, src, offs, hp, rec_bit, v16, r16
+        del arrs, handles, src, offs, hp, rec_bit, v16, r16, mh, m_out, m_pos, m_flg
         out["compat_batch_face_k21"] = {"call": "ntk_canonical_kmers_batch_planes", "records": c_reads, "items": items,
                                         "seconds": round(best_pl, 4), "Gbases_s": round(c_reads * read_len / best_pl / 1e9, 2),
                                         "Mitems_s": round(items / best_pl / 1e6, 1), "bytes_out_per_base": 0.25,
@@ -433,6 +454,7 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
                                                              "GB_s_out": round(items * 9 / best_pin / 1e9, 1),
                                                              "pageable_arrays": {"seconds": round(best_pg, 4),
                                                                                  "Gbases_s": round(c_reads * read_len / best_pg / 1e9, 2)}}}
+        out["minimizer_batch_m21"] = minimizer_batch_line
     except (nt.NtkError, AttributeError) as e:  # pragma: no cover
         out["compat_batch_face_k21"] = {"error": str(e)}
     ctx.accum_reset()
