@@ -284,3 +284,19 @@ def test_synth_reads_deterministic():
     assert 0.0005 < frac_n < 0.0015
     # SplitMix64 reference value (public test vector: seed 0 first output)
     assert O.splitmix64_at(0, 0) == 0xE220A8397B1DCDAF
+
+
+def test_minimizer_with_position_restatement_agrees_with_the_oracle():
+    """tests/_refs.py minimizer_with_position (what the ntk_minimizer_batch tests check window start and strand against) returns the
+    oracle's sequence::minimizer bytes, and its start / strand point at them (reference src/sequence.rs:139-152; literal :363-367)."""
+    import numpy as np
+    from _refs import minimizer_with_position
+    assert minimizer_with_position(b"ATTTCG", 3) == (b"AAA", 2, 1)   # reverse complement CGAAAT, window 2
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGTACGTacgtNURYKM", dtype=np.uint8)
+    for _ in range(300):
+        rec = bytes(alphabet[rng.integers(0, len(alphabet), int(rng.integers(1, 80)))])
+        m = int(rng.integers(1, len(rec) + 1))
+        got, start, is_rc = minimizer_with_position(rec, m)
+        assert got == O.minimizer(rec, m)
+        assert (O.reverse_complement(rec) if is_rc else rec)[start:start + m] == got
