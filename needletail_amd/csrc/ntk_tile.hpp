@@ -52,6 +52,9 @@ struct ScanArgs {
     uint32_t min_w, min_halo_lanes;
     uint32_t min_smear[6];
     uint32_t min_overlap;    // w - 2^floor(log2 w): the shift between the two overlapping power-of-two windows that make a window of w
+    // k + w - 1 <= 49: ONE smear of the break bits over the k + w - 1 window ends a break spoils (own 16 + 48 earlier positions fit 64 bits)
+    // instead of the k smear followed by the w smear; min_smear_kw[0] == 0: not used
+    uint32_t min_smear_kw[6];
 };
 
 // Fills the k-derived fields (host side).  k must be 1..32.
@@ -485,13 +488,18 @@ NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lan
     }
     const uint32_t c1 = xl.prev_auto(en.code), c2 = xl.prev_auto(c1);
     const uint32_t r1 = xl.prev_auto(en.rcode);
-    const uint32_t b1 = xl.prev_auto(en.bad), b2 = xl.prev_auto(b1);
-    uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;   // windows of k containing a break (as lane_tile)
+    if (a.min_smear_kw[0]) {
+        // k + w - 1 <= 49: the break bits themselves, smeared once over k + w - 1 by the caller
+        inval = en.bad;
+    } else {
+        const uint32_t b1 = xl.prev_auto(en.bad), b2 = xl.prev_auto(b1);
+        uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;   // windows of k containing a break (as lane_tile)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
-    inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+        for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+        inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    }
     // Q = (rcode : r1 : r2 : r3) >> (64 - 2k), Q[3] the least significant word; the value whose top group is own base j sits at Q bits
     // [34 + 2j, 34 + 2j + 2k)
     const uint32_t sh = 64u - 2u * a.k;   // 14 .. 62
@@ -545,13 +553,18 @@ NTK_HD void minimizer_windows(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane
         sink.lane16 = lane * 16u;
         lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, lane_base, lane < (uint32_t)kHaloLanes, tail_tile);
     }
-    // window validity: a k-mer that is invalid takes the w windows it is part of with it
+    // window validity: a k-mer that is invalid takes the w windows it is part of with it (f64 keys with k + w - 1 <= 49: sink.inval holds
+    // the break bits and ONE smear over k + w - 1 does both steps)
     const uint32_t b1 = xl.prev_auto(sink.inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
     uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | sink.inval;
+    const bool one_smear = F64 && a.min_smear_kw[0] != 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 6; i++) bw |= bw >> a.min_smear[i];
+    for (int i = 0; i < 6; i++) {
+        const uint32_t sft = one_smear ? a.min_smear_kw[i] : a.min_smear[i];
+        if (sft) bw |= bw >> sft;   // (wave-uniform)
+    }
     invw = lane < a.min_halo_lanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
     // sliding minimum over W: M doubles while 2q <= W, then two overlapping windows of q make W (every branch is wave-uniform)
     const uint32_t W = a.min_w;
@@ -584,6 +597,10 @@ inline void scan_args_set_window(ScanArgs &a, uint32_t w)
     a.min_overlap = w - q;
     uint32_t len = 1;
     for (int i = 0; i < 6; i++) { const uint32_t sft = len < w ? (len < w - len ? len : w - len) : 0; a.min_smear[i] = sft; len += sft; }
+    const uint32_t kw = a.k + w - 1;   // (scan_args_set_k first)
+    len = 1;
+    for (int i = 0; i < 6; i++) { const uint32_t sft = kw <= 49 && len < kw ? (len < kw - len ? len : kw - len) : 0; a.min_smear_kw[i] = sft; len += sft; }
+    if (kw == 1) a.min_smear_kw[0] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
