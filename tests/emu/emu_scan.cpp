@@ -489,6 +489,17 @@ int emu_minimizers_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, ui
     return 0;
 }
 
+// ... with the quality stream of the QM builds: bases whose quality byte is below `cutoff` (1..255) are breaks.
+int emu_minimizers_generic_quality(const uint8_t *buf, const uint8_t *qual, uint32_t cutoff, uint64_t n, uint64_t n_padded, uint32_t k, uint32_t w,
+                                   int tie_rc, int accept_u, int f64, uint64_t *out)
+{
+    if (cutoff < 1 || cutoff > 255 || !qual) return -1;
+    g_qual = qual; g_qc = quality_cut(cutoff);
+    const int rc = emu_minimizers_generic(buf, n, n_padded, k, w, tie_rc, accept_u, f64, out);
+    g_qual = nullptr;
+    return rc;
+}
+
 int emu_window_masks(const uint64_t *g16, uint32_t k, uint64_t *ok16, uint64_t *ab16)
 {
     uint64_t G[16];

@@ -372,3 +372,29 @@ def test_emu_generic_minimizers_every_window_length(emu):
         for k, f64 in ((19, 1), (27, 0)):
             want = O.minimizers_reduce(b, k, w, accept_u=True, tie_rc=True)
             assert_stats_equal(emu_minimizers_generic(emu, b, k, w, 1, 1, f64), want, (k, w, f64))
+
+
+def test_emu_generic_minimizers_with_a_quality_stream(emu):
+    """The QM builds of the generic fused minimizer kernel: the quality tile folded into the sequence bytes (quality_break16) ahead of the same
+    per-lane source; against the oracle's quality_mask followed by the literal minimizer of every window."""
+    rng = np.random.default_rng(37)
+    L = emu
+    L.emu_minimizers_generic_quality.restype = C.c_int
+    L.emu_minimizers_generic_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                                 C.c_int, C.c_void_p]
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNU\n", dtype=np.uint8)
+    for trial in range(6):
+        n = int(rng.integers(200, 2600))
+        b = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        q = rng.integers(33, 75, n, dtype=np.uint8)
+        if trial % 2:
+            q[:] = 73; q[rng.integers(0, n, max(1, n // 40))] = 34
+        npad = (n + 15) // 16 * 16
+        arr = np.frombuffer(b + b"\xAA" * (npad - n), dtype=np.uint8).copy()
+        qarr = np.frombuffer(q.tobytes() + b"\x49" * (npad - n), dtype=np.uint8).copy()
+        for k, w, cutoff, f64 in ((23, 11, 50, 1), (31, 19, 60, 0), (12, 33, 40, 1), (17, 16, 35, 0), (25, 49, 45, 1)):
+            out = np.zeros(4 + 4096, dtype=np.uint64)
+            assert L.emu_minimizers_generic_quality(arr.ctypes.data, qarr.ctypes.data, cutoff, n, npad, k, w, 1, 1, f64, out.ctypes.data) == 0
+            got = {"n_total": int(out[0]), "n_fwd": int(out[1]), "n_rc": int(out[0] - out[1]), "sum": int(out[2]), "xor": int(out[3]), "hist": out[4:].copy()}
+            want = O.minimizers_reduce(O.quality_mask(b, q.tobytes(), cutoff), k, w, accept_u=True, tie_rc=True)
+            assert_stats_equal(got, want, (trial, k, w, cutoff, f64))
