@@ -198,3 +198,28 @@ def test_rust_binding_is_generated_from_the_header():
     # every declared function is used or at least visible to the adapters below the block; the struct mirrors keep their layout
     assert "pub struct NtkParams { pub k: u32, pub path: u32, pub pre: u32, pub flags: u32 }" in rs
     assert os.path.exists(os.path.join(ROOT, "rust", "build.rs"))
+
+
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md section 1 maps the C ABI to the reference interface it replaces: every symbol the header declares is named there
+    (literally, or as a member of an `ntk_prefix_a / b / c` group)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "needletail_amd.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    syms = sorted(set(re.findall(r"\b(ntk_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(syms) >= 64
+    groups = re.findall(r"`(ntk_[a-z0-9_]+(?: / [a-z0-9_]+)+)`", doc)   # `ntk_reader_open_file / open_memory / next`
+    grouped = set()
+    for g in groups:
+        parts = g.split(" / ")
+        head = parts[0]
+        grouped.add(head)
+        prefix = head[: head.rfind("_") + 1]
+        for tail in parts[1:]:
+            for cut in range(len(head), 3, -1):   # the shared prefix is some `ntk_..._` of the first member
+                if head[cut - 1] == "_" and (head[:cut] + tail) in syms:
+                    grouped.add(head[:cut] + tail)
+                    break
+    wild = [w[:-1] for w in re.findall(r"`(ntk_[a-z0-9_]+\*)`", doc)]      # `ntk_accum_*`
+    missing = [s for s in syms if s not in doc and s not in grouped and not any(s.startswith(w) for w in wild)]
+    assert not missing, missing
