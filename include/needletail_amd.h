@@ -124,6 +124,20 @@ int ntk_ctx_synchronize(ntk_ctx *ctx);
  * 1024; 0 = auto: the largest of 768 / 640 / 512 that keeps two blocks of a reduce build resident per CU - 768 for every shipped
  * build; materialise mode always runs 256-thread blocks). */
 int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
+/* Test / A-B support, per ctx (the library's dispatch reads no environment variable): value 0 restores an option's default.
+ *   NTK_OPT_COMPAT_CHUNK_BYTES     bytes per chunk of the batched compat faces (default 16 MiB; the suites force hundreds of chunks
+ *                                  out of small batches with it; values below 64 are taken as 64)
+ *   NTK_OPT_MINIMIZER_CHUNK_BYTES  input bytes per pass of the two-pass minimizer route (default 256 MiB; a multiple of 4096)
+ *   NTK_OPT_MINIMIZER_ROUTE        NTK_ROUTE_NO_* bits: routes of ntk_minimizers_reduce_device switched OFF - the register-fused
+ *                                  builds, the generic fused kernel (both off = materialise + window-min), the v_min_f64 keys of the
+ *                                  generic kernel (k <= 25 then runs the general keys) - so that each route can be checked against
+ *                                  the others on the same input
+ *   NTK_OPT_COMPAT_PACK_THREADS    host threads that pack a chunk of the item-array compat faces (default 8) */
+enum { NTK_OPT_COMPAT_CHUNK_BYTES = 1, NTK_OPT_MINIMIZER_CHUNK_BYTES = 2, NTK_OPT_MINIMIZER_ROUTE = 3, NTK_OPT_COMPAT_PACK_THREADS = 4 };
+#define NTK_ROUTE_NO_REGFUSED 1u
+#define NTK_ROUTE_NO_GENERIC 2u
+#define NTK_ROUTE_NO_F64 4u
+int ntk_ctx_set_option(ntk_ctx *ctx, int option, uint64_t value);
 /* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */
 int ntk_ctx_enable_timing(ntk_ctx *ctx, int on);

@@ -103,6 +103,7 @@ public:
     CanonicalKmersPlanes(const uint8_t *seq, const std::vector<uint64_t> &offsets, uint8_t k, Context &c = Context::global())
         : k_(k), offsets_(offsets), rec_bit_(offsets.size())
     {
+        if (offsets.empty()) return;   // no offsets at all = zero records (n + 1 entries describe n records)
         const uint64_t n = offsets.size() - 1, cap = (offsets[n] - offsets[0]) / 16 + n + 1;
         valid16_.resize(cap); rc16_.resize(cap);
         uint64_t words = 0;

@@ -16,13 +16,17 @@ PRE_NONE, PRE_STRIP_RETURNS, PRE_NORMALIZE, PRE_NORMALIZE_IUPAC = 0, 1, 2, 3
 HIST_BINS = 4096
 ACC_N_TOTAL, ACC_N_FWD, ACC_N_RC, ACC_SUM, ACC_XOR, ACC_HIST = 0, 1, 2, 3, 4, 8
 ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
+# ntk_ctx_set_option (test / A-B support)
+OPT_COMPAT_CHUNK_BYTES, OPT_MINIMIZER_CHUNK_BYTES, OPT_MINIMIZER_ROUTE, OPT_COMPAT_PACK_THREADS = 1, 2, 3, 4
+ROUTE_NO_REGFUSED, ROUTE_NO_GENERIC, ROUTE_NO_F64 = 1, 2, 4
+ROUTE_TWO_PASS = ROUTE_NO_REGFUSED | ROUTE_NO_GENERIC
 
 # every symbol include/needletail_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
     "ntk_strerror", "ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version", "ntk_device_count",
     "ntk_comm_init_all", "ntk_comm_unique_id", "ntk_comm_init_rank", "ntk_comm_size", "ntk_allreduce_accumulators", "ntk_comm_allreduce_time_ms", "ntk_comm_destroy",
     "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
-    "ntk_ctx_set_launch", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
+    "ntk_ctx_set_launch", "ntk_ctx_set_option", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
     "ntk_accum_reset", "ntk_reduce_device", "ntk_reduce_device_quality", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
     "ntk_materialize_device", "ntk_materialize_device_quality",
     "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_append_quality", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
@@ -101,6 +105,7 @@ def lib() -> C.CDLL:
     L.ntk_ctx_destroy.argtypes = [vp]
     L.ntk_ctx_synchronize.argtypes = [vp]
     L.ntk_ctx_set_launch.argtypes = [vp, i32, i32]
+    L.ntk_ctx_set_option.argtypes = [vp, i32, u64]
     L.ntk_ctx_enable_timing.argtypes = [vp, i32]
     L.ntk_ctx_scan_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.ntk_accum_reset.argtypes = [vp]

@@ -119,7 +119,11 @@ struct ntk_ctx {
     uint32_t *d_part_hist = nullptr;
     uint32_t *d_work = nullptr;     // kMaxShards work counters, one per 64-B line
     bool work_dirty = true;         // not known to be zero
-    uint64_t minimizer_chunk = (uint64_t)256 << 20;  // bytes of input per minimizer pass (NTK_MINIMIZER_CHUNK_BYTES: test hook)
+    // ntk_ctx_set_option (test / A-B support, per ctx: nothing in the dispatch reads the environment)
+    uint64_t minimizer_chunk = (uint64_t)256 << 20;  // NTK_OPT_MINIMIZER_CHUNK_BYTES: bytes of input per two-pass minimizer pass
+    uint64_t compat_chunk = (uint64_t)16 << 20;      // NTK_OPT_COMPAT_CHUNK_BYTES: packed bytes per chunk of the batched compat faces
+    uint32_t route_off = 0;                          // NTK_OPT_MINIMIZER_ROUTE: NTK_ROUTE_NO_* bits
+    uint32_t pack_threads = 8;                       // NTK_OPT_COMPAT_PACK_THREADS
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
@@ -373,7 +377,7 @@ const void *pick_min_generic(const Mode &m, bool quality, bool f64)   // f64: k 
 #define NTK_PICK_MG4(KW, Q, F) NTK_PICK_MG(KW, false, false, Q, F) NTK_PICK_MG(KW, false, true, Q, F) NTK_PICK_MG(KW, true, false, Q, F) NTK_PICK_MG(KW, true, true, Q, F)
     NTK_PICK_MG4(2, false, true) NTK_PICK_MG4(2, true, true)
     NTK_PICK_MG4(2, false, false) NTK_PICK_MG4(2, true, false)   // 26 <= k <= 31
-    NTK_PICK_MG4(1, false, false) NTK_PICK_MG4(1, true, false)   // (only under NTK_MINGEN_NO_F64, the A/B switch)
+    NTK_PICK_MG4(1, false, false) NTK_PICK_MG4(1, true, false)   // (only under NTK_ROUTE_NO_F64, the A/B switch)
 #undef NTK_PICK_MG4
 #undef NTK_PICK_MG
     return nullptr;
@@ -383,7 +387,7 @@ int run_min_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params 
 {
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;
-    const void *fn = pick_min_generic(m, cutoff != 0, p->k <= 25 && !getenv("NTK_MINGEN_NO_F64"));
+    const void *fn = pick_min_generic(m, cutoff != 0, p->k <= 25 && !(c->route_off & NTK_ROUTE_NO_F64));
     if (!fn) return NTK_ERR_BAD_ARG;
     const int threads = 256;
     int per_cu = 0;
@@ -498,10 +502,6 @@ int init_ctx(ntk_ctx *c, void *stream, bool borrow)
     build_strip_lut(h + 512);
     build_complement_lut(h + 768);
     HIPCHK(hipMemcpyAsync(c->d_lut, h, 4 * 256 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    if (const char *e = getenv("NTK_MINIMIZER_CHUNK_BYTES")) {
-        const uint64_t v = strtoull(e, nullptr, 10);
-        if (v >= 4096) c->minimizer_chunk = v & ~(uint64_t)4095;
-    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return NTK_OK;
 }
@@ -593,6 +593,32 @@ int ntk_ctx_set_launch(ntk_ctx *c, int blocks, int threads)
     if (!c || blocks < 0 || threads < 0 || threads > 1024 || (threads & 63)) return NTK_ERR_BAD_ARG;   // threads 0 = automatic
     c->launch_blocks = blocks; c->launch_threads = threads;
     return NTK_OK;
+}
+
+int ntk_ctx_set_option(ntk_ctx *c, int option, uint64_t value)
+{
+    if (!c) return NTK_ERR_BAD_ARG;
+    switch (option) {
+    case NTK_OPT_COMPAT_CHUNK_BYTES:      // 0 = default; below 64 bytes is taken as 64 (a stray 1 would cost a launch and an event wait per record)
+        c->compat_chunk = value == 0 ? ((uint64_t)16 << 20) : (value < 64 ? 64 : value);
+        return NTK_OK;
+    case NTK_OPT_MINIMIZER_CHUNK_BYTES:   // 0 = default; a multiple of 4096, at least 4096
+        if (value && value < 4096) return NTK_ERR_BAD_ARG;
+        c->minimizer_chunk = value == 0 ? ((uint64_t)256 << 20) : (value & ~(uint64_t)4095);
+        return NTK_OK;
+    case NTK_OPT_MINIMIZER_ROUTE:
+        if (value & ~(uint64_t)(NTK_ROUTE_NO_REGFUSED | NTK_ROUTE_NO_GENERIC | NTK_ROUTE_NO_F64)) return NTK_ERR_BAD_ARG;
+        c->route_off = (uint32_t)value;
+        return NTK_OK;
+    case NTK_OPT_COMPAT_PACK_THREADS: {   // 0 = default (8); capped by the hardware threads and 64
+        uint64_t v = value ? value : 8;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && v > hw) v = hw;
+        c->pack_threads = (uint32_t)(v > 64 ? 64 : v);
+        return NTK_OK;
+    }
+    default: return NTK_ERR_BAD_ARG;
+    }
 }
 
 int ntk_ctx_enable_timing(ntk_ctx *c, int on)
@@ -1005,18 +1031,7 @@ namespace {
 // chunk's D2H has finished, and with two the host would wait for D2H(c-1) - enqueued a moment ago - before it could pack chunk
 // c+1 (measured: 3.85 ms per chunk = 2.35 ms of copies + 1.5 ms of packing in series, profiles/r03b/compat_trace.txt).
 // Caller arrays may be pageable or pinned (ntk_pinned_alloc).
-constexpr uint64_t kCompatChunkBytes = (uint64_t)16 << 20;
-// NTK_COMPAT_CHUNK_BYTES is a test hook (many chunks from small batches; the suites switch it between calls, so it is read per call -
-// one getenv against milliseconds of work).  Values below 64 bytes are taken as 64: a stray "1" would cost a launch and an event
-// wait per record.
-uint64_t compat_chunk_bytes()
-{
-    const char *e = getenv("NTK_COMPAT_CHUNK_BYTES");
-    if (!e) return kCompatChunkBytes;
-    const long long x = atoll(e);
-    if (x <= 0) return kCompatChunkBytes;
-    return (uint64_t)(x < 64 ? 64 : x);
-}
+// (chunk size: ntk_ctx::compat_chunk, 16 MiB; NTK_OPT_COMPAT_CHUNK_BYTES lets the suites force many chunks out of small batches)
 // The banks keep their staging and device buffers between calls (re-allocation costs milliseconds); what a call leaves behind above
 // this many bytes per bank is released when it returns (a single 10-kb-record batch used to pin ~1.2 GiB until ctx_destroy).
 constexpr size_t kBankKeepBytes = (size_t)512 << 20;   // a 16 MiB chunk of the bit path needs ~420 MiB per bank: kept; more than that: released
@@ -1076,7 +1091,7 @@ int compat_stage_a(ntk_ctx *c, CompatBank &b, const CompatJob &j, uint64_t r0, u
     uint8_t *h_seq = (uint8_t *)b.h_stage + (size_t)(nrec + 1) * 8;
     // record r of the chunk lands at offsets[r0 + r] - offsets[r0] + r (one break byte after every record before it): the
     // packing splits over threads without a prefix pass (one core packs ~5 GB/s of 150-byte records - less than the PCIe link
-    // takes back - so a chunk is packed by up to NTK_COMPAT_PACK_THREADS threads, default 8)
+    // takes back - so a chunk is packed by up to ntk_ctx::pack_threads threads, default 8)
     const uint64_t o0 = j.offsets[r0];
     auto pack = [&](uint64_t ra, uint64_t rb) {
         for (uint64_t r = ra; r < rb; r++) {
@@ -1086,15 +1101,7 @@ int compat_stage_a(ntk_ctx *c, CompatBank &b, const CompatJob &j, uint64_t r0, u
             h_seq[w + len] = '\n';
         }
     };
-    static const unsigned pack_threads = [] {
-        const char *e = getenv("NTK_COMPAT_PACK_THREADS");
-        long v = e ? atol(e) : 8;
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (v < 1) v = 1;
-        if (hw && (unsigned long)v > hw) v = (long)hw;
-        return (unsigned)(v > 64 ? 64 : v);
-    }();
-    const unsigned nth = (unsigned)std::min<uint64_t>(pack_threads, n / (256 << 10) + 1);   // a thread per 256 KiB at least
+    const unsigned nth = (unsigned)std::min<uint64_t>(c->pack_threads, n / (256 << 10) + 1);   // a thread per 256 KiB at least
     if (nth <= 1) pack(0, nrec);
     else {
         // a thread that cannot be created (thread / cgroup limit: std::system_error, bad_alloc) must not unwind across the C ABI:
@@ -1189,7 +1196,7 @@ int compat_batch(ntk_ctx *c, const CompatJob &j, uint64_t n_records, uint64_t *t
     for (CompatBank &b : c->bank) if ((rc = bank_init(c, b))) return rc;
     uint64_t items = 0, r0 = 0;
     int cur = 0, prev = -1;
-    const uint64_t chunk_bytes = compat_chunk_bytes();
+    const uint64_t chunk_bytes = c->compat_chunk;
     constexpr int kBanks = (int)(sizeof(c->bank) / sizeof(c->bank[0]));
     while (r0 < n_records && rc == NTK_OK) {
         // the chunk: records up to chunk_bytes packed bytes (at least one record)
@@ -1225,7 +1232,7 @@ int compat_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint6
                   uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words, uint64_t *total)
 {
     for (uint64_t r = 0; r < n_records; r++) if (offsets[r] > offsets[r + 1]) return NTK_ERR_BAD_ARG;
-    const uint64_t chunk_bytes = compat_chunk_bytes();
+    const uint64_t chunk_bytes = c->compat_chunk;
     constexpr int kBanks = (int)(sizeof(c->bank) / sizeof(c->bank[0]));
     // pass 1 (host): the chunks and the words they need
     struct Chunk { uint64_t r0, r1, wbase, nb; };
@@ -1325,7 +1332,7 @@ int minimizer_batch_impl(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets
 {
     constexpr uint64_t kLongRecord = 1ull << 16;
     constexpr int kBanks = (int)(sizeof(c->bank) / sizeof(c->bank[0]));
-    const uint64_t chunk_bytes = compat_chunk_bytes();
+    const uint64_t chunk_bytes = c->compat_chunk;
     struct Chunk { uint64_t r0, r1, nb; };
     std::vector<Chunk> chunks;
     try {
@@ -1492,13 +1499,13 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     if (!m.canon) return NTK_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
     // fused build (one pass, nothing written to HBM) where one exists - with a quality stream: the quality-masked builds
-    if (n && !getenv("NTK_MINIMIZERS_TWO_PASS")) {
+    if (n) {
         const bool masked = d_qual && quality_cutoff(p);
-        const void *fn = getenv("NTK_MINIMIZERS_NO_REGFUSED") ? nullptr : pick_scan_min(m, p->k, w, masked);   // (A/B switch)
+        const void *fn = (c->route_off & NTK_ROUTE_NO_REGFUSED) ? nullptr : pick_scan_min(m, p->k, w, masked);   // (route bits: ntk_ctx_set_option)
         if (fn)
             return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, masked ? d_qual : nullptr, fn);
         // every other (k <= 31, w <= 49): the generic fused kernel (one pass as well, run-time k and w)
-        if (p->k <= 31 && w <= 49 && !getenv("NTK_MINIMIZERS_NO_GENERIC"))
+        if (p->k <= 31 && w <= 49 && !(c->route_off & NTK_ROUTE_NO_GENERIC))
             return run_min_scan(c, d_seq, n, p, m, w, masked ? d_qual : nullptr);
     }
     if (p->flags & NTK_FLAG_RESET) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
@@ -1806,21 +1813,25 @@ int ntk_allreduce_accumulators(ntk_comm *m)
         rc = get_event(c0, &e1); if (rc) { c0->ev_free.push_back(e0); return rc; }
         HIPCHK(hipEventRecord(e0, c0->stream));
     }
-    RCCLCHK(R.GroupStart());
+    // from here on a failure hands the event pair back to the ctx's pool (the timing of this call is lost, the events are not)
+    auto fail = [&](int status) { if (e0) { c0->ev_free.push_back(e0); c0->ev_free.push_back(e1); } return status; };
+    ncclResult_t r = R.GroupStart();
+    if (r != ncclSuccess) { g_last_rccl = (int)r; return fail(NTK_ERR_RCCL); }
     for (size_t i = 0; i < m->ctxs.size(); i++) {
         ntk_ctx *c = m->ctxs[i];
-        ncclResult_t r = R.AllReduce(c->d_acc, c->d_acc, NTK_ACC_WORDS, ncclUint64, ncclSum, m->comms[i], c->stream);
-        if (r != ncclSuccess) { (void)R.GroupEnd(); g_last_rccl = (int)r; return NTK_ERR_RCCL; }
+        r = R.AllReduce(c->d_acc, c->d_acc, NTK_ACC_WORDS, ncclUint64, ncclSum, m->comms[i], c->stream);
+        if (r != ncclSuccess) { (void)R.GroupEnd(); g_last_rccl = (int)r; return fail(NTK_ERR_RCCL); }
     }
-    RCCLCHK(R.GroupEnd());
+    if ((r = R.GroupEnd()) != ncclSuccess) { g_last_rccl = (int)r; return fail(NTK_ERR_RCCL); }
     for (ntk_ctx *c : m->ctxs) {
-        HIPCHK(hipSetDevice(c->device));
-        hipLaunchKernelGGL(xor_from_bit_counters_kernel, dim3(1), dim3(64), 0, c->stream, c->d_acc);
-        HIPCHK(hipGetLastError());
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) { hipLaunchKernelGGL(xor_from_bit_counters_kernel, dim3(1), dim3(64), 0, c->stream, c->d_acc); e = hipGetLastError(); }
+        if (e != hipSuccess) { g_last_hip = (int)e; return fail(NTK_ERR_HIP); }
     }
     if (e0) {
-        HIPCHK(hipSetDevice(c0->device));
-        HIPCHK(hipEventRecord(e1, c0->stream));
+        hipError_t e = hipSetDevice(c0->device);
+        if (e == hipSuccess) e = hipEventRecord(e1, c0->stream);
+        if (e != hipSuccess) { g_last_hip = (int)e; (void)hipGetLastError(); return fail(NTK_ERR_HIP); }
         m->ev_used.emplace_back(e0, e1);
     }
     return NTK_OK;
@@ -1852,6 +1863,8 @@ void ntk_comm_destroy(ntk_comm *m)
     if (!m) return;
     const RcclApi &R = load_rccl();
     if (R.ok) for (ncclComm_t h : m->comms) if (h) (void)R.CommDestroy(h);
+    // timing events of all-reduces nobody asked ntk_comm_allreduce_time_ms about: destroyed here (the ctx they were drawn from may be gone)
+    for (auto &p : m->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete m;
 }
 

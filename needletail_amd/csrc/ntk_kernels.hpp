@@ -15,6 +15,14 @@
 
 #include "ntk_tile.hpp"
 
+// Ablation switches (NTK_ABL_*: loads only, floor kernel, no LDS atomics, no digests, no exec writes, no SDWA compares, no mask algebra) and
+// the per-wave clock census (NTK_V_CLOCKS) exist for tools/kbench.hip alone, which is built with -DNTK_KBENCH: they produce WRONG results
+// by design and measure what a class of the tile loop costs (profiles/r03c/ablation.txt, r04i/ablation.txt).  No product object may see one.
+#if !defined(NTK_KBENCH) && (defined(NTK_ABL_LOADSONLY) || defined(NTK_ABL_FLOOR) || defined(NTK_ABL_NOLDS) || defined(NTK_ABL_NODIGEST) || \
+                             defined(NTK_ABL_NOEXEC) || defined(NTK_ABL_NOSDWA) || defined(NTK_ABL_NOMASKALG) || defined(NTK_V_CLOCKS))
+#error "NTK_ABL_* / NTK_V_CLOCKS are kernel-bench switches: build with -DNTK_KBENCH (tools/build_kbench.sh), never into the library"
+#endif
+
 namespace ntk {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -26,11 +34,7 @@ struct DevXL {
     __device__ __forceinline__ uint32_t prev_auto(uint32_t x) const { return prev(0, x); }   // (the host emulation numbers these call sites itself)
     __device__ __forceinline__ uint32_t prev(int, uint32_t x) const
     {
-#ifdef NTK_XL_BPERMUTE   // experiment: the cross-lane move on the LDS pipe (ds_bpermute_b32) instead of the VALU (lane 0 gets lane 63's value: a halo lane)
-        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + 63u) & 63u) << 2), (int)x);
-#else
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, kDppWaveShr1, 0xf, 0xf, true);
-#endif
     }
     // (the previous lane's x) + c in one DPP add
     __device__ __forceinline__ uint32_t prev_add(int, uint32_t x, uint32_t c) const
@@ -67,16 +71,10 @@ struct ReduceSink {
     {
         if (valid) {
             const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
-#ifndef NTK_ABL_NODIGEST
             sum += v;
             xr ^= v;
-#endif
             n_fwd += take_fwd ? 1u : 0u;  // v_addc_co_u32 off the compare's carry mask
-#ifndef NTK_ABL_NOHIST
             atomicAdd(&hist[KW == 2 ? (uint32_t)(v >> bin_shift) : (lo >> bin_shift)], 1u);  // no 64-bit shift for 32-bit values
-#else
-            n_valid += (uint32_t)(v >> bin_shift);
-#endif
         }
     }
     __device__ __forceinline__ void end_tile() {}
@@ -148,16 +146,10 @@ struct ReduceSinkSV {
     __device__ __forceinline__ void add(uint32_t hi, uint32_t lo, uint32_t off)
     {
         const uint64_t v = ((uint64_t)hi << 32) | lo;
-#ifndef NTK_ABL_NODIGEST
         sum += v;
         xr ^= v;
-#endif
-#ifndef NTK_ABL_NOHIST
         __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hist) + off), 1u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-        sum += off;
-#endif
     }
 };
 
@@ -240,9 +232,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     __shared__ uint32_t s_nfwd[SV ? 1024 : 1];  // sv builds: per-thread forward-strand counters
     extern __shared__ __attribute__((aligned(16))) uint64_t s_stage[];  // materialise mode: kStageWaveU64 u64 per wave (dynamic)
 
-#ifdef NTK_V_CLOCKS
-    const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
-#endif
     Sink sink;
     if constexpr (REDUCE) {
         for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
@@ -335,16 +324,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         next = __builtin_amdgcn_readfirstlane(next);
     }
 
-#ifdef NTK_V_CLOCKS
-    if ((threadIdx.x & 63) == 0 && a.values) {  // per-wave census: start, end, shader cycles, placement
-        uint32_t hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        a.values[w * 4 + 0] = dbg_w0; a.values[w * 4 + 1] = wall_clock64();
-        a.values[w * 4 + 2] = clock64() - dbg_c0; a.values[w * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
-    }
-#endif
     if constexpr (REDUCE) {
         // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
         uint64_t sum = sink.sum, xr = sink.xr, nf, nv;
@@ -449,23 +428,8 @@ struct DevMasks2 {
     // Byte offset of a histogram cell = the value's top HB bits, * 4.  (LDS atomics at an address that is not 4-byte aligned raise a
     // memory violation on gfx950 - measured - so the low two bits have to be cleared.)  _hi: the prefix sits in bits 31:16 of T,
     // _lo: in bits 15:0 (the second position of a packed minimum).
-    // NTK_LANE_CELLS (round-4 experiment): the 14-bit cell = the value's top 12 bits (the result bin) + TWO BITS OF THE LANE NUMBER, so that the
-    // lanes of a wave spread over the banks by construction (LDS bank conflicts: 2/3 of the LDS's busy time, profiles/r04c); LIGHT then needs
-    // 2K - 12 <= 32: the canonical builds with 17 <= K <= 22.
-    uint32_t lane_off = 0;   // (lane & 3) << 2
-    uint32_t mask_fff0 = 0xFFF0u;
-#ifdef NTK_LANE_CELLS
-    static constexpr bool kLaneCells = K >= 17 && K <= 22 && HB == 14;
-#else
-    static constexpr bool kLaneCells = false;
-#endif
     __device__ __forceinline__ uint32_t cell_offset_hi(uint32_t T) const
     {
-        if constexpr (kLaneCells) {
-            uint32_t off;
-            asm("v_bitop3_b32 %0, %1, %3, %2 bitop3:0xea" : "=v"(off) : "v"(T >> 16), "v"(lane_off), "v"(mask_fff0));   // ((T >> 16) & 0xFFF0) | lane_off, full-rate (all operands VGPRs)
-            return off;
-        }
         if (HB == 14) {
             uint32_t off;
             const uint32_t kMask = 0xFFFCu;   // (T >> 16) & 0xFFFC in one SDWA op
@@ -476,11 +440,6 @@ struct DevMasks2 {
     }
     __device__ __forceinline__ uint32_t cell_offset_lo(uint32_t T) const
     {
-        if constexpr (kLaneCells) {
-            uint32_t off;
-            asm("v_bitop3_b32 %0, %1, %3, %2 bitop3:0xea" : "=v"(off) : "v"(T), "v"(lane_off), "v"(mask_fff0));
-            return off;
-        }
         return HB == 14 ? (T & 0xFFFCu) : ((T >> 2) & 0x3FFCu);
     }
 
@@ -504,37 +463,16 @@ struct DevMasks2 {
 #else
 #define NTK_R_HIST(i) "ds_add_u32 %[o" #i "], %[one]\n"
 #endif
-#ifdef NTK_ABL_NOCOUNT     // ablation (wrong n_fwd): what the scalar forward count costs
-#define NTK_R_CNT_FIRST "s_mov_b32 %[nf], 0\n"
-#define NTK_R_CNT ""
-#define NTK_R_CNT_A ""
-#define NTK_R_CNT_B ""
-#else
 #define NTK_R_CNT_FIRST "s_bcnt1_i32_b64 %[nf], vcc\n"                                   /* the block's first position starts its count */
 #define NTK_R_CNT "s_bcnt1_i32_b64 %[cn], vcc\n s_add_u32 %[nf], %[nf], %[cn]\n"
-#define NTK_R_CNT_A "s_bcnt1_i32_b64 %[cn], vcc\n"
-#define NTK_R_CNT_B "s_add_u32 %[nf], %[nf], %[cn]\n"
-#endif
 #ifdef NTK_ABL_NODIGEST
 #define NTK_R_SUM_0(x) ""
 #define NTK_R_SUM_1(x) ""
 #define NTK_R_XOR(x) ""
 #else
-#ifdef NTK_ABL_NOSUM
-#define NTK_R_SUM_0(x) ""
-#define NTK_R_SUM_1(x) ""
-#elif defined(NTK_ABL_SUM32)   // ablation (wrong sum): the 64-bit sum as a full-rate 32-bit add
-#define NTK_R_SUM_0(x) "v_add_u32 %[sumA], %[sumA], " x "\n"
-#define NTK_R_SUM_1(x) "v_add_u32 %[sumB], %[sumB], " x "\n"
-#else
 #define NTK_R_SUM_0(x) "v_mad_u64_u32 %[sumA], %[sd], " x ", 1, %[sumA]\n"
 #define NTK_R_SUM_1(x) "v_mad_u64_u32 %[sumB], %[sd], " x ", 1, %[sumB]\n"
-#endif
-#ifdef NTK_ABL_NOXOR
-#define NTK_R_XOR(x) ""
-#else
 #define NTK_R_XOR(x) "v_xor_b32 %[xlo], %[xlo], " x "\n"
-#endif
 #endif
 #define NTK_R_SUM_2(x) NTK_R_SUM_0(x)
 #define NTK_R_SUM_3(x) NTK_R_SUM_1(x)
@@ -548,50 +486,16 @@ struct DevMasks2 {
         const uint32_t off[4] = {cell_offset_hi(Tm0), cell_offset_hi(Tm1), cell_offset_lo(Tm0), cell_offset_lo(Tm1)};
         uint32_t t0, t1, t2, t3, cn, nf_grp;
         uint64_t sd;
-#ifndef NTK_REGION_ORDER
-#define NTK_REGION_ORDER 0
-#endif
-#if NTK_REGION_ORDER == 0
-#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
+#define NTK_R_POS(i, CMP, CNT)                                              \
         NTK_R_EXEC(i)                                                       \
         CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
         "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
         NTK_R_SUM_##i("%[t" #i "]")                                         \
         NTK_R_XOR("%[t" #i "]")                                             \
         NTK_R_HIST(i)                                                       \
-        CNTA CNTB
-#elif NTK_REGION_ORDER == 1   /* a scalar op straight after each half-rate op: cmp, bcnt, cndmask, xor, mad, ds, add */
-#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
-        NTK_R_EXEC(i)                                                       \
-        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
-        CNTA                                                                \
-        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
-        NTK_R_XOR("%[t" #i "]")                                             \
-        NTK_R_SUM_##i("%[t" #i "]")                                         \
-        NTK_R_HIST(i)                                                       \
-        CNTB
-#elif NTK_REGION_ORDER == 2   /* cmp, bcnt, add, cndmask, xor, ds, mad */
-#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
-        NTK_R_EXEC(i)                                                       \
-        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
-        CNTA CNTB                                                           \
-        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
-        NTK_R_XOR("%[t" #i "]")                                             \
-        NTK_R_HIST(i)                                                       \
-        NTK_R_SUM_##i("%[t" #i "]")
-#else                          /* cmp, bcnt, cndmask, xor, add, mad, ds */
-#define NTK_R_POS(i, CMP, CNTA, CNTB)                                       \
-        NTK_R_EXEC(i)                                                       \
-        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                              \
-        CNTA                                                                \
-        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
-        NTK_R_XOR("%[t" #i "]")                                             \
-        CNTB                                                                \
-        NTK_R_SUM_##i("%[t" #i "]")                                         \
-        NTK_R_HIST(i)
-#endif
+        CNT
 #define NTK_R_IN(i) [o##i] "v"(off[i]), [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_R_MASKS(i)
-#define NTK_R_BODY(CMP) NTK_R_POS(0, CMP, NTK_R_CNT_FIRST, "") NTK_R_POS(1, CMP, NTK_R_CNT_A, NTK_R_CNT_B) NTK_R_POS(2, CMP, NTK_R_CNT_A, NTK_R_CNT_B) NTK_R_POS(3, CMP, NTK_R_CNT_A, NTK_R_CNT_B) "s_mov_b64 exec, -1\n"
+#define NTK_R_BODY(CMP) NTK_R_POS(0, CMP, NTK_R_CNT_FIRST) NTK_R_POS(1, CMP, NTK_R_CNT) NTK_R_POS(2, CMP, NTK_R_CNT) NTK_R_POS(3, CMP, NTK_R_CNT) "s_mov_b64 exec, -1\n"
 #define NTK_R_OPS                                                                                                                        \
         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),           \
           [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                                                                             \
@@ -613,101 +517,11 @@ struct DevMasks2 {
     // forward count is s_and (F with the window's validity, which is exec) + s_bcnt1 + s_add.  (Measured, k = 31, profiles/r03a/wide_ab.txt: the
     // select inside the region with separate sums of the lo and hi words costs 16 more VALU instructions per tile and is 4-8 % slower;
     // these builds are VALU-bound at 235 instructions per tile - scalar count, LDS count and the round-2 region all run within 1 %.)
-    // Round 4 experiment, NOT shipped (NTK_WIDE_REGION_INSIDE; profiles/r04b/wide_region_ab.txt): the whole position inside the region -
-    // compare into vcc (under the window's exec it is "valid and forward": the count is s_bcnt1 of vcc itself), lo and T selected by two
-    // v_cndmask on vcc (full-rate; the VOP3 select on an SGPR pair the compiler emits is half-rate, and v_min_u32 is), the hi word one
-    // full-rate shift of T, and the (lo : hi) pair for v_lshl_add_u64 built in two PINNED register pairs (v[70:71], v[72:73]; T in v74 /
-    // v75, the cell offset in v76 / v77 - clobbers, so that the asm can name the halves).  3 half-rate + 5 full-rate VALU ops per position
-    // where the shipped form has 5 + 3, i.e. 4 issue cycles fewer by the class costs - and 2.5 % SLOWER (0.559 against 0.545 ms at k = 31):
-    // everything of a position is now one dependent chain under its own exec mask, where the shipped form computes compare, minimum,
-    // select, shift and cell under the full mask, for the scheduler to interleave.  The same selects as a 4-instruction snippet outside
-    // the region (NTK_WIDE_VCC_SELECT: v_cmp -> vcc, two v_cndmask, s_mov of the mask): 1.4 % slower.
+    // (Round 4 measured the whole position inside the region with vcc selects and a pinned (lo : hi) pair - 4 issue cycles fewer per
+    // position by the class costs, 2.5 % SLOWER: one dependent chain under its own exec mask - and the same selects as a snippet outside:
+    // 1.4 % slower; profiles/r04b/wide_region_ab.txt.  Neither form is kept in the source.)
     template <bool TIE_RC_, class S>
-    __device__ __forceinline__ void emit_canon_wide(S &s_, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
-                                                    const uint32_t (&rl)[4])
-    {
-#ifndef NTK_WIDE_REGION_INSIDE
-        emit_canon_wide_r3<TIE_RC_>(s_, pos, ft, rt, fl, rl);
-#else
-        static_assert(!kLight && K >= 17, "wide builds");
-        constexpr int SH = 64 - 2 * K;
-        uint32_t cn, nf_grp;
-        const uint32_t kMask = 0xFFFCu;
-#define NTK_W_PAIR(i) NTK_W_PAIR_##i
-#define NTK_W_PAIR_0 "v[70:71]"
-#define NTK_W_PAIR_1 "v[72:73]"
-#define NTK_W_PAIR_2 "v[70:71]"
-#define NTK_W_PAIR_3 "v[72:73]"
-#define NTK_W_LO_0 "v70"
-#define NTK_W_LO_1 "v72"
-#define NTK_W_LO_2 "v70"
-#define NTK_W_LO_3 "v72"
-#define NTK_W_HI_0 "v71"
-#define NTK_W_HI_1 "v73"
-#define NTK_W_HI_2 "v71"
-#define NTK_W_HI_3 "v73"
-#define NTK_W_T_0 "v74"
-#define NTK_W_T_1 "v75"
-#define NTK_W_T_2 "v74"
-#define NTK_W_T_3 "v75"
-#define NTK_W_O_0 "v76"
-#define NTK_W_O_1 "v77"
-#define NTK_W_O_2 "v76"
-#define NTK_W_O_3 "v77"
-#define NTK_W_SUM_0 "%[sumA]"
-#define NTK_W_SUM_1 "%[sumB]"
-#define NTK_W_SUM_2 "%[sumA]"
-#define NTK_W_SUM_3 "%[sumB]"
-#ifdef NTK_ABL_NOLDS
-#define NTK_W_HIST(i) ""
-#else
-#define NTK_W_HIST(i) "ds_add_u32 " NTK_W_O_##i ", %[one]\n"
-#endif
-        // SHIFTED: hi = T >> SH through the T register; K = 32: the hi word IS the chosen T word
-#define NTK_W_POS(i, CMP, SEL_HI, CNT)                                                              \
-        NTK_R_EXEC(i)                                                                               \
-        CMP " vcc, %[ft" #i "], %[rt" #i "]\n"                                                      \
-        "v_cndmask_b32 " NTK_W_LO_##i ", %[rl" #i "], %[fl" #i "], vcc\n"                           \
-        SEL_HI(i)                                                                                   \
-        "v_lshl_add_u64 " NTK_W_SUM_##i ", " NTK_W_PAIR_##i ", 0, " NTK_W_SUM_##i "\n"             \
-        "v_xor_b32 %[xh], %[xh], " NTK_W_HI_##i "\n"                                                \
-        "v_xor_b32 %[xlo], %[xlo], " NTK_W_LO_##i "\n"                                              \
-        NTK_W_HIST(i)                                                                               \
-        CNT
-#define NTK_W_SEL_SHIFT(i)                                                                          \
-        "v_cndmask_b32 " NTK_W_T_##i ", %[rt" #i "], %[ft" #i "], vcc\n"                            \
-        "v_lshrrev_b32 " NTK_W_HI_##i ", %[sh], " NTK_W_T_##i "\n"                                  \
-        "v_and_b32_sdwa " NTK_W_O_##i ", %[km], " NTK_W_T_##i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-#define NTK_W_SEL_K32(i)                                                                            \
-        "v_cndmask_b32 " NTK_W_HI_##i ", %[rt" #i "], %[ft" #i "], vcc\n"                           \
-        "v_and_b32_sdwa " NTK_W_O_##i ", %[km], " NTK_W_HI_##i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-#define NTK_W_IN(i) [ft##i] "v"(ft[i]), [rt##i] "v"(rt[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), NTK_R_MASKS(i)
-#define NTK_W_BODY(CMP, SEL) NTK_W_POS(0, CMP, SEL, NTK_R_CNT_FIRST) NTK_W_POS(1, CMP, SEL, NTK_R_CNT) NTK_W_POS(2, CMP, SEL, NTK_R_CNT) NTK_W_POS(3, CMP, SEL, NTK_R_CNT) "s_mov_b64 exec, -1\n"
-#define NTK_W_OPS                                                                                                                        \
-        : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [xh] "+v"(xh), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                        \
-        : NTK_W_IN(0), NTK_W_IN(1), NTK_W_IN(2), NTK_W_IN(3), [one] "v"(one), [km] "s"(kMask), [sh] "n"(SH)                            \
-        : "memory", "vcc", "scc", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77"
-        static_assert(HB == 14, "the wide region forms the cell offset for the 14-bit histogram");
-        if constexpr (SH > 0) {
-            if constexpr (TIE_RC_) asm volatile(NTK_W_BODY("v_cmp_lt_u32", NTK_W_SEL_SHIFT) NTK_W_OPS);
-            else asm volatile(NTK_W_BODY("v_cmp_le_u32", NTK_W_SEL_SHIFT) NTK_W_OPS);
-        } else {
-            if constexpr (TIE_RC_) asm volatile(NTK_W_BODY("v_cmp_lt_u32", NTK_W_SEL_K32) NTK_W_OPS);
-            else asm volatile(NTK_W_BODY("v_cmp_le_u32", NTK_W_SEL_K32) NTK_W_OPS);
-        }
-        nf_s += nf_grp;
-#undef NTK_W_OPS
-#undef NTK_W_BODY
-#undef NTK_W_IN
-#undef NTK_W_SEL_K32
-#undef NTK_W_SEL_SHIFT
-#undef NTK_W_POS
-#undef NTK_W_HIST
-#endif
-    }
-
-    template <bool TIE_RC_, class S>
-    __device__ __forceinline__ void emit_canon_wide_r3(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
+    __device__ __forceinline__ void emit_canon_wide(S &, const int (&pos)[4], const uint32_t (&ft)[4], const uint32_t (&rt)[4], const uint32_t (&fl)[4],
                                                        const uint32_t (&rl)[4])
     {
         static_assert(!kLight && K >= 17, "wide builds");
@@ -716,20 +530,10 @@ struct DevMasks2 {
         uint64_t F[4], val[4], fm;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-#ifdef NTK_WIDE_VCC_SELECT   // compare into vcc, both selects on vcc (full-rate), the mask copied out for the count: 1 half-rate + 2 full-rate VALU ops
-            uint32_t T;     // + 1 scalar move where the compiler's form is 3 half-rate ops (VOP3 compare, v_min_u32, VOP3 select)
-            if constexpr (TIE_RC_)
-                asm("v_cmp_lt_u32 vcc, %[ft], %[rt]\n v_cndmask_b32 %[lo], %[rl], %[fl], vcc\n v_cndmask_b32 %[T], %[rt], %[ft], vcc\n s_mov_b64 %[F], vcc"
-                    : [lo] "=&v"(lo[i]), [T] "=&v"(T), [F] "=&s"(F[i]) : [ft] "v"(ft[i]), [rt] "v"(rt[i]), [fl] "v"(fl[i]), [rl] "v"(rl[i]) : "vcc");
-            else
-                asm("v_cmp_le_u32 vcc, %[ft], %[rt]\n v_cndmask_b32 %[lo], %[rl], %[fl], vcc\n v_cndmask_b32 %[T], %[rt], %[ft], vcc\n s_mov_b64 %[F], vcc"
-                    : [lo] "=&v"(lo[i]), [T] "=&v"(T), [F] "=&s"(F[i]) : [ft] "v"(ft[i]), [rt] "v"(rt[i]), [fl] "v"(fl[i]), [rl] "v"(rl[i]) : "vcc");
-#else
             const bool fwd = TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i];
             F[i] = __builtin_amdgcn_ballot_w64(fwd);   // the compare's own SGPR pair
             const uint32_t T = ft[i] < rt[i] ? ft[i] : rt[i];
             lo[i] = fwd ? fl[i] : rl[i];
-#endif
             hi[i] = SH ? T >> SH : T;
             off[i] = cell_offset_hi(T);
             val[i] = ((uint64_t)hi[i] << 32) | lo[i];
@@ -879,8 +683,6 @@ struct DevMasks2 {
 #undef NTK_R_SUM_2
 #undef NTK_R_SUM_1
 #undef NTK_R_SUM_0
-#undef NTK_R_CNT_B
-#undef NTK_R_CNT_A
 #undef NTK_R_CNT
 #undef NTK_R_CNT_FIRST
 #undef NTK_R_HIST
@@ -932,81 +734,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     DevMasks2<K, HB> mp;
     NoSink sink;
     mp.rep = lane & (uint32_t)(DevMasks2<K, HB>::kWordCopies - 1);
-    mp.lane_off = (lane & 3u) << 2;
-    asm volatile("v_mov_b32 %0, 0xfff0" : "=v"(mp.mask_fff0));   // a VGPR constant: v_bitop3 takes no literal, and an SGPR operand would make it half-rate
 
-#if defined(NTK_XCHUNK) && !defined(NTK_ABL_FLOOR) && !defined(NTK_SV2_PINGPONG)
-    // Round-4 experiment: the first tile of the NEXT chunk is loaded while the last tile of the current one is processed (the plain loop
-    // below starts every chunk with a load it waits for at once: ~1-2 us of HBM latency per 24 tiles and wave).
-    {
-        uint32_t r0 = 0, r1 = 0, voff = 0, pulled = 0;
-        uint64_t tile_byte = 0;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.seq, 0, 0, 0x00020000), rq = rs;
-        u32x4 ta = {0u, 0u, 0u, 0u}, qa = ta;
-        auto enter_chunk = [&](uint32_t nx) {   // sets the chunk's range and descriptors and issues the load of its first tile
-            r0 = shard_begin + nx;
-            r1 = r0 + a.chunk_tiles;
-            if (r1 > shard_end) r1 = shard_end;
-            const uint64_t t0 = a.tile_begin + r0;
-            const uint64_t run_byte = t0 * kTileStride;
-            const uint32_t halo = t0 ? 32u : 0u;
-            const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
-            uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - (run_byte - halo);
-            if (rem > 0xFFFFFF00ull) rem = 0xFFFFFF00ull;
-            const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)cbase);
-            const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
-            const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)rem);
-            rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)bhi << 32) | blo), 0, nrec, 0x00020000);
-            if constexpr (QM) {
-                const uint64_t qbase = (uint64_t)a.qual + run_byte - halo;
-                const uint32_t qlo = __builtin_amdgcn_readfirstlane((uint32_t)qbase);
-                const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
-                rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qhi << 32) | qlo), 0, nrec, 0x00020000);
-            }
-            voff = lane * 16u - (32u - halo);
-            tile_byte = run_byte;
-            ta = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-            if constexpr (QM) qa = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
-        };
-        uint32_t next = 0;
-        if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
-        next = __builtin_amdgcn_readfirstlane(next);
-        if (next < shard_tiles) enter_chunk(next);
-        while (next < shard_tiles) {
-            if (lane == 0) pulled = atomicAdd(ctr, a.chunk_tiles);   // the chunk after this one: in flight while this one is processed
-            const uint32_t r_end = r1;
-            for (uint32_t r = r0; r < r_end; r++) {
-                const bool tail = r >= a.tail_tile_rel;
-                Raw16 raw{ta.x, ta.y, ta.z, ta.w};
-                if constexpr (QM) raw = quality_break16(raw, Raw16{qa.x, qa.y, qa.z, qa.w}, a.q_add, a.q_sel);
-#ifdef NTK_ABL_LOADSONLY
-                mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
-#else
-                const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
-                mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-#endif
-                // the registers of the tile are free: the next tile - of this chunk or the first one of the next - is loaded into them
-                if (r + 1 < r_end) {
-                    voff += kTileStride; tile_byte += kTileStride;
-                    ta = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-                    if constexpr (QM) qa = __builtin_amdgcn_raw_buffer_load_b128(rq, voff, 0, 0);
-                } else {
-                    next = __builtin_amdgcn_readfirstlane(pulled);
-                    if (next < shard_tiles) enter_chunk(next);
-                }
-#ifndef NTK_ABL_LOADSONLY
-                if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
-                else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
-                else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
-                else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
-#endif
-#ifdef NTK_V_CLOCKS
-                dbg_tiles++;
-#endif
-            }
-        }
-    }
-#else
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
     next = __builtin_amdgcn_readfirstlane(next);
@@ -1064,10 +792,6 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
             mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
             after_encode();
-#ifdef NTK_SCHED_ALT   // round-4 experiment: ask the scheduler to deal the scalar mask algebra out among the vector ops, one by one
-#pragma unroll
-            for (int i = 0; i < NTK_SCHED_ALT; i++) { __builtin_amdgcn_sched_group_barrier(0x2, 1, 0); __builtin_amdgcn_sched_group_barrier(0x4, 1, 0); }
-#endif
             if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
@@ -1079,33 +803,21 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 #endif
         };
         // the next tile's load is in flight while the current one is processed
-        u32x4 ta = load_tile(voff), qa = ta, tb = ta, qb = ta;
+        u32x4 ta = load_tile(voff), qa = ta;
         if constexpr (QM) qa = load_qual(voff);
-#ifndef NTK_SV2_PINGPONG   // (two tiles per loop trip without register moves doubles the loop body: measured 5 - 25 % slower, profiles/r02b; with
-                           //  the tile offset in the scalar operand and unconditional, clamped loads: no gain at k = 21, +4 % at k = 31, profiles/r03a/pp2_ab.txt)
         // One tile per trip.  The next tile is loaded into the SAME registers as soon as the encode and the validity compares have
         // consumed the current one - the rest of the tile's work (most of it) hides the latency, and no rotation moves are needed
         // (a separate next-tile buffer loaded at the top of the trip and moved at its end: +2 v_mov_b64, about 1 % slower at k = 21, 23
-        // and 31, profiles/r03d/lateload_ab*.txt; pinning the load's place with scheduling barriers: 3.7 % slower).
+        // and 31, profiles/r03d/lateload_ab2.txt; two tiles per trip: 5 - 25 % slower, profiles/r02b, with the tile offset in the scalar
+        // operand no gain, profiles/r03a/pp2_ab.txt; the first tile of the next chunk loaded during the last tile of this one: no gain,
+        // profiles/r04b).
         for (uint32_t r = r0; r < r1; r++)
             process(ta, qa, r, [&] {
                 if (r + 1 < r1) { ta = load_tile(voff + kTileStride); if constexpr (QM) qa = load_qual(voff + kTileStride); }
             });
-        (void)tb; (void)qb;
-        if (false)
-#endif
-        for (uint32_t r = r0; r < r1; r += 2) {
-            const bool has_b = r + 1 < r1;   // wave-uniform
-            if (has_b) { tb = load_tile(voff + kTileStride); if constexpr (QM) qb = load_qual(voff + kTileStride); }
-            process(ta, qa, r, [] {});
-            if (!has_b) break;
-            if (r + 2 < r1) { ta = load_tile(voff + kTileStride); if constexpr (QM) qa = load_qual(voff + kTileStride); }
-            process(tb, qb, r + 1, [] {});
-        }
         next = __builtin_amdgcn_readfirstlane(next);
     }
 
-#endif   // NTK_XCHUNK
 #ifdef NTK_V_CLOCKS
     if ((threadIdx.x & 63) == 0 && a.values) {  // per-wave census (tools/kbench.hip): start, end of the tile loop, shader cycles | tiles << 40, placement
         uint32_t hwid, xcc;
@@ -1126,7 +838,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     nf = lane == 0 ? mp.nf_s : 0u;          // the wave's forward-strand count lives in a scalar register
     if constexpr (W > 0) nf = mp.nf_bits;   // strand bits of the chosen keys: forward count (TIE_RC) or rc count
     __syncthreads();
-    constexpr int HBE = (DevMasks2<K, HB>::kLaneCells && W == 0) ? 12 : HB;   // bits of the cell index that are value bits
+    constexpr int HBE = HB;   // bits of the cell index that are value bits
     for (int c = threadIdx.x; c < kHistBins; c += blockDim.x) {
         uint32_t tot = 0;
         if constexpr (K <= 6) {   // word builds up to 6 bases: cell = copy * 4^K + value, bin = value

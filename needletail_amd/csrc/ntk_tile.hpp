@@ -277,11 +277,7 @@ enum { kSlotCode = 16, kSlotRcode = 17, kSlotBad = 18, kSlotBad1 = 19, kSlotQ1 =
 template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX, class Sink, class XL>
 NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t lane_base, bool halo_lane, bool tail_tile)
 {
-#ifdef NTK_ABL_NOENC
-    Enc en; en.code = raw.x; en.rcode = raw.y; en.bad = raw.z & raw.w & 0xFFFFu;  // ablation: no encode
-#else
     Enc en = encode16<ACCEPT_U>(raw);
-#endif
     if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
         const int64_t keep = (int64_t)a.n_bytes - lane_base;
         en.bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
@@ -328,11 +324,6 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
             rls[j] = win32(Q, 32 + 2 * (15 - j));
         }
     }
-#ifdef NTK_ABL_NOPOS
-    sink.emit(0, (vbits ^ Q[0] ^ Q[1] ^ Q[2] ^ c1) == 0x12345u, true, mask_hi_v, c1);  // ablation: no per-position work
-    sink.end_tile();
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         uint32_t fh = 0, fl, rh = 0, rl;

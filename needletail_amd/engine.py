@@ -55,6 +55,10 @@ class Context:
     def set_launch(self, blocks: int, threads: int):
         L.check(L.lib().ntk_ctx_set_launch(self._h, blocks, threads), "ntk_ctx_set_launch")
 
+    def set_option(self, option: int, value: int = 0):
+        """ntk_ctx_set_option: test / A-B support (chunk sizes, minimizer routes switched off); value 0 = the default."""
+        L.check(L.lib().ntk_ctx_set_option(self._h, option, value), "ntk_ctx_set_option")
+
     def enable_timing(self, on: bool = True):
         L.check(L.lib().ntk_ctx_enable_timing(self._h, int(on)), "ntk_ctx_enable_timing")
 

@@ -50,6 +50,7 @@ extern "C" {
     pub fn ntk_ctx_destroy(ctx: *mut NtkCtx);
     pub fn ntk_ctx_synchronize(ctx: *mut NtkCtx) -> c_int;
     pub fn ntk_ctx_set_launch(ctx: *mut NtkCtx, blocks: c_int, threads_per_block: c_int) -> c_int;
+    pub fn ntk_ctx_set_option(ctx: *mut NtkCtx, option: c_int, value: u64) -> c_int;
     pub fn ntk_ctx_enable_timing(ctx: *mut NtkCtx, on: c_int) -> c_int;
     pub fn ntk_ctx_scan_time_ms(ctx: *mut NtkCtx, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn ntk_comm_init_all(ctxs: *const *mut NtkCtx, n: c_int, out: *mut *mut NtkComm) -> c_int;
@@ -169,6 +170,9 @@ pub struct AmdCanonicalKmersPlanes { k: usize, lens: Vec<usize>, rec_bit: Vec<u6
 impl AmdCanonicalKmersPlanes {
     /// `seq` + `offsets` (n + 1 entries): record i = seq[offsets[i]..offsets[i + 1]] - e.g. the reader's own buffer, no copy
     pub fn new(ctx: &AmdContext, seq: &[u8], offsets: &[u64], k: u8) -> Result<Self, AmdError> {
+        if offsets.is_empty() {   // no offsets at all = zero records (n + 1 entries describe n records)
+            return Ok(Self { k: k as usize, lens: Vec::new(), rec_bit: Vec::new(), valid16: Vec::new(), rc16: Vec::new(), total: 0 });
+        }
         let n = offsets.len() - 1;
         let cap = (offsets[n] - offsets[0]) / 16 + n as u64 + 1;
         let (mut rec_bit, mut valid16, mut rc16) = (vec![0u64; n + 1], vec![0u16; cap as usize], vec![0u16; cap as usize]);

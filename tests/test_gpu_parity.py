@@ -38,6 +38,28 @@ def gpu_reduce(ctx, buf: bytes, k, path, pre):
     return ctx.accum_read()
 
 
+from contextlib import contextmanager  # noqa: E402
+from needletail_amd import _lib as NL  # noqa: E402
+
+
+@pytest.fixture
+def restore_options(ctx):
+    """Tests that switch ntk_ctx_set_option on the module's shared ctx: every option back to its default afterwards."""
+    yield
+    for o in (NL.OPT_COMPAT_CHUNK_BYTES, NL.OPT_MINIMIZER_CHUNK_BYTES, NL.OPT_MINIMIZER_ROUTE, NL.OPT_COMPAT_PACK_THREADS):
+        ctx.set_option(o, 0)
+
+
+@contextmanager
+def ctx_option(c, option, value):
+    """ntk_ctx_set_option for the duration of a block (the module's ctx is shared: the default is restored)."""
+    c.set_option(option, value)
+    try:
+        yield
+    finally:
+        c.set_option(option, 0)
+
+
 def assert_stats_equal(a, b, what=""):
     for key in ("n_total", "n_fwd", "n_rc", "sum", "xor"):
         assert a[key] == b[key], (what, key, a[key], b[key])
@@ -828,27 +850,25 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank():
     assert r.returncode == 0 and "n2_on_one_gpu ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_minimizers_in_chunks(monkeypatch):
+def test_minimizers_in_chunks():
     """Long inputs are scanned in chunks with w+k-2 bytes of left context (bounded scratch); with a 4 KiB chunk every
     boundary case shows up in a small buffer: records and windows straddling chunk edges, all window sizes."""
-    monkeypatch.setenv("NTK_MINIMIZER_CHUNK_BYTES", "4096")
     rng = np.random.default_rng(2718)
     parts = []
     for L in rng.integers(1, 3000, size=60):
         parts.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(L))].tobytes())
     buf = b"\n".join(parts) + b"\n"
     with nt.Context(0, stream=torch.cuda.current_stream().cuda_stream) as c:
+        c.set_option(NL.OPT_MINIMIZER_CHUNK_BYTES, 4096)
         t = to_dev(buf)
         for k, w in ((21, 11), (31, 2), (17, 16), (5, 64), (12, 256), (32, 1)):
             for path, accept_u, tie_rc in ((nt.PATH_BYTES_CANONICAL, True, True), (nt.PATH_BITS_CANONICAL, False, False)):
                 want = O.minimizers_reduce(buf, k, w, accept_u, tie_rc)
                 for two_pass in (False, True):   # the default route (a fused kernel where one serves the pair), then the chunked two-pass path
-                    if two_pass:
-                        monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1"); monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
+                    c.set_option(NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_TWO_PASS if two_pass else 0)
                     c.accum_reset()
                     c.minimizers_reduce_device(t, len(buf), k, w, path, nt.PRE_NORMALIZE if accept_u else nt.PRE_NONE)
                     assert_stats_equal(c.accum_read(), want, (k, w, "chunked two-pass" if two_pass else "default route"))
-                    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False); monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
 
 
 def test_compressed_inputs_through_the_pipeline(ctx, golden_dir, tmp_path):
@@ -1037,14 +1057,13 @@ def test_bench_collective_fallback_is_opt_in():
 
 
 @pytest.mark.parametrize("chunk_bytes", [None, 97, 4096])
-def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, monkeypatch):
+def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, restore_options):
     """ntk_bit_kmers_batch / ntk_canonical_kmers_batch: one call for a whole batch of records, element-wise against the
     oracle's literal iterators (reference src/sequence.rs:237-252) record by record; ragged, empty and all-N records,
     mixed case, k up to 255 on the byte path, and the capacity protocol.  The call pipelines chunks of the batch (two in
-    flight, 16 MiB of packed bytes each); NTK_COMPAT_CHUNK_BYTES = 97 / 4096 forces hundreds of chunks out of this small batch:
+    flight, 16 MiB of packed bytes each); NTK_OPT_COMPAT_CHUNK_BYTES = 97 / 4096 forces hundreds of chunks out of this small batch:
     chunks of one record, records larger than a chunk, the capacity running out in the middle of a chunk."""
-    if chunk_bytes:
-        monkeypatch.setenv("NTK_COMPAT_CHUNK_BYTES", str(chunk_bytes))
+    ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, chunk_bytes or 0)   # (restored at the end of the test)
     rng = np.random.default_rng(21)
     alphabet = np.frombuffer(b"ACGTACGTACGTacgtNn-", dtype=np.uint8)
     records = [b"", b"A", b"N" * 40, b"ACGT" * 10, b"acgtACGTnACGTTGCA" * 3]
@@ -1175,7 +1194,7 @@ def test_batched_compat_face_with_page_locked_arrays(ctx):
             lib.ntk_pinned_free(ptr)
 
 
-def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatch):
+def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, restore_options):
     """configs[4] kernel side: the fused minimizer builds (one pass, no scratch planes) against the literal minimizer of every
     window (oracle) and against the two-pass path (materialise + window-min) on the same buffer, for every fused (k, w),
     both tie rules; a (k, w) without a fused build still works."""
@@ -1188,25 +1207,23 @@ def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatc
     for k, w in ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12), (23, 11), (21, 5)):
         for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
             want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
-            monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
             ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
             assert_stats_equal(ctx.accum_read(), want, ("fused", k, w, tie))
-            monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1")
-            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
-            assert_stats_equal(ctx.accum_read(), want, ("two-pass", k, w, tie))
-    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
+            with ctx_option(ctx, NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_TWO_PASS):
+                ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
+                assert_stats_equal(ctx.accum_read(), want, ("two-pass", k, w, tie))
     # a 2 M-read batch: fused == two-pass (the two-pass path is pinned against the oracle above and in the chunk test)
     n_reads = 2_000_000
     big = torch.empty(n_reads * 151 + 1024, dtype=torch.uint8, device="cuda")
     ctx.synth_reads_device(0x5EED0002, 0, n_reads, 150, 1, big)
     ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); fused = ctx.accum_read()
-    monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1")
-    ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); two = ctx.accum_read()
+    with ctx_option(ctx, NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_TWO_PASS):
+        ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); two = ctx.accum_read()
     assert_stats_equal(fused, two, "2 M reads")
     assert fused["n_total"] > 0
 
 
-def test_generic_fused_minimizers_any_k_w(ctx, monkeypatch):
+def test_generic_fused_minimizers_any_k_w(ctx, restore_options):
     """The generic fused minimizer kernel (run-time k <= 31 and w <= 49; every (k, w) without a register-fused build) against the literal
     minimizer of every window (oracle: sequence::minimizer, reference src/sequence.rs:139-152, on each window of w + k - 1 good bases):
     window lengths around the lane (16 / 32 / 48 positions) and the power-of-two boundaries of the sliding minimum, k on both sides of the
@@ -1221,25 +1238,20 @@ def test_generic_fused_minimizers_any_k_w(ctx, monkeypatch):
     qual = bytes(rng.integers(33, 75, len(buf)).astype(np.uint8))
     tq = to_dev(qual)
     pairs = [(k, w) for k in (1, 4, 11, 16, 17, 23, 27, 31) for w in (1, 2, 3, 8, 13, 16, 17, 19, 31, 32, 33, 49)] + [(21, 19), (25, 11), (31, 15), (15, 25)]
-    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
-    monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
     for i, (k, w) in enumerate(pairs):
         path, pre, tie, u = ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False))[i & 1]
         want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
         ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
         assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie))
     # k = 25 / 26: the last k of the v_min_f64 keys (value << 11 | position | strand) and the first of the general keys; the general keys
-    # below 26 as well (NTK_MINGEN_NO_F64), and the generic kernel on pairs that have a register-fused build (NTK_MINIMIZERS_NO_REGFUSED)
-    for k, w, env in ((24, 7, None), (25, 49, None), (26, 49, None), (25, 12, None), (26, 12, None), (25, 33, "NTK_MINGEN_NO_F64"), (16, 20, "NTK_MINGEN_NO_F64"),
-                      (9, 5, "NTK_MINGEN_NO_F64"), (21, 11, "NTK_MINIMIZERS_NO_REGFUSED"), (17, 16, "NTK_MINIMIZERS_NO_REGFUSED")):
-        if env:
-            monkeypatch.setenv(env, "1")
-        for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
-            want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
-            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
-            assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie, env))
-        if env:
-            monkeypatch.delenv(env)
+    # below 26 as well (NTK_ROUTE_NO_F64), and the generic kernel on pairs that have a register-fused build (NTK_ROUTE_NO_REGFUSED)
+    for k, w, off in ((24, 7, 0), (25, 49, 0), (26, 49, 0), (25, 12, 0), (26, 12, 0), (25, 33, NL.ROUTE_NO_F64), (16, 20, NL.ROUTE_NO_F64),
+                      (9, 5, NL.ROUTE_NO_F64), (21, 11, NL.ROUTE_NO_REGFUSED), (17, 16, NL.ROUTE_NO_REGFUSED)):
+        with ctx_option(ctx, NL.OPT_MINIMIZER_ROUTE, off):
+            for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
+                want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
+                ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
+                assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie, off))
     for k, w, cutoff in ((23, 11, 50), (31, 19, 60), (12, 33, 40)):
         masked = O.quality_mask(buf, qual, cutoff)
         want = O.minimizers_reduce(masked, k, w, accept_u=True, tie_rc=True)
@@ -1250,20 +1262,18 @@ def test_generic_fused_minimizers_any_k_w(ctx, monkeypatch):
         want = O.minimizers_reduce(buf, k, w, accept_u=False, tie_rc=False)
         ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, nt.PATH_BITS_CANONICAL, nt.PRE_NONE, w=w)
         assert_stats_equal(ctx.accum_read(), want, ("two-pass fallback", k, w))
-    monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
     want = O.minimizers_reduce(buf, 23, 11, accept_u=True, tie_rc=True)
-    ctx.accum_reset(); ctx.reduce_device(t, len(buf), 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
-    assert_stats_equal(ctx.accum_read(), want, "two-pass with the generic kernel off")
-    monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
+    with ctx_option(ctx, NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_NO_GENERIC):
+        ctx.accum_reset(); ctx.reduce_device(t, len(buf), 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
+        assert_stats_equal(ctx.accum_read(), want, "two-pass with the generic kernel off")
     # a 2 M-read batch: several launches' worth of tiles per wave, generic fused == two-pass
     n_reads = 2_000_000
     big = torch.empty(n_reads * 151 + 1024, dtype=torch.uint8, device="cuda")
     ctx.synth_reads_device(0x5EED0002, 0, n_reads, 150, 1, big)
     for k, w in ((23, 11), (31, 19)):
         ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); fused = ctx.accum_read()
-        monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
-        ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); two = ctx.accum_read()
-        monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
+        with ctx_option(ctx, NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_NO_GENERIC):
+            ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); two = ctx.accum_read()
         assert_stats_equal(fused, two, ("2 M reads", k, w))
         assert fused["n_total"] > 0
 
@@ -1316,304 +1326,15 @@ from _refs import minimizer_with_position as _ref_minimizer_with_position  # noq
 
 
 @pytest.mark.parametrize("chunk_bytes", [None, 97, 4096])
-def test_batched_compat_face_matches_the_iterators_per_record(ctx, chunk_bytes, monkeypatch):
-    """ntk_bit_kmers_batch / ntk_canonical_kmers_batch: one call for a whole batch of records, element-wise against the
-    oracle's literal iterators (reference src/sequence.rs:237-252) record by record; ragged, empty and all-N records,
-    mixed case, k up to 255 on the byte path, and the capacity protocol.  The call pipelines chunks of the batch (two in
-    flight, 16 MiB of packed bytes each); NTK_COMPAT_CHUNK_BYTES = 97 / 4096 forces hundreds of chunks out of this small batch:
-    chunks of one record, records larger than a chunk, the capacity running out in the middle of a chunk."""
-    if chunk_bytes:
-        monkeypatch.setenv("NTK_COMPAT_CHUNK_BYTES", str(chunk_bytes))
-    rng = np.random.default_rng(21)
-    alphabet = np.frombuffer(b"ACGTACGTACGTacgtNn-", dtype=np.uint8)
-    records = [b"", b"A", b"N" * 40, b"ACGT" * 10, b"acgtACGTnACGTTGCA" * 3]
-    for _ in range(400):
-        records.append(bytes(alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 400)))]))
-    records += [b"", bytes(alphabet[rng.integers(0, 4, 3000)])]
-    for k, canonical in ((1, True), (4, False), (21, True), (31, True), (32, False)):
-        counts, pos, val, flg = nt.bit_kmers_batch(records, k, canonical, ctx)
-        assert len(counts) == len(records)
-        o = 0
-        for r, n in zip(records, counts.tolist()):
-            p_, v_, f_ = O.bit_kmers_arrays(r, k, canonical)
-            assert n == len(p_), (k, len(r))
-            assert np.array_equal(pos[o:o + n], p_) and np.array_equal(val[o:o + n], v_) and np.array_equal(flg[o:o + n], f_)
-            o += n
-        assert o == len(pos)
-    for k in (1, 4, 21, 33, 70, 255):
-        counts, pos, flg = nt.canonical_kmers_batch(records, k, ctx)
-        o = 0
-        for r, n in zip(records, counts.tolist()):
-            p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), k)
-            assert n == len(p_), (k, len(r))
-            assert np.array_equal(pos[o:o + n], p_) and np.array_equal(flg[o:o + n], f_)
-            o += n
-        assert o == len(pos)
-    # the same items as bit planes (ntk_canonical_kmers_batch_planes): the records are uploaded as they lie (no break bytes: windows
-    # must not reach across a record start), a chunk begins on a word boundary of the planes, empty records share a position
-    for k in (1, 2, 4, 21, 33, 70, 255):
-        pl = nt.canonical_kmers_planes(records, k, ctx)
-        tot = 0
-        for i, r in enumerate(records):
-            p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), k)
-            gp, gf = pl.arrays(i)
-            assert np.array_equal(gp, p_) and np.array_equal(gf, f_), (k, i, len(r))
-            tot += len(p_)
-        assert pl.total == tot and int(pl.rec_bit[-1]) == 16 * len(pl.valid16)
-        # nothing is set outside the records' own windows (padding bits, the last k - 1 starts of a record)
-        allbits = int(np.unpackbits(pl.valid16.astype(">u2").view(np.uint8)).sum())
-        assert allbits == tot and int(np.unpackbits((pl.rc16 & ~pl.valid16).astype(">u2").view(np.uint8)).sum()) == 0
-    it = list(nt.canonical_kmers_planes(records[:8], 4, ctx).iter(4, records[4], O.reverse_complement(records[4])))
-    assert it == O.canonical_kmers(records[4], O.reverse_complement(records[4]), 4)
-    # offsets need not start at 0 (a slice of a reader's buffer), and an empty batch is fine
-    import ctypes as C_
-    from needletail_amd import _lib as L_
-    flat = b"ACGTN" + b"".join(records[:40])
-    offs2 = np.zeros(41, dtype=np.uint64); np.cumsum([len(r) for r in records[:40]], out=offs2[1:]); offs2 += 5
-    capw = int(offs2[-1] - offs2[0]) // 16 + 41
-    rb2 = np.zeros(41, dtype=np.uint64); v2 = np.zeros(capw, dtype=np.uint16); r2 = np.zeros(capw, dtype=np.uint16)
-    nw2, tt2 = C_.c_uint64(0), C_.c_uint64(0)
-    L_.check(L_.lib().ntk_canonical_kmers_batch_planes(ctx._h, flat, offs2.ctypes.data, 40, 21, rb2.ctypes.data, v2.ctypes.data, r2.ctypes.data, capw,
-                                                      C_.byref(nw2), C_.byref(tt2)), "planes with offsets[0] = 5")
-    ref = nt.canonical_kmers_planes(records[:40], 21, ctx)
-    assert tt2.value == ref.total and np.array_equal(v2[: nw2.value], ref.valid16) and np.array_equal(r2[: nw2.value], ref.rc16) and np.array_equal(rb2, ref.rec_bit)
-    e = nt.canonical_kmers_planes([], 21, ctx)
-    assert e.total == 0 and len(e.valid16) == 0
-    # capacity protocol: too small a buffer reports the needed count and fills what fits
-    import ctypes as C
-    from needletail_amd import _lib as L
-    seq = b"".join(records)
-    offs = np.zeros(len(records) + 1, dtype=np.uint64)
-    np.cumsum([len(r) for r in records], out=offs[1:])
-    rb = np.zeros(len(records) + 1, dtype=np.uint64); nw = C.c_uint64(0); tt = C.c_uint64(0)
-    v16 = np.zeros(4, dtype=np.uint16); r16 = np.zeros(4, dtype=np.uint16)
-    rc = L.lib().ntk_canonical_kmers_batch_planes(ctx._h, seq, offs.ctypes.data, len(records), 21, rb.ctypes.data, v16.ctypes.data, r16.ctypes.data,
-                                                  4, C.byref(nw), C.byref(tt))
-    assert rc == 5 and nw.value >= len(seq) // 16 and not v16.any()
-    want_counts, want_pos, want_val, want_flg = nt.bit_kmers_batch(records, 21, True, ctx)
-    cap = 100
-    cnt = np.zeros(len(records), dtype=np.uint64); p2 = np.zeros(cap, dtype=np.uint64); v2 = np.zeros(cap, dtype=np.uint64)
-    f2 = np.zeros(cap, dtype=np.uint8); tot = C.c_uint64(0)
-    rc = L.lib().ntk_bit_kmers_batch(ctx._h, seq, offs.ctypes.data, len(records), 21, 1, cnt.ctypes.data, p2.ctypes.data,
-                                     v2.ctypes.data, f2.ctypes.data, cap, C.byref(tot))
-    assert rc == 5 and tot.value == len(want_pos) and np.array_equal(cnt, want_counts)
-    assert np.array_equal(p2, want_pos[:cap]) and np.array_equal(v2, want_val[:cap]) and np.array_equal(f2, want_flg[:cap])
-    # a larger batch: 20 000 reads of 150 bp in one call
-    big = [bytes(r) for r in O.synth_reads(0x5EED0002, 0, 20000, 150, 4).reshape(20000, 151)[:, :150]]
-    counts, pos, val, flg = nt.bit_kmers_batch(big, 21, True, ctx)
-    assert int(counts.sum()) == len(pos)
-    st = O.reduce_fused(b"".join(r + b"\n" for r in big), 21, True, False, False)
-    assert len(pos) == st["n_total"] and int(flg.sum()) == st["n_rc"] and int(val.sum(dtype=np.uint64)) == st["sum"]
-    for i in (0, 7, 19999):
-        o = int(counts[:i].sum())
-        p_, v_, f_ = O.bit_kmers_arrays(big[i], 21, True)
-        assert np.array_equal(pos[o:o + len(p_)], p_) and np.array_equal(val[o:o + len(p_)], v_)
-
-
-def test_batched_compat_face_with_page_locked_arrays(ctx):
-    """ntk_pinned_alloc / ntk_pinned_free: the caller's arrays page-locked by the library (the copies of the batched compat face then
-    run at the PCIe rate instead of through a bounce buffer) - same results as with pageable arrays, element-wise against the oracle."""
-    import ctypes as C
-    from needletail_amd import _lib as L
-    lib = L.lib()
-    assert lib.ntk_pinned_alloc(64, None) != 0                       # no out pointer: an argument error, not a crash
-    lib.ntk_pinned_free(None)                                        # freeing nothing is allowed
-    held = []
-
-    def pinned(n_items, dtype):
-        n_bytes = max(int(n_items) * np.dtype(dtype).itemsize, 8)
-        ptr = C.c_void_p()
-        L.check(lib.ntk_pinned_alloc(n_bytes, C.byref(ptr)), "ntk_pinned_alloc")
-        assert ptr.value
-        held.append(ptr)
-        return np.frombuffer((C.c_uint8 * n_bytes).from_address(ptr.value), dtype=dtype)[:int(n_items)]
-
-    reads = [bytes(r) for r in O.synth_reads(0x5EED0002, 3, 5000, 150, 16).reshape(5000, 151)[:, :150]] + [b"", b"ACGTN" * 7]
-    want_counts, want_pos, want_flg = nt.canonical_kmers_batch(reads, 21, ctx)   # pageable arrays (checked against the oracle above)
-    flat = pinned(sum(len(r) for r in reads), np.uint8); flat[:] = np.frombuffer(b"".join(reads), dtype=np.uint8)
-    offs = pinned(len(reads) + 1, np.uint64); offs[0] = 0; np.cumsum([len(r) for r in reads], out=offs[1:])
-    cap = len(want_pos)
-    counts, pos, flg = pinned(len(reads), np.uint64), pinned(cap, np.uint64), pinned(cap, np.uint8)
-    tot = C.c_uint64(0)
-    try:
-        for _ in range(3):   # the banks of the pipeline are re-used from call to call
-            counts[:] = 0; pos[:] = 0; flg[:] = 0
-            L.check(lib.ntk_canonical_kmers_batch(ctx._h, C.cast(flat.ctypes.data, C.c_char_p), offs.ctypes.data, len(reads), 21, counts.ctypes.data,
-                                                  pos.ctypes.data, flg.ctypes.data, cap, C.byref(tot)), "ntk_canonical_kmers_batch")
-            assert tot.value == cap and np.array_equal(counts, want_counts) and np.array_equal(pos, want_pos) and np.array_equal(flg, want_flg)
-        o = 0
-        for r, n in list(zip(reads, counts.tolist()))[:50] + [(reads[-1], int(counts[-1]))]:
-            p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), 21)
-            if r is reads[-1]:
-                o = cap - n
-            assert n == len(p_) and np.array_equal(pos[o:o + n], p_) and np.array_equal(flg[o:o + n], f_)
-            o += n
-    finally:
-        del flat, offs, counts, pos, flg
-        for ptr in held:
-            lib.ntk_pinned_free(ptr)
-
-
-def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, monkeypatch):
-    """configs[4] kernel side: the fused minimizer builds (one pass, no scratch planes) against the literal minimizer of every
-    window (oracle) and against the two-pass path (materialise + window-min) on the same buffer, for every fused (k, w),
-    both tie rules; a (k, w) without a fused build still works."""
-    rng = np.random.default_rng(17)
-    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNU\n", dtype=np.uint8)
-    h = bytes(rng.choice(list(b"ACGT"), size=41).astype(np.uint8))
-    buf = bytes(alphabet[rng.integers(0, len(alphabet), 60_000)]) + h + O.reverse_complement(h) + b"A" * 90 + b"T" * 90 + \
-        O.synth_reads(0x5EED0002, 9, 3000, 150, 8).tobytes()
-    t = to_dev(buf)
-    for k, w in ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12), (23, 11), (21, 5)):
-        for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
-            want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
-            monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
-            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
-            assert_stats_equal(ctx.accum_read(), want, ("fused", k, w, tie))
-            monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1")
-            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
-            assert_stats_equal(ctx.accum_read(), want, ("two-pass", k, w, tie))
-    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
-    # a 2 M-read batch: fused == two-pass (the two-pass path is pinned against the oracle above and in the chunk test)
-    n_reads = 2_000_000
-    big = torch.empty(n_reads * 151 + 1024, dtype=torch.uint8, device="cuda")
-    ctx.synth_reads_device(0x5EED0002, 0, n_reads, 150, 1, big)
-    ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); fused = ctx.accum_read()
-    monkeypatch.setenv("NTK_MINIMIZERS_TWO_PASS", "1")
-    ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11); two = ctx.accum_read()
-    assert_stats_equal(fused, two, "2 M reads")
-    assert fused["n_total"] > 0
-
-
-def test_generic_fused_minimizers_any_k_w(ctx, monkeypatch):
-    """The generic fused minimizer kernel (run-time k <= 31 and w <= 49; every (k, w) without a register-fused build) against the literal
-    minimizer of every window (oracle: sequence::minimizer, reference src/sequence.rs:139-152, on each window of w + k - 1 good bases):
-    window lengths around the lane (16 / 32 / 48 positions) and the power-of-two boundaries of the sliding minimum, k on both sides of the
-    one-word / two-word values, both tie rules, ragged records, repeats (leftmost rule), with and without a quality stream; and the same
-    buffer through the two-pass path."""
-    rng = np.random.default_rng(23)
-    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNU\n", dtype=np.uint8)
-    h = bytes(rng.choice(list(b"ACGT"), size=70).astype(np.uint8))
-    buf = bytes(alphabet[rng.integers(0, len(alphabet), 30_000)]) + h + O.reverse_complement(h) + h + b"A" * 200 + b"AC" * 100 + b"T" * 90 + \
-        O.synth_reads(0x5EED0002, 9, 1500, 150, 8).tobytes() + O.synth_reads(0x5EED0003, 0, 40, 3000, 4).tobytes()
-    t = to_dev(buf)
-    qual = bytes(rng.integers(33, 75, len(buf)).astype(np.uint8))
-    tq = to_dev(qual)
-    pairs = [(k, w) for k in (1, 4, 11, 16, 17, 23, 27, 31) for w in (1, 2, 3, 8, 13, 16, 17, 19, 31, 32, 33, 49)] + [(21, 19), (25, 11), (31, 15), (15, 25)]
-    monkeypatch.delenv("NTK_MINIMIZERS_TWO_PASS", raising=False)
-    monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
-    for i, (k, w) in enumerate(pairs):
-        path, pre, tie, u = ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False))[i & 1]
-        want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
-        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
-        assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie))
-    # k = 25 / 26: the last k of the v_min_f64 keys (value << 11 | position | strand) and the first of the general keys; the general keys
-    # below 26 as well (NTK_MINGEN_NO_F64), and the generic kernel on pairs that have a register-fused build (NTK_MINIMIZERS_NO_REGFUSED)
-    for k, w, env in ((24, 7, None), (25, 49, None), (26, 49, None), (25, 12, None), (26, 12, None), (25, 33, "NTK_MINGEN_NO_F64"), (16, 20, "NTK_MINGEN_NO_F64"),
-                      (9, 5, "NTK_MINGEN_NO_F64"), (21, 11, "NTK_MINIMIZERS_NO_REGFUSED"), (17, 16, "NTK_MINIMIZERS_NO_REGFUSED")):
-        if env:
-            monkeypatch.setenv(env, "1")
-        for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
-            want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
-            ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)
-            assert_stats_equal(ctx.accum_read(), want, ("generic fused", k, w, tie, env))
-        if env:
-            monkeypatch.delenv(env)
-    for k, w, cutoff in ((23, 11, 50), (31, 19, 60), (12, 33, 40)):
-        masked = O.quality_mask(buf, qual, cutoff)
-        want = O.minimizers_reduce(masked, k, w, accept_u=True, tie_rc=True)
-        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w, d_qual=tq, quality_cutoff=cutoff)
-        assert_stats_equal(ctx.accum_read(), want, ("generic fused, quality", k, w, cutoff))
-    # beyond the kernel's range (k = 32, w = 50) and with the kernel switched off: the two-pass path, same results
-    for k, w in ((32, 11), (21, 50)):
-        want = O.minimizers_reduce(buf, k, w, accept_u=False, tie_rc=False)
-        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, nt.PATH_BITS_CANONICAL, nt.PRE_NONE, w=w)
-        assert_stats_equal(ctx.accum_read(), want, ("two-pass fallback", k, w))
-    monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
-    want = O.minimizers_reduce(buf, 23, 11, accept_u=True, tie_rc=True)
-    ctx.accum_reset(); ctx.reduce_device(t, len(buf), 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
-    assert_stats_equal(ctx.accum_read(), want, "two-pass with the generic kernel off")
-    monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
-    # a 2 M-read batch: several launches' worth of tiles per wave, generic fused == two-pass
-    n_reads = 2_000_000
-    big = torch.empty(n_reads * 151 + 1024, dtype=torch.uint8, device="cuda")
-    ctx.synth_reads_device(0x5EED0002, 0, n_reads, 150, 1, big)
-    for k, w in ((23, 11), (31, 19)):
-        ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); fused = ctx.accum_read()
-        monkeypatch.setenv("NTK_MINIMIZERS_NO_GENERIC", "1")
-        ctx.accum_reset(); ctx.reduce_device(big, n_reads * 151, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w); two = ctx.accum_read()
-        monkeypatch.delenv("NTK_MINIMIZERS_NO_GENERIC", raising=False)
-        assert_stats_equal(fused, two, ("2 M reads", k, w))
-        assert fused["n_total"] > 0
-
-
-def test_reset_flag_starts_a_new_result(ctx, monkeypatch):
-    """NTK_FLAG_RESET (ntk_params.flags bit 16): the reduce call zeroes the accumulators inside its own launch - same result as
-    ntk_accum_reset + the call, on every route that takes it (plain, quality-masked, fused and two-pass minimizers, empty input,
-    several launches, a pinned batch, a whole-reader scan)."""
-    a = O.synth_reads(0x5EED0011, 0, 3000, 150, 4).tobytes()
-    b = O.synth_reads(0x5EED0012, 5, 2000, 150, 2).tobytes()
-    ta, tb = to_dev(a), to_dev(b)
-    path, pre = nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE
-    for k in (4, 16, 21, 31):
-        ctx.accum_reset(); ctx.reduce_device(ta, len(a), k, path, pre)          # leave something in the accumulators
-        ctx.reduce_device(tb, len(b), k, path, pre, reset=True)
-        assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, k, True, True, True), ("reset", k))
-        ctx.reduce_device(ta, len(a), k, path, pre)                             # and without the flag it accumulates
-        both = ctx.accum_read()
-        assert both["n_total"] == O.reduce_fused(a, k, True, True, True)["n_total"] + O.reduce_fused(b, k, True, True, True)["n_total"]
-    # forward-only bit path
-    ctx.reduce_device(tb, len(b), 21, nt.PATH_BITS, nt.PRE_NONE, reset=True)
-    assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, 21, False, False, False), "reset fwd")
-    # quality-masked
-    q = np.full(len(b), 73, dtype=np.uint8); q[::5] = 34
-    tq = _qual_dev(q.tobytes())
-    ctx.reduce_device(tb, len(b), 21, path, pre, d_qual=tq, quality_cutoff=40, reset=True)
-    assert_stats_equal(ctx.accum_read(), O.reduce_fused(O.quality_mask(b, q.tobytes(), 40), 21, True, True, True), "reset quality")
-    # minimizers: fused build, then the two-pass path
-    want = O.minimizers_reduce(b, 21, 11, True, True)
-    ctx.reduce_device(tb, len(b), 21, path, pre, w=11, reset=True)
-    assert_stats_equal(ctx.accum_read(), want, "reset fused minimizers")
-    want2 = O.minimizers_reduce(b, 21, 33, True, True)
-    ctx.reduce_device(tb, len(b), 21, path, pre, w=33, reset=True)
-    assert_stats_equal(ctx.accum_read(), want2, "reset two-pass minimizers")
-    # empty input: only the reset happens
-    ctx.reduce_device(tb, 0, 21, path, pre, reset=True)
-    z = ctx.accum_read()
-    assert z["n_total"] == 0 and z["sum"] == 0 and z["xor"] == 0 and int(np.asarray(z["hist"]).sum()) == 0
-    # a pinned batch
-    ctx.reduce_device(ta, len(a), 21, path, pre)
-    bt = ctx.batch(1 << 20, 1 << 14)
-    recs = b.split(b"\n")[:-1]
-    for r in recs:
-        assert bt.append(r, pre)
-    bt.submit(21, path, pre, reset=True); bt.wait(); bt.release()
-    assert_stats_equal(ctx.accum_read(), O.reduce_fused(b, 21, True, True, True), "reset batch")
-
-
-def _ref_minimizer_with_position(rec: bytes, m: int):
-    """sequence::minimizer restated WITH the winner's window start and strand: the reference's loop order (src/sequence.rs:143-150: forward
-    window i, then reverse-complement window i, i ascending, strict <) decides between equal byte strings."""
-    rcs = O.reverse_complement(rec)
-    best = None
-    for i in range(len(rec) - m + 1):
-        for st, strand in ((0, rec), (1, rcs)):
-            c = strand[i:i + m]
-            if best is None or c < best[0]:
-                best = (c, i, st)
-    return best
-
-
-@pytest.mark.parametrize("chunk_bytes", [None, 97, 4096])
-def test_minimizer_batch_matches_the_reference_function_per_record(ctx, monkeypatch, chunk_bytes):
+def test_minimizer_batch_matches_the_reference_function_per_record(ctx, restore_options, chunk_bytes):
     """ntk_minimizer_batch = sequence::minimizer (reference src/sequence.rs:139-152) applied to every record of a reader batch in one call:
     raw-byte comparison (mixed case, N, IUPAC, U - complement() maps what it maps), homopolymers and repeats (ties: the reference's loop order
     decides which window is reported), records of exactly m bytes, a record beyond 64 KiB (the one-block kernel), the reference's own literal;
     a record shorter than m fails the call and names itself; the empty batch."""
     import ctypes as C
     from needletail_amd import _lib as L
-    if chunk_bytes:   # the upload / kernel / download pipeline over hundreds of chunks (the default is 16 MiB: one chunk here)
-        monkeypatch.setenv("NTK_COMPAT_CHUNK_BYTES", str(chunk_bytes))
+    # the upload / kernel / download pipeline over hundreds of chunks (the default is 16 MiB: one chunk here); restored at the end of the test
+    ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, chunk_bytes or 0)
     rng = np.random.default_rng(41)
     alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnURYKMSWBDHV", dtype=np.uint8)
     assert nt.minimizer_batch([b"ATTTCG"], 3, ctx) == [b"AAA"]                      # reference src/sequence.rs:363-367

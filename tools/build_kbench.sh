@@ -5,7 +5,7 @@
 # work on synthetic register-resident words: no loads, no encode, no validity), kb_s2_default = the same kernel under the default
 # scheduler, plus the instruction micro-benchmarks.
 cd "$(dirname "$0")"
-F="--offload-arch=gfx950 -O3 -std=c++17 -DNTK_KB_FIX -DNTK_KB_SV"
+F="--offload-arch=gfx950 -O3 -std=c++17 -DNTK_KBENCH -DNTK_KB_FIX -DNTK_KB_SV"
 S="$F -DNTK_KB_SV2 -DNTK_KB_HB=14 -mllvm -amdgpu-sched-strategy=iterative-ilp"
 rm -f kb_*
 hipcc $F -o kb_cur kbench.hip 2>/dev/null &

@@ -40,7 +40,7 @@ for _ in range(6):
 print(f"planes: {reads} reads, {tot.value} items, {best * 1e3:.2f} ms = {reads * read_len / best / 1e9:.1f} Gbases/s, {src.nbytes / best / 1e9:.1f} GB/s in, "
       f"{nw.value * 4 / best / 1e9:.1f} GB/s out")
 for chunk in (4 << 20, 8 << 20, 32 << 20, 64 << 20):
-    os.environ["NTK_COMPAT_CHUNK_BYTES"] = str(chunk)
+    ctx.set_option(L.OPT_COMPAT_CHUNK_BYTES, chunk)
     b2 = None
     for _ in range(5):
         t0 = time.perf_counter()
@@ -49,7 +49,7 @@ for chunk in (4 << 20, 8 << 20, 32 << 20, 64 << 20):
         dt = time.perf_counter() - t0
         b2 = dt if b2 is None else min(b2, dt)
     print(f"   chunk {chunk >> 20:3d} MiB: {b2 * 1e3:.2f} ms = {reads * read_len / b2 / 1e9:.1f} Gbases/s")
-os.environ.pop("NTK_COMPAT_CHUNK_BYTES", None)
+ctx.set_option(L.OPT_COMPAT_CHUNK_BYTES, 0)
 # sequence::minimizer per record for the same batch (ntk_minimizer_batch): one upload, one wave per record, n_records x m bytes back
 for m in (21, 31):
     mout = pinned(reads * m, np.uint8)

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-import needletail_amd as nt  # noqa: E402
+import needletail_amd as nt
+from needletail_amd import _lib as NL  # noqa: E402
 import oracle as O  # noqa: E402  (checker)
 
 MODES = [  # (path, pre, canonical, tie_rc, accept_u)
@@ -197,12 +198,9 @@ def main():
             if u3 < 0.34:
                 # the bit-plane form: any k <= 255 (the raw-byte kernel), records uploaded without break bytes
                 kp = int(rng.choice([k, k, int(rng.integers(1, 64)), int(rng.integers(64, 256))]))
-                if rng.random() < 0.5:
-                    os.environ["NTK_COMPAT_CHUNK_BYTES"] = str(int(rng.choice([64, 97, 1000, 4096, 1 << 16])))
-                else:
-                    os.environ.pop("NTK_COMPAT_CHUNK_BYTES", None)
+                ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, int(rng.choice([64, 97, 1000, 4096, 1 << 16])) if rng.random() < 0.5 else 0)
                 pl = nt.canonical_kmers_planes(recs, kp, ctx=ctx)
-                os.environ.pop("NTK_COMPAT_CHUNK_BYTES", None)
+                ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, 0)
                 ok, tot = True, 0
                 for i, r in enumerate(recs):
                     p_, f_ = O.canonical_kmers_arrays(r, O.reverse_complement(r), kp)

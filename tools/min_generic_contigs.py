@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import needletail_amd as nt
+from needletail_amd import _lib as NL
 reads, L = 1_000_000, 10_000
 n = reads * (L + 1)
 ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
@@ -28,7 +29,7 @@ for k, w in ((19, 19), (15, 10), (25, 31), (31, 19)):
     print(f"k={k:2d} w={w:2d}: {ms:8.3f} ms per 10.0 GB = {reads * L / ms / 1e6:7.1f} Gbases/s = {n / ms / 1e6:6.0f} GB/s  (windows {r['n_total']})", flush=True)
 pre = (reads // 16) * (L + 1)
 _, a = run(19, 19, pre, 1)
-os.environ["NTK_MINIMIZERS_TWO_PASS"] = "1"
+ctx.set_option(NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_TWO_PASS)
 ms2, b = run(19, 19, pre, 1)
 assert all(a[x] == b[x] for x in ("n_total", "n_fwd", "sum", "xor")) and (a["hist"] == b["hist"]).all()
 print(f"(19, 19) on the first {reads // 16} contigs: equal to the two-pass path ({ms2:.1f} ms there)")
