@@ -476,7 +476,161 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     out["pipeline_fastq_h2d_inclusive"] = {"reads": p_reads, "parser_threads": th, "seconds": round(best, 4),
                                            "Gbases_s": round(p_reads * read_len / best / 1e9, 2),
                                            "fastq_GB_s": round(len(text) / best / 1e9, 2)}
+    try:
+        out["config5_gzip_minimizers"] = config5_gzip_minimizers(ctx, nt, text, k21_seq, p_reads, read_len)
+    except (nt.NtkError, OSError, MemoryError) as e:  # pragma: no cover
+        out["config5_gzip_minimizers"] = {"error": str(e)}
     return out
+
+
+def gzip_one_member(text, threads, level=6):
+    """`text` as ONE gzip member at zlib level `level`, compressed by `threads` threads the way pigz does it: pieces of the input are
+    deflated concurrently, each primed with the 32 KiB before it (so matches cross the piece boundaries, as in a stream written in one
+    go) and closed with a sync flush; one header, one CRC-32 / ISIZE trailer.  (Python's zlib releases the GIL.)"""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    mv = memoryview(text)
+    n = len(mv)
+    piece = max(1 << 23, -(-n // (threads * 4)))
+    cuts = list(range(0, n, piece)) or [0]
+
+    def comp(a):
+        b = min(n, a + piece)
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY, bytes(mv[a - 32768:a])) if a >= 32768 else \
+            zlib.compressobj(level, zlib.DEFLATED, -15)
+        return c.compress(mv[a:b]) + c.flush(zlib.Z_FINISH if b == n else zlib.Z_SYNC_FLUSH)
+
+    with ThreadPoolExecutor(threads) as ex:
+        crc_f = ex.submit(zlib.crc32, mv)
+        parts = list(ex.map(comp, cuts))
+        crc = crc_f.result()
+    return b"".join([b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03"] + parts + [struct.pack("<II", crc & 0xFFFFFFFF, n & 0xFFFFFFFF)])
+
+
+def bgzf_members(text, threads, block=60000):
+    """Block gzip as bgzip / htslib write it: independent members of <= 64 KiB, each with its compressed size in a 'BC' extra subfield,
+    closed by the empty EOF member."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    mv = memoryview(text)
+    n = len(mv)
+    group = block * 256
+
+    def comp(a):
+        out = bytearray()
+        for o in range(a, min(n, a + group), block):
+            ch = mv[o:min(n, o + block)]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = c.compress(ch) + c.flush()
+            out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+            out += body + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch))
+        return bytes(out)
+
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(comp, range(0, n, group)))
+    eof = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\0\0\0\0\0\0\0\0"
+    return b"".join(parts + [eof])
+
+
+def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
+    """BASELINE.json configs[4] end to end: the first 10 M reads of C2 as FASTQ text, ONE gzip member at zlib level 6,
+    as a file -> inflate on the host's cores -> parallel record parser -> pinned batches -> overlapped H2D + fused (21, 11) minimizers;
+    the result must equal the accumulators of the resident minimizer run over the same reads.  Routes: (a) the ordinary .gz through
+    ntk_scan_file_parallel (speculative parallel inflate of the one deflate stream, all granted CPUs), (b) the same file through the
+    streaming reader (zlib on one thread: what the reference does, src/parser/mod.rs:95-108; a 1 M-read sample), (c) block gzip
+    (bgzip-style members).  Plus ntk_gunzip alone per thread count."""
+    import ctypes as C
+    import tempfile
+
+    from needletail_amd import _lib as L
+    cpus, host = effective_cpus()
+    rec_bytes = len(text) // reads
+    k, w = 21, 11
+    ctx.accum_reset()
+    ctx.reduce_device(k21_seq, reads * (read_len + 1), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w)
+    want = ctx.accum_read()
+    line = {"workload": f"first {reads} reads of C2 as FASTQ text ({len(text) / 1e9:.2f} GB), one gzip member, zlib level 6 -> file -> "
+                        f"inflate + parse on the host -> pinned batches -> H2D + fused minimizers (k = {k}, w = {w})",
+            "cpus_granted": cpus, "host": host}
+    t0 = time.perf_counter()
+    gz = gzip_one_member(text, cpus)
+    line["gzip_bytes"] = len(gz)
+    line["compress_s_untimed"] = round(time.perf_counter() - t0, 2)
+
+    def gunzip(buf, threads):
+        o, n, info = C.c_void_p(), C.c_uint64(0), L.GunzipInfo()
+        t0 = time.perf_counter()
+        L.check(L.lib().ntk_gunzip(buf, len(buf), threads, C.byref(o), C.byref(n), C.byref(info)), "ntk_gunzip")
+        dt = time.perf_counter() - t0
+        L.lib().ntk_gunzip_free(o, n.value)
+        return dt, int(n.value), info
+
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        path = os.path.join(d, "c5.fastq.gz")
+        with open(path, "wb") as f:
+            f.write(gz)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
+            dt = time.perf_counter() - t0
+            if not (stats_equal(st, want) and st["n_records"] == reads):
+                raise SystemExit("secondary: config 5 (gzip + minimizers) differs from the resident minimizer run")
+            best = dt if best is None else min(best, dt)
+        line["plain_gz_parallel_inflate"] = {"call": "ntk_scan_file_parallel", "inflate_threads": cpus, "parser_threads": cpus, "seconds": round(best, 3),
+                                             "Gbases_s": round(reads * read_len / best / 1e9, 3), "text_GB_s": round(len(text) / best / 1e9, 2),
+                                             "equal_to_resident_run": True}
+        # the inflate alone, per thread count (the whole file for 1 and all granted CPUs, a 2 M-read member for the ones between)
+        table = []
+        dt, n_out, info = gunzip(gz, cpus)
+        assert n_out == len(text)
+        table.append({"threads": cpus, "input": "whole file", "seconds": round(dt, 3), "text_GB_s": round(n_out / dt / 1e9, 2), "route": info.route,
+                      "chunks": info.chunks, "chunks_dropped": info.chunks_dropped, "search_s": round(info.search_s, 3),
+                      "decode_wall_s": round(info.decode_s, 3), "decode_cpu_s": round(info.decode_busy_s, 3),
+                      "marker_share": round(info.marker_symbols / max(n_out, 1), 3),
+                      "per_thread_text_MB_s": round(n_out / max(info.decode_busy_s, 1e-9) / 1e6, 1)})
+        sample_reads = min(reads, 2_000_000)
+        sample = gzip_one_member(memoryview(text)[: sample_reads * rec_bytes], cpus)
+        tlist = sorted({1, 2, 4, 8, cpus} & set(range(1, cpus + 1)))
+        for t in tlist:
+            dt, n_out, info = min((gunzip(sample, t) for _ in range(2)), key=lambda x: x[0])
+            table.append({"threads": t, "input": f"{sample_reads} reads", "seconds": round(dt, 3), "text_GB_s": round(n_out / dt / 1e9, 2), "route": info.route,
+                          "decode_cpu_s": round(info.decode_busy_s, 3), "per_thread_text_MB_s": round(n_out / max(info.decode_busy_s, 1e-9) / 1e6, 1)})
+        line["gunzip_alone"] = table
+        # (b) the streaming reader on a 1 M-read member: one zlib thread, copies and kernels overlapped behind it
+        s_reads = min(reads, 1_000_000)
+        spath = os.path.join(d, "c5_sample.fastq.gz")
+        with open(spath, "wb") as f:
+            f.write(gzip_one_member(memoryview(text)[: s_reads * rec_bytes], cpus))
+        ctx.accum_reset()
+        ctx.reduce_device(k21_seq, s_reads * (read_len + 1), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w)
+        want_s = ctx.accum_read()
+        t0 = time.perf_counter()
+        st = nt.scan_file(ctx, spath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w)
+        dt = time.perf_counter() - t0
+        if not (stats_equal(st, want_s) and st["n_records"] == s_reads):
+            raise SystemExit("secondary: config 5 through the streaming reader differs from the resident minimizer run")
+        line["plain_gz_stream_one_thread"] = {"call": "ntk_scan_reader (zlib inflate on the reader thread: the reference's MultiGzDecoder arrangement)",
+                                              "reads": s_reads, "seconds": round(dt, 3), "Gbases_s": round(s_reads * read_len / dt / 1e9, 3)}
+        # (c) block gzip
+        bpath = os.path.join(d, "c5.fastq.bgz")
+        with open(bpath, "wb") as f:
+            f.write(bgzf_members(text, cpus))
+        bbest = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            st = nt.scan_file_parallel(ctx, bpath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
+            dt = time.perf_counter() - t0
+            if not (stats_equal(st, want) and st["n_records"] == reads):
+                raise SystemExit("secondary: config 5 (block gzip + minimizers) differs from the resident minimizer run")
+            bbest = dt if bbest is None else min(bbest, dt)
+        line["block_gzip"] = {"call": "ntk_scan_file_parallel", "threads": cpus, "seconds": round(bbest, 3), "Gbases_s": round(reads * read_len / bbest / 1e9, 3)}
+    line["Gbases_s"] = line["plain_gz_parallel_inflate"]["Gbases_s"]
+    line["note"] = ("PCIe- and host-inclusive, never `value`; the GPU work (fused minimizers: secondary.minimizers_w11_k21_resident) hides behind the host's "
+                    "inflate, which is the bound: gunzip_alone lists its rate per thread count")
+    return line
 
 
 class phase_deadline:

@@ -265,8 +265,8 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t b
 /* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into about eight pieces per
  * thread, handed out on demand to n_threads parser threads (at most 64 are used; 32 reach the PCIe rate), each filling
  * its own pinned batches (record order is not preserved; the reduced result does not depend on it).  A gzip stream is sequential: ntk_scan_buffer_parallel refuses it (NTK_ERR_UNSUPPORTED, use
- * ntk_scan_reader; the same for bzip2 / xz / zstd); ntk_scan_file_parallel inflates the whole file into memory first (all members) when libdeflate.so.0 can
- * be loaded and the output stays under 16 GiB (NTK_GZ_INMEM_LIMIT_BYTES), and is NTK_ERR_UNSUPPORTED otherwise.
+ * ntk_scan_reader; the same for bzip2 / xz / zstd); ntk_scan_file_parallel inflates the whole file into memory first (ntk_gunzip below: all members,
+ * all threads) when the output stays under 16 GiB (NTK_GZ_INMEM_LIMIT_BYTES), and is NTK_ERR_UNSUPPORTED otherwise.
  * Parse errors return NTK_ERR_PARSE without position detail. */
 /* The cut points the parallel producer uses: cuts[0] = 0 <= cuts[1] <= ... <= cuts[n_pieces] = n, every cut a record start. */
 int ntk_fastx_split_points(const uint8_t *data, uint64_t n, uint32_t n_pieces, uint64_t *cuts);
@@ -274,6 +274,23 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
                              uint32_t n_threads, uint64_t *n_records, uint64_t *n_bases);
 int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads,
                            uint64_t *n_records, uint64_t *n_bases);
+
+/* The gzip front-end of the parallel producer on its own: every member of a gzip file inflated into ONE buffer by
+ * n_threads threads, CRC-32 and ISIZE of every member checked; truncated or corrupt data is NTK_ERR_PARSE (what the reference's reader
+ * reports as an Io error: MultiGzDecoder, src/parser/mod.rs:95-108), output beyond the in-memory limit NTK_ERR_UNSUPPORTED.  An
+ * ORDINARY gzip stream (one member, as `gzip` writes it) is inflated in parallel too: chunks of the compressed bytes enter the deflate
+ * stream at block boundaries found by search, decode with the 32 KiB of history before them as unknowns and are resolved once the
+ * chunk before them is known (route 2); block gzip (bgzip) inflates member by member (route 1); n_threads = 1 is a plain sequential
+ * inflate (route 3).  *out is released with ntk_gunzip_free(*out, *out_n) (an anonymous mapping, not malloc'ed memory); it is what
+ * ntk_scan_buffer_parallel takes.  info may be NULL. */
+typedef struct ntk_gunzip_info {
+    uint32_t route, threads, chunks, chunks_dropped;   /* chunks_dropped: chunk starts that turned out not to be block boundaries */
+    uint32_t members, reserved;
+    double search_s, decode_s, decode_busy_s, crc_s;   /* wall seconds of the boundary search / of the decode + resolve pipeline; CPU seconds inside the chunk decoders; CRC combination */
+    uint64_t marker_symbols;                           /* symbols that went through the 16-bit "unknown window" form */
+} ntk_gunzip_info;
+int ntk_gunzip(const uint8_t *gz, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info);
+void ntk_gunzip_free(uint8_t *out, uint64_t out_n);
 
 /* ---- compat face: the reference's per-sequence functions, eager ---------------------------------
  * Caller-allocated outputs; *_len out-params; outputs need capacity n unless stated. */

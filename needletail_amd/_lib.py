@@ -35,7 +35,7 @@ SYMBOLS = [
     "ntk_canonical_kmers_batch_planes", "ntk_ctx_trim", "ntk_minimizer_batch",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
     "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_position", "ntk_reader_close",
-    "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points",
+    "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points", "ntk_gunzip", "ntk_gunzip_free",
     "ntk_minimizers_reduce_device", "ntk_minimizer", "ntk_canonical", "ntk_bit_minimizers", "ntk_quality_mask", "ntk_bit_canonical",
 ]
 
@@ -63,6 +63,12 @@ class Record(C.Structure):
     _fields_ = [("id", C.c_void_p), ("id_len", C.c_uint64), ("seq", C.c_void_p), ("seq_len", C.c_uint64),
                 ("qual", C.c_void_p), ("qual_len", C.c_uint64), ("format", C.c_uint32), ("line_ending", C.c_uint32),
                 ("line", C.c_uint64), ("num_bases", C.c_uint64), ("byte", C.c_uint64)]
+
+
+class GunzipInfo(C.Structure):
+    _fields_ = [("route", C.c_uint32), ("threads", C.c_uint32), ("chunks", C.c_uint32), ("chunks_dropped", C.c_uint32),
+                ("members", C.c_uint32), ("reserved", C.c_uint32), ("search_s", C.c_double), ("decode_s", C.c_double),
+                ("decode_busy_s", C.c_double), ("crc_s", C.c_double), ("marker_symbols", C.c_uint64)]
 
 
 class NtkError(RuntimeError):
@@ -149,6 +155,9 @@ def lib() -> C.CDLL:
     L.ntk_fastx_split_points.argtypes = [C.c_char_p, u64, u32, vp]
     L.ntk_scan_buffer_parallel.argtypes = [vp, C.c_char_p, u64, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]
     L.ntk_scan_file_parallel.argtypes = [vp, C.c_char_p, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]
+    L.ntk_gunzip.argtypes = [C.c_char_p, u64, u32, pp, C.POINTER(u64), C.POINTER(GunzipInfo)]
+    L.ntk_gunzip_free.restype = None
+    L.ntk_gunzip_free.argtypes = [vp, u64]
     L.ntk_minimizers_reduce_device.argtypes = [vp, vp, u64, C.POINTER(Params), u32]
     L.ntk_minimizer.argtypes = [vp, C.c_char_p, u64, u32, C.c_char_p]
     L.ntk_minimizer_batch.argtypes = [vp, C.c_char_p, vp, u64, u32, vp, vp, vp, C.POINTER(u64)]

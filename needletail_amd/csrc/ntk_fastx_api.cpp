@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "ntk_fastx.hpp"
+#include "ntk_pgzip.hpp"
 
 struct ntk_reader {
     ntk::FastxReader r;
@@ -343,11 +344,11 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
 }
 
 namespace {
-// Whole-file gzip for the parallel producer.  A gzip stream is sequential, so the parser threads cannot share it; but
-// when libdeflate (a whole-buffer decoder, ~2x zlib's inflate rate) is installed the file is inflated into memory member by
-// member and the plain-text buffer is then parsed in parallel.  The library is loaded at run time (its runtime .so ships
-// with the image, its headers do not; the three entry points below are its stable v1 ABI); without it, or for outputs
-// beyond the in-memory limit, gzip input stays NTK_ERR_UNSUPPORTED here and the streaming ntk_scan_reader (zlib) is the way.
+// Whole-file gzip for the parallel producer: the file is inflated into memory by all threads (inflate_whole below) and the plain
+// text is then parsed in parallel.  libdeflate (a whole-buffer decoder; its runtime .so ships with the image, its headers do not; the
+// three entry points below are its stable v1 ABI) inflates the members of BLOCK gzip files; ordinary gzip streams go through this
+// library's own speculative parallel inflater (ntk_pgzip.cpp).  Outputs beyond the in-memory limit are NTK_ERR_UNSUPPORTED here: the
+// streaming ntk_scan_reader (zlib, one thread - what the reference does) is the way for those.
 struct Deflate {
     void *(*alloc)() = nullptr;
     int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
@@ -392,21 +393,28 @@ bool bgzf_index(const uint8_t *in, uint64_t n, std::vector<BgzfBlock> *blocks, u
     return !blocks->empty();
 }
 
-// NTK_OK with *out (malloc'ed) / *out_n, NTK_ERR_UNSUPPORTED (no library, or larger than the limit), NTK_ERR_PARSE (bad data)
-int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n)
+// The whole gzip file inflated into one buffer (every member, CRC-32 and ISIZE checked; reference: MultiGzDecoder,
+// src/parser/mod.rs:95-108).  NTK_OK with *out (an anonymous mapping: ntk::pgz_free) / *out_n; NTK_ERR_UNSUPPORTED (larger than the
+// limit), NTK_ERR_PARSE (corrupt or truncated data), NTK_ERR_NOMEM.  Routes:
+//   1  block gzip (BGZF): the members carry their sizes, are located without inflating anything and inflated in parallel
+//      (libdeflate when it can be loaded, else route 2)
+//   2  an ordinary gzip stream, n_threads > 1: speculative parallel inflate (ntk_pgzip.cpp: chunks enter the stream at block
+//      boundaries with the 32 KiB before them as unknowns, resolved afterwards)
+//   3  the same decoder on one thread
+int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info)
 {
     static const Deflate lib;
-    if (!lib.ok) return NTK_ERR_UNSUPPORTED;
     uint64_t limit = (uint64_t)16 << 30;
     if (const char *e = getenv("NTK_GZ_INMEM_LIMIT_BYTES")) limit = strtoull(e, nullptr, 10);
-    {   // BGZF: members inflate in parallel straight to their final offsets
+    const uint32_t nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    if (info) { memset(info, 0, sizeof(*info)); info->threads = nt; }
+    if (lib.ok) {   // BGZF: members inflate in parallel straight to their final offsets
         std::vector<BgzfBlock> blocks;
         uint64_t total = 0;
         if (bgzf_index(in, n, &blocks, &total)) {
             if (total > limit) return NTK_ERR_UNSUPPORTED;
-            uint8_t *buf = (uint8_t *)malloc(total ? total : 1);
+            uint8_t *buf = ntk::pgz_alloc(total);
             if (!buf) return NTK_ERR_NOMEM;
-            const uint32_t nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
             std::atomic<int> bad{0};
             std::atomic<size_t> next{0};
             auto work = [&]() {
@@ -422,46 +430,23 @@ int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint8_t **o
                 lib.free_(d);
             };
             std::vector<std::thread> th;
-            for (uint32_t t = 1; t < nt; t++) th.emplace_back(work);
+            try { for (uint32_t t = 1; t < nt; t++) th.emplace_back(work); } catch (...) {}
             work();
             for (auto &t : th) t.join();
-            if (bad) { free(buf); return NTK_ERR_PARSE; }
+            if (bad) { ntk::pgz_free(buf, total); return NTK_ERR_PARSE; }
             *out = buf; *out_n = total;
+            if (info) { info->route = 1; info->chunks = (uint32_t)blocks.size(); info->members = (uint32_t)blocks.size(); }
             return NTK_OK;
         }
     }
-    uint64_t cap = n * 5 + (1 << 20);
-    if (cap > limit) cap = limit;
-    uint8_t *buf = (uint8_t *)malloc(cap);
-    if (!buf) return NTK_ERR_NOMEM;
-    void *d = lib.alloc();
-    if (!d) { free(buf); return NTK_ERR_NOMEM; }
-    uint64_t ip = 0, op = 0;
-    int rc = NTK_OK;
-    while (ip < n) {   // concatenated members (MultiGzDecoder, reference src/parser/mod.rs:95-108)
-        if (n - ip < 18 || in[ip] != 0x1F || in[ip + 1] != 0x8B) {
-            bool pad = true;   // trailing zero padding after the last member is tolerated like zlib-based readers do
-            for (uint64_t i = ip; i < n && pad; i++) pad = in[i] == 0;
-            if (!pad) rc = NTK_ERR_PARSE;
-            break;
-        }
-        size_t used = 0, made = 0;
-        const int r = lib.gzip_ex(d, in + ip, n - ip, buf + op, cap - op, &used, &made);
-        if (r == 3) {   // LIBDEFLATE_INSUFFICIENT_SPACE: grow and retry this member
-            if (cap >= limit) { rc = NTK_ERR_UNSUPPORTED; break; }
-            uint64_t ncap = cap * 2 > limit ? limit : cap * 2;
-            uint8_t *nb = (uint8_t *)realloc(buf, ncap);
-            if (!nb) { rc = NTK_ERR_NOMEM; break; }
-            buf = nb; cap = ncap;
-            continue;
-        }
-        if (r != 0) { rc = NTK_ERR_PARSE; break; }
-        ip += used; op += made;
+    ntk::PgzStats st;
+    const int r = ntk::pgz_inflate(in, n, nt, limit, out, out_n, &st);
+    if (info) {
+        info->route = nt > 1 ? 2 : 3; info->chunks = st.chunks; info->chunks_dropped = st.chunks_dropped; info->members = st.members;
+        info->search_s = st.search_s; info->decode_s = st.decode_s; info->decode_busy_s = st.decode_busy_s; info->crc_s = st.crc_s;
+        info->marker_symbols = st.marker_symbols;
     }
-    lib.free_(d);
-    if (rc != NTK_OK) { free(buf); return rc; }
-    *out = buf; *out_n = op;
-    return NTK_OK;
+    return r == 0 ? NTK_OK : (r == 2 ? NTK_ERR_UNSUPPORTED : (r == 3 ? NTK_ERR_NOMEM : NTK_ERR_PARSE));
 }
 }  // namespace
 
@@ -480,10 +465,10 @@ int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, 
     int rc;
     if (data[0] == 0x1F && data[1] == 0x8B) {
         uint8_t *plain = nullptr; uint64_t plain_n = 0;
-        rc = inflate_whole(data, (uint64_t)st.st_size, n_threads, &plain, &plain_n);
+        rc = inflate_whole(data, (uint64_t)st.st_size, n_threads, &plain, &plain_n, nullptr);
         if (rc == NTK_OK) {
             rc = ntk_scan_buffer_parallel(ctx, plain, plain_n, p, batch_bytes, n_threads, n_records, n_bases);
-            free(plain);
+            ntk::pgz_free(plain, plain_n);
         }
     } else {
         rc = ntk_scan_buffer_parallel(ctx, data, (uint64_t)st.st_size, p, batch_bytes, n_threads, n_records, n_bases);
@@ -491,5 +476,15 @@ int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, 
     munmap(m, (size_t)st.st_size);
     return rc;
 }
+
+int ntk_gunzip(const uint8_t *gz, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info)
+{
+    if (!gz || !out || !out_n) return NTK_ERR_BAD_ARG;
+    *out = nullptr; *out_n = 0;
+    if (n < 18 || gz[0] != 0x1F || gz[1] != 0x8B) return NTK_ERR_PARSE;
+    return inflate_whole(gz, n, n_threads, out, out_n, info);
+}
+
+void ntk_gunzip_free(uint8_t *out, uint64_t out_n) { ntk::pgz_free(out, out_n); }
 
 }  // extern "C"

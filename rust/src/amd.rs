@@ -34,6 +34,12 @@ pub struct NtkRecord {
     pub id: *const u8, pub id_len: u64, pub seq: *const u8, pub seq_len: u64, pub qual: *const u8, pub qual_len: u64,
     pub format: u32, pub line_ending: u32, pub line: u64, pub num_bases: u64, pub byte: u64,
 }
+/// ntk_gunzip: which route inflated the file (1 block gzip, 2 speculative parallel inflate of an ordinary stream, 3 sequential) and its timings
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct NtkGunzipInfo {
+    pub route: u32, pub threads: u32, pub chunks: u32, pub chunks_dropped: u32, pub members: u32, pub reserved: u32,
+    pub search_s: f64, pub decode_s: f64, pub decode_busy_s: f64, pub crc_s: f64, pub marker_symbols: u64,
+}
 pub enum NtkCtx {}
 pub enum NtkBatch {}
 pub enum NtkReader {}
@@ -85,6 +91,8 @@ extern "C" {
     pub fn ntk_fastx_split_points(data: *const u8, n: u64, n_pieces: u32, cuts: *mut u64) -> c_int;
     pub fn ntk_scan_buffer_parallel(ctx: *mut NtkCtx, data: *const u8, n: u64, p: *const NtkParams, batch_bytes: u64, n_threads: u32, n_records: *mut u64, n_bases: *mut u64) -> c_int;
     pub fn ntk_scan_file_parallel(ctx: *mut NtkCtx, path: *const c_char, p: *const NtkParams, batch_bytes: u64, n_threads: u32, n_records: *mut u64, n_bases: *mut u64) -> c_int;
+    pub fn ntk_gunzip(gz: *const u8, n: u64, n_threads: u32, out: *mut *mut u8, out_n: *mut u64, info: *mut NtkGunzipInfo) -> c_int;
+    pub fn ntk_gunzip_free(out: *mut u8, out_n: u64);
     pub fn ntk_normalize(ctx: *mut NtkCtx, seq: *const u8, n: u64, allow_iupac: c_int, out: *mut u8, out_len: *mut u64, changed: *mut c_int) -> c_int;
     pub fn ntk_strip_returns(ctx: *mut NtkCtx, seq: *const u8, n: u64, out: *mut u8, out_len: *mut u64, borrowed: *mut c_int) -> c_int;
     pub fn ntk_reverse_complement(ctx: *mut NtkCtx, seq: *const u8, n: u64, out: *mut u8) -> c_int;

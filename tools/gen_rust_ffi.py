@@ -7,7 +7,7 @@
 tests/test_abi.py::test_rust_binding_is_generated_from_the_header compares the block in the file with this output, so a
 drift in parameter TYPES or constness (u32 <-> u64, *const <-> *mut) fails the CPU suite, not only names and arity.
 The C subset the header uses is small and fixed: scalar typedefs, pointers (one or two levels, const on either),
-array parameters (decay to pointers), opaque handle structs and the three plain structs."""
+array parameters (decay to pointers), opaque handle structs and the four plain structs."""
 import os
 import re
 import sys
@@ -19,7 +19,7 @@ RUST = os.path.join(ROOT, "rust", "src", "amd.rs")
 SCALARS = {"int": "c_int", "double": "f64", "char": "c_char", "void": "c_void", "uint8_t": "u8", "uint16_t": "u16",
            "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "int32_t": "i32", "size_t": "usize"}
 STRUCTS = {"ntk_ctx": "NtkCtx", "ntk_batch": "NtkBatch", "ntk_reader": "NtkReader", "ntk_comm": "NtkComm",
-           "ntk_params": "NtkParams", "ntk_result": "NtkResult", "ntk_record": "NtkRecord"}
+           "ntk_params": "NtkParams", "ntk_result": "NtkResult", "ntk_record": "NtkRecord", "ntk_gunzip_info": "NtkGunzipInfo"}
 
 
 def rust_type(ctype: str) -> str:
