@@ -389,7 +389,7 @@ int run_min_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params 
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;
     const void *fn = pick_min_generic(m, cutoff != 0, p->k <= 25 && !(c->route_off & NTK_ROUTE_NO_F64));
     if (!fn) return NTK_ERR_BAD_ARG;
-    const int threads = 256;
+    const int threads = 512;   // two blocks per CU, each with its 64 KiB LDS histogram
     int per_cu = 0;
     auto it = c->occupancy.find(std::make_pair(fn, threads));
     if (it != c->occupancy.end()) per_cu = it->second;

@@ -906,24 +906,67 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 //     is part of (w <= 49 keeps that in 64 bits).
 // Tile geometry at run time: ScanArgs::min_halo_lanes non-emitting lanes, stride (64 - that) * 16 bytes.
 // ---------------------------------------------------------------------------------------------
-#ifndef NTK_MINGEN_MINBLOCKS
-// 256-thread blocks per CU the register allocation has to allow, general keys (26 <= k <= 31).  1 = no constraint: 102 VGPRs, 4 waves per SIMD
-#define NTK_MINGEN_MINBLOCKS 1
+#ifndef NTK_MINGEN_WAVES
+// waves per SIMD the register allocation has to allow (two 512-thread blocks per CU, each with its 64 KiB histogram: 4 waves per SIMD = 128 VGPRs)
+#define NTK_MINGEN_WAVES 4
 #endif
-#ifndef NTK_MINGEN_MINBLOCKS_F64
-// ... and with the v_min_f64 keys (k <= 25): 128 VGPRs unconstrained = 4 waves per SIMD (with the keys built from the values of lane_tile:
-// 116; 5 blocks fit in 96 there without scratch and changed nothing: (23, 11) 1.50 against 1.49 ms, profiles/r04f/min_generic_5blocks.txt)
-#define NTK_MINGEN_MINBLOCKS_F64 1
-#endif
-// (keys, the left-preferring minimum and the sliding minimum: ntk_tile.hpp, minimizer_windows - shared with the host emulation)
+// The output stage of the generic fused minimizer kernel: per window the side effects on the accumulators, four positions per asm block under
+// the window's validity mask (as the scan2 regions: exec write, v_mad_u64_u32 on the lo word, xor, strand bit, LDS atomic; WIDE: the bits above
+// the lo word summed mod 2^32 and xor-ed as well).  Everything that does not depend on validity is computed outside under the full exec mask.
+struct DevMinOut {
+    uint64_t sum = 0, sum2 = 0;   // lo words, two accumulators used alternately
+    uint32_t sumh = 0, xh = 0;    // WIDE: hi words (mod 2^32: all that 2^32 * sum needs mod 2^64), their xor
+    uint32_t xlo = 0, nfb = 0, one = 1;
+    template <bool WIDE>
+    __device__ __forceinline__ void region(const uint64_t *V, const uint32_t (&off)[4], const uint32_t (&lo)[4], const uint32_t (&hi)[4],
+                                           const uint32_t (&sb)[4])
+    {
+        uint64_t sd;
+#define NTK_M_POS(i, ACC, W)                                                \
+        "s_mov_b64 exec, %[m" #i "]\n"                                      \
+        "v_mad_u64_u32 %[" ACC "], %[sd], %[l" #i "], 1, %[" ACC "]\n"       \
+        "v_xor_b32 %[xlo], %[xlo], %[l" #i "]\n"                            \
+        "v_add_u32 %[nfb], %[nfb], %[f" #i "]\n"                            \
+        W                                                                   \
+        "ds_add_u32 %[o" #i "], %[one]\n"
+#define NTK_M_WIDE(i) "v_add_u32 %[sumh], %[sumh], %[h" #i "]\n v_xor_b32 %[xh], %[xh], %[h" #i "]\n"
+#define NTK_M_IN_N(i) [o##i] "v"(off[i]), [l##i] "v"(lo[i]), [f##i] "v"(sb[i]), [m##i] "s"(V[i])
+#define NTK_M_IN(i) NTK_M_IN_N(i), [h##i] "v"(hi[i])
+        if constexpr (WIDE)
+            asm volatile(NTK_M_POS(0, "sumA", NTK_M_WIDE(0)) NTK_M_POS(1, "sumB", NTK_M_WIDE(1)) NTK_M_POS(2, "sumA", NTK_M_WIDE(2)) NTK_M_POS(3, "sumB", NTK_M_WIDE(3))
+                         "s_mov_b64 exec, -1\n"
+                         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [nfb] "+v"(nfb), [sumh] "+v"(sumh), [xh] "+v"(xh), [sd] "=&s"(sd)
+                         : NTK_M_IN(0), NTK_M_IN(1), NTK_M_IN(2), NTK_M_IN(3), [one] "v"(one) : "memory");
+        else
+            asm volatile(NTK_M_POS(0, "sumA", "") NTK_M_POS(1, "sumB", "") NTK_M_POS(2, "sumA", "") NTK_M_POS(3, "sumB", "")
+                         "s_mov_b64 exec, -1\n"
+                         : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [nfb] "+v"(nfb), [sd] "=&s"(sd)
+                         : NTK_M_IN_N(0), NTK_M_IN_N(1), NTK_M_IN_N(2), NTK_M_IN_N(3), [one] "v"(one) : "memory");
+#undef NTK_M_IN
+#undef NTK_M_IN_N
+#undef NTK_M_WIDE
+#undef NTK_M_POS
+    }
+};
+
+// (keys, minima and window validity: ntk_tile.hpp, minimizer_lane - shared with the host emulation)
+// LDS: a 14-bit histogram (64 KiB, cell = the value's top 14 bits, left-aligned for k < 7) at address 0 - the regions address it with the
+// cell's byte offset alone.  Digests: the lo word of every window's minimizer is summed / xor-ed; k <= 16: that is the value; 17 <= k <= 23:
+// the bits above follow from the histogram when the block writes out (cell and lo word cover every bit, as in the LIGHT scan2 builds);
+// k >= 24: the hi words are accumulated as well (WIDE).
 template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM, bool F64>
-__global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MINBLOCKS) void minimizer_scan_kernel(ScanArgs a)
+__global__ __launch_bounds__(512, NTK_MINGEN_WAVES) void minimizer_scan_kernel(ScanArgs a)
 {
-    __shared__ uint32_t s_hist[kHistBins];
-    __shared__ uint64_t s_red[4 * 4];
+    constexpr int HB = 14, kCells = 1 << HB;
+    struct Lds { uint32_t hist[kCells]; uint64_t red[8 * 4]; };
+    __shared__ Lds L;
+    uint32_t *const s_hist = L.hist;
+    uint64_t *const s_red = L.red;
+    if ((uint32_t)(uintptr_t)&L.hist[0] != 0u) __builtin_trap();
+    typedef typename MinKey<F64>::type Key;
     if (a.zero_acc && blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
-    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) s_hist[i] = 0;
+    for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -936,9 +979,17 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
     const uint32_t HL = a.min_halo_lanes, stride = (64u - HL) * 16u, halo_bytes = HL * 16u;
     DevXL xl;
-    uint64_t sum = 0, xr = 0;
-    uint32_t n_fwd = 0, n_valid = 0;
-    const uint32_t hist_shift = a.bin_shift + 11 - 2;   // (F64 keys: the bin's BYTE offset - the value's top bits, bit 62 masked off with the bins)
+    DevMinOut out;
+    uint32_t nv_lane = 0;
+    // where the cell's 14 bits come from (wave-uniform): 0: k <= 7, the value shifted up; 1: 8 <= k <= 23, a funnel shift of (hi : lo);
+    // 2: k >= 24, the hi word alone (these also sum the hi words: WIDE); 3: f64 keys with 19 <= k <= 23, the key's high word alone
+    const uint32_t kk = a.k;
+    const int mode = kk >= 24 ? 2 : ((F64 && kk >= 19) ? 3 : (kk >= 8 ? 1 : 0));
+    uint32_t cell_sh;   // the shift of the mode, in a VGPR (an SGPR operand would make the full-rate shifts half-rate)
+    {
+        const uint32_t s_ = mode == 2 ? 2 * kk - 48 : (mode == 3 ? 2 * kk - 37 : (mode == 1 ? 2 * kk - 16 : 16 - 2 * kk));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(cell_sh) : "s"(s_));
+    }
 
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
@@ -979,43 +1030,79 @@ __global__ __launch_bounds__(256, F64 ? NTK_MINGEN_MINBLOCKS_F64 : NTK_MINGEN_MI
             Raw16 raw{cur.x, cur.y, cur.z, cur.w};
             if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
             // keys of the 16 own k-mers, window validity and the 16 window minima (ntk_tile.hpp)
-            uint64_t A[16];
+            Key A[16];
             uint32_t invw;
-            minimizer_windows<KW, TIE_RC, ACCEPT_U, F64>(a, xl, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane, tail, A, invw);
-            // the window's minimizer = key >> 1, its strand flag = key & 1.  xor and the flag count are taken on the keys (xor commutes
-            // with the shift; n_fwd = windows - flags) and the window count from the validity mask: 16 instructions per tile fewer each
-            uint32_t vb = invw << 16;
-            n_valid += __popc(~invw & 0xFFFFu);
+            minimizer_lane<KW, TIE_RC, ACCEPT_U, F64>(a, xl, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane, tail, A, invw);
+            nv_lane += __popc(~invw & 0xFFFFu);
+            // the 16 validity masks: one flag is shifted out per position (v_add_co_u32: the carry lands in the mask's SGPR pair)
+            uint64_t V[16];
+            uint32_t vb = ~invw << 16;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const bool valid = !__builtin_add_overflow(vb, vb, &vb);
-                if (valid) {
-                    n_fwd += (uint32_t)A[j] & 1u;   // the keys' strand bits (their meaning: the epilogue)
-                    if constexpr (F64) {   // raw keys: bit 62 and the low 11 bits are taken out of sum / xor after the loop
-                        sum += A[j] >> 11; xr ^= A[j];
-                        atomicAdd((uint32_t *)((char *)s_hist + ((uint32_t)(A[j] >> hist_shift) & (uint32_t)(4 * kHistBins - 4))), 1u);
-                    } else {
-                        sum += A[j] >> 1; xr ^= A[j];
-                        atomicAdd(&s_hist[(uint32_t)(A[j] >> (a.bin_shift + 1))], 1u);
+            for (int j = 0; j < 16; j++) asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(vb), "=s"(V[j]));
+            auto stage = [&](auto mode_tag) {
+                constexpr int M = decltype(mode_tag)::value;
+#pragma unroll
+                for (int jb = 0; jb < 16; jb += 4) {
+                    uint32_t lo[4], hi[4], sb[4], off[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        key_fields(A[jb + i], lo[i], hi[i], sb[i]);
+                        if constexpr (M == 2) off[i] = (hi[i] >> cell_sh) & 0xFFFCu;
+                        else if constexpr (M == 3) {
+                            if constexpr (F64) off[i] = ((uint32_t)(A[jb + i].k >> 32) >> cell_sh) & 0xFFFCu;
+                            else off[i] = 0;
+                        }
+                        else if constexpr (M == 1) off[i] = alignbit(hi[i], lo[i], cell_sh) & 0xFFFCu;
+                        else off[i] = (lo[i] << cell_sh) & 0xFFFCu;
                     }
+                    out.template region<M == 2>(V + jb, off, lo, hi, sb);
                 }
-            }
+            };
+            if (mode == 3) stage(std::integral_constant<int, 3>());
+            else if (mode == 2) stage(std::integral_constant<int, 2>());
+            else if (mode == 1) stage(std::integral_constant<int, 1>());
+            else stage(std::integral_constant<int, 0>());
             cur = nxt; curq = nxtq; voff += stride; tile_byte += stride;
         }
         next = __builtin_amdgcn_readfirstlane(next);
     }
-    // n_fwd counted the keys' bit 0: "reverse complement" - except for the f64 keys under TIE_RC, where the tie-winning strand (rc) carries 0
-    uint64_t nf = (F64 && TIE_RC) ? n_fwd : n_valid - n_fwd, nv = n_valid;
-    if constexpr (F64) { sum -= (uint64_t)n_valid << 51; xr = (xr >> 11) & ((1ull << 51) - 1); }
-    else xr >>= 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
+    const bool wide = kk >= 24, light = kk >= 17 && kk <= 23;
+    uint64_t sum = out.sum + out.sum2, xr = out.xlo;
+    if (wide) {
+        uint32_t sumh = out.sumh, xh = out.xh;
+        if constexpr (F64) { sumh -= nv_lane << 19; xh ^= (nv_lane & 1u) << 19; }   // the keys' marker bit rode along in every hi word
+        sum += (uint64_t)sumh << 32;
+        xr |= (uint64_t)xh << 32;
+    }
+    // the strand bits counted: "reverse complement" - except for the f64 keys under TIE_RC, where the tie-winning strand (rc) carries 0
+    uint64_t nf = (F64 && TIE_RC) ? out.nfb : nv_lane - out.nfb, nv = nv_lane;
+    __syncthreads();
+    // cells -> the result's bins (the leading min(k, 6) bases): four cells per bin for k >= 7, 4^(7 - k) for k <= 6
+    uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
+    const uint32_t cshift = kk >= 7 ? 2u : 14u - 2u * kk, nbins = kk >= 6 ? (uint32_t)kHistBins : 1u << (2u * kk);
+    uint64_t shi = 0, xf = 0;
+    for (uint32_t c = threadIdx.x; c < (uint32_t)kHistBins; c += blockDim.x) {
+        uint32_t tot = 0;
+        if (c < nbins)
+            for (uint32_t q = 0; q < (1u << cshift); q++) {
+                const uint32_t f = (c << cshift) + q, h = s_hist[f];
+                tot += h;
+                if (light) { shi += (uint64_t)(f >> (46u - 2u * kk)) * h; xf ^= (h & 1u) ? f : 0u; }
+            }
+        ph[c] = tot;
+    }
+    if (light) {
+        const uint32_t low_bits = 2u * kk - 14u;   // 20 .. 32: the lo word below the cell's bits
+        sum += shi << 32;
+        xr = (xf << low_bits) | (low_bits >= 32u ? xr : (xr & ((1ull << low_bits) - 1ull)));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         sum += __shfl_xor(sum, o, 64); xr ^= __shfl_xor(xr, o, 64); nf += __shfl_xor(nf, o, 64); nv += __shfl_xor(nv, o, 64);
     }
     if (lane == 0) { s_red[wave * 4 + 0] = nv; s_red[wave * 4 + 1] = nf; s_red[wave * 4 + 2] = sum; s_red[wave * 4 + 3] = xr; }
     __syncthreads();
-    uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
-    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
     if (threadIdx.x == 0) {
         uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
         for (uint32_t w = 0; w < (blockDim.x >> 6); w++) { tv += s_red[w * 4 + 0]; tf += s_red[w * 4 + 1]; ts += s_red[w * 4 + 2]; tx ^= s_red[w * 4 + 3]; }

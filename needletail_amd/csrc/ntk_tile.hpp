@@ -360,101 +360,117 @@ NTK_HD void lane_tile(const ScanArgs &a, Sink &sink, XL &xl, Raw16 raw, int64_t 
 // Generic fused windowed minimizers (minimizer_scan_kernel, ntk_kernels.hpp): the per-lane part - keys of the lane's 16 k-mers, window
 // validity, and the sliding minimum over ANY run-time w <= 49 (k <= 31).  Semantics and scheme: the comment block above the kernel.
 // Cross-lane words go through XL::prev_auto (device: DPP wave_shr:1; host emulation: the call sites of a lane numbered in order).
+// Round 5: the bytes are decoded by the scan2 encode (encode16_sv2 below; the round-1 transpose encode cost 56 VALU per tile, this one 19 +
+// 22 for the lane's break mask), and the keys of 26 <= k <= 31 are (value, strand) register triples compared strictly (4 VALU per minimum
+// where the (value << 1 | strand) form needed 5 and a register pair built per compare).
 //
-// F64 (k <= 25): key = bit 62 | value << 11 | (tile position x = 16 * lane + j) << 1 | strand flag - unique per position and ordered by
-// (value, position), bit 61 clear: a positive NORMAL double whose order is its bit pattern's, so ONE v_min_f64 is the leftmost minimum
-// (the general form needs v_or + v_mov + v_cmp_gt_u64 + two v_cndmask per minimum: the compiler has to build the pair (r | 1)).
+// Two key forms:
+//   KeyF (k <= 25): bit 62 | value << 11 | (tile position x = 16 * lane + j) << 1 | strand bit - unique per position and ordered by
+//        (value, position), bit 61 clear: a positive NORMAL double whose order is its bit pattern's, so ONE v_min_f64 is the leftmost minimum;
+//   KeyG (any k): the value in a register pair, the strand flag beside it.  A minimum takes its RIGHT operand only when that one's value is
+//        strictly smaller: the left operand always covers the older positions, so ties go to the leftmost k-mer with no position in the key.
 // ---------------------------------------------------------------------------------------------
-template <int KW, bool F64>
-struct MinimizerSinkG {
-    uint64_t key[16];
-    uint32_t inval = 0, lane16 = 0;   // lane16 = 16 * lane
-    int64_t base = 0;
-    NTK_HD void begin_tile(int64_t lane_base, uint32_t inval16, bool) { base = lane_base; inval = inval16; }
-    NTK_HD void emit(int j, bool, bool take_fwd, uint32_t hi, uint32_t lo)
-    {
-        const uint64_t v = KW == 2 ? (((uint64_t)hi << 32) | lo) : (uint64_t)lo;
-        if constexpr (F64) {
-            // word by word (as one 64-bit expression the compiler shifts the pair and ORs three times: 6 ops per key instead of 4):
-            // hi word = one funnel shift + the marker bit, lo word = one shift-or with the tag
-            const uint32_t tag = ((lane16 + (uint32_t)j) << 1) | (take_fwd ? 0u : 1u);
-            const uint32_t kh = (KW == 2 ? alignbit(hi, lo, 21) : (lo >> 21)) | 0x40000000u;
-            key[j] = ((uint64_t)kh << 32) | ((lo << 11) | tag);
-        } else {
-            key[j] = (v << 1) | (take_fwd ? 0u : 1u);
-        }
-    }
-    NTK_HD void end_tile() {}
-};
+struct KeyF { uint64_t k; };
+struct KeyG { uint64_t v; uint32_t s; };
 
-// the minimum that prefers its LEFT operand on value ties and never lets the strand flag decide
-template <bool F64>
-NTK_HD uint64_t min_left(uint64_t l, uint64_t r)
+NTK_HD KeyF key_min(KeyF l, KeyF r)
 {
-    if constexpr (F64) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint64_t m;
-        asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(l), "v"(r));
-        return m;
+    KeyF m;
+    asm("v_min_f64 %0, %1, %2" : "=v"(m.k) : "v"(l.k), "v"(r.k));
+    return m;
 #else
-        return l < r ? l : r;   // (keys are unique per position; positive normal doubles order like their patterns)
+    return l.k < r.k ? l : r;   // (keys are unique per position; positive normal doubles order like their patterns)
 #endif
-    } else {
-        return l <= (r | 1ull) ? l : r;
-    }
+}
+NTK_HD KeyG key_min(KeyG l, KeyG r)
+{
+    const bool t = r.v < l.v;   // v_cmp_lt_u64 into vcc, three v_cndmask on it
+    KeyG m;
+    m.v = t ? r.v : l.v;
+    m.s = t ? r.s : l.s;
+    return m;
 }
 template <class XL>
-NTK_HD uint64_t prev_lane64(XL &xl, uint64_t v)
+NTK_HD KeyF key_prev(XL &xl, KeyF v)
 {
-    const uint32_t hi = xl.prev_auto((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | xl.prev_auto((uint32_t)v);
+    const uint32_t hi = xl.prev_auto((uint32_t)(v.k >> 32));
+    KeyF r;
+    r.k = ((uint64_t)hi << 32) | xl.prev_auto((uint32_t)v.k);
+    return r;
 }
-// X[x] <- min_left(Y[x - Q], X[x]) for the 16 own positions, Q = 1, 2, 4, 8, 16; Y may be X itself (doubling).  In place, descending j;
+template <class XL>
+NTK_HD KeyG key_prev(XL &xl, KeyG v)
+{
+    const uint32_t hi = xl.prev_auto((uint32_t)(v.v >> 32));
+    KeyG r;
+    r.v = ((uint64_t)hi << 32) | xl.prev_auto((uint32_t)v.v);
+    r.s = xl.prev_auto(v.s);
+    return r;
+}
+// X[x] <- min(Y[x - Q], X[x]) for the 16 own positions, Q = 1, 2, 4, 8, 16; Y may be X itself (doubling).  In place, descending j;
 // the words that come from the previous lane are fetched first.
-template <int Q, bool F64, class XL>
-NTK_HD void min_shifted(XL &xl, uint64_t (&X)[16], const uint64_t (&Y)[16])
+template <int Q, class Key, class XL>
+NTK_HD void min_shifted(XL &xl, Key (&X)[16], const Key (&Y)[16])
 {
     if constexpr (Q < 16) {
-        uint64_t imp[Q];
+        Key imp[Q];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int j = 0; j < Q; j++) imp[j] = prev_lane64(xl, Y[16 + j - Q]);
+        for (int j = 0; j < Q; j++) imp[j] = key_prev(xl, Y[16 + j - Q]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int j = 15; j >= 0; j--) X[j] = min_left<F64>(j >= Q ? Y[j - Q] : imp[j], X[j]);
+        for (int j = 15; j >= 0; j--) X[j] = key_min(j >= Q ? Y[j - Q] : imp[j], X[j]);
     } else {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int h = 0; h < 2; h++) {   // eight at a time: 16 more live registers instead of 32
-            uint64_t imp[8];
+        for (int h = 0; h < 2; h++) {   // eight at a time: fewer live registers
+            Key imp[8];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int j = 0; j < 8; j++) imp[j] = prev_lane64(xl, Y[8 * h + j]);
+            for (int j = 0; j < 8; j++) imp[j] = key_prev(xl, Y[8 * h + j]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int j = 0; j < 8; j++) X[8 * h + j] = min_left<F64>(imp[j], X[8 * h + j]);
+            for (int j = 0; j < 8; j++) X[8 * h + j] = key_min(imp[j], X[8 * h + j]);
         }
     }
 }
-// A[x] <- min_left(M[x - S], M[x]) for ANY shift 0 < S <= 31: two overlapping windows of M's span cover span + S positions
-template <int S, bool F64, class XL>
-NTK_HD void min_overlap(XL &xl, uint64_t (&A)[16], const uint64_t (&M)[16])
+// A[x] <- min(M[x - S], M[x]) for ANY shift 0 < S <= 31: two overlapping windows of M's span cover span + S positions
+template <int S, class Key, class XL>
+NTK_HD void min_overlap(XL &xl, Key (&A)[16], const Key (&M)[16])
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int j = 0; j < 16; j++) {
-        uint64_t l;
+        Key l;
         if (j >= S) l = M[j - S];
-        else if (j - S + 16 >= 0) l = prev_lane64(xl, M[j - S + 16]);
-        else l = prev_lane64(xl, prev_lane64(xl, M[j - S + 32]));
-        A[j] = min_left<F64>(l, M[j]);
+        else if (j - S + 16 >= 0) l = key_prev(xl, M[j - S + 16]);
+        else l = key_prev(xl, key_prev(xl, M[j - S + 32]));
+        A[j] = key_min(l, M[j]);
     }
+}
+
+// The lane's 16-bit break mask (base i at bit 15 - i) from the scan2 encode's expected / actual letters: per dword one xor, the SWAR
+// "byte is not zero" test and ONE v_dot4_u32_u8 that gathers the four flags with the weights of their bit positions (22 VALU for 16 bases).
+NTK_HD uint32_t bad16_from_letters(const uint32_t (&ex)[4], const uint32_t (&uu)[4])
+{
+    uint32_t hi = 0, lo = 0;   // 0x80 x (flags of bases 0..7 / 8..15, first base in bit 7)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int d = 0; d < 4; d++) {
+        const uint32_t dif = ex[d] ^ uu[d];
+        const uint32_t nz = or_and((dif & 0x7F7F7F7Fu) + 0x7F7F7F7Fu, dif, 0x80808080u);   // 0x80 in every byte that differs
+        const uint32_t wt = (d & 1) ? 0x01020408u : 0x10204080u;                           // byte b of dword d = base 4 d + b -> weight 2^(7 - (4 d + b) % 8)
+        if (d < 2) hi = dot4(nz, wt, hi); else lo = dot4(nz, wt, lo);
+    }
+    return (hi << 1) | (lo >> 7);
 }
 
 // The f64 keys of a lane's 16 k-mers (k <= 25) straight from the code streams, both strands, no compare and no select: the key of a strand is
@@ -467,43 +483,28 @@ NTK_HD void min_overlap(XL &xl, uint64_t (&A)[16], const uint64_t (&M)[16])
 //   * strand bit: the strand that wins a tie (equal values at the same position) carries 0 - reverse complement under TIE_RC (reference
 //     src/kmer.rs:124-128), forward otherwise (src/bitkmer.rs:138-142); so bit 0 of a key says "forward" under TIE_RC and "reverse
 //     complement" otherwise.
-// Against the lane_tile route (values of both strands, 64-bit compare into an SGPR pair, three selects, then the key): 697 instead of 863
-// issue cycles per tile by the class costs, and no SGPR-writing VALU op.
-template <bool TIE_RC, bool ACCEPT_U, class XL>
-NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, uint64_t (&key)[16], uint32_t &inval)
+template <bool TIE_RC, class XL>
+NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, uint32_t code, uint32_t rcode, uint32_t lane, KeyF (&key)[16])
 {
-    Enc en = encode16<ACCEPT_U>(raw);
-    if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
-        const int64_t keep = (int64_t)a.n_bytes - lane_base;
-        en.bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
-    }
-    const uint32_t c1 = xl.prev_auto(en.code), c2 = xl.prev_auto(c1);
-    const uint32_t r1 = xl.prev_auto(en.rcode);
-    if (a.min_smear_kw[0]) {
-        // k + w - 1 <= 49: the break bits themselves, smeared once over k + w - 1 by the caller
-        inval = en.bad;
-    } else {
-        const uint32_t b1 = xl.prev_auto(en.bad), b2 = xl.prev_auto(b1);
-        uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | en.bad;   // windows of k containing a break (as lane_tile)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
-        inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
-    }
+    const uint32_t c1 = xl.prev_auto(code), c2 = xl.prev_auto(c1);
+    const uint32_t r1 = xl.prev_auto(rcode);
     // Q = (rcode : r1 : r2 : r3) >> (64 - 2k), Q[3] the least significant word; the value whose top group is own base j sits at Q bits
     // [34 + 2j, 34 + 2j + 2k)
     const uint32_t sh = 64u - 2u * a.k;   // 14 .. 62
     uint32_t Q[4];
     if (sh < 32u) {
-        Q[0] = en.rcode >> sh; Q[1] = alignbit(en.rcode, r1, sh); Q[2] = xl.prev_auto(Q[1]); Q[3] = xl.prev_auto(Q[2]);
+        Q[0] = rcode >> sh; Q[1] = alignbit(rcode, r1, sh); Q[2] = xl.prev_auto(Q[1]); Q[3] = xl.prev_auto(Q[2]);
     } else {
-        Q[0] = 0u; Q[1] = en.rcode >> (sh - 32u); Q[2] = alignbit(en.rcode, r1, sh - 32u); Q[3] = xl.prev_auto(Q[2]);
+        Q[0] = 0u; Q[1] = rcode >> (sh - 32u); Q[2] = alignbit(rcode, r1, sh - 32u); Q[3] = xl.prev_auto(Q[2]);
     }
     const uint32_t vbits = 2u * a.k;
-    const uint32_t mask_lo = vbits >= 21u ? 0xFFFFF800u : (((1u << vbits) - 1u) << 11);
-    const uint32_t mask_hi = vbits > 21u ? (1u << (vbits - 21u)) - 1u : 0u;
-    const uint32_t marker = 0x40000000u;
+    uint32_t mask_lo = vbits >= 21u ? 0xFFFFF800u : (((1u << vbits) - 1u) << 11);
+    uint32_t mask_hi = vbits > 21u ? (1u << (vbits - 21u)) - 1u : 0u;
+    uint32_t marker = 0x40000000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the three wave-uniform operands of the 64 v_bitop3 below, held in VGPRs: with an SGPR operand a v_bitop3 issues at half rate
+    asm("" : "+v"(mask_lo)); asm("" : "+v"(mask_hi)); asm("" : "+v"(marker));
+#endif
     const uint32_t lane32 = lane << 5;
     constexpr uint32_t fbitF = TIE_RC ? 1u : 0u, fbitR = TIE_RC ? 0u : 1u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -513,42 +514,84 @@ NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lan
         // forward: the value ends (LSB) at stream bit e = 30 - 2j of (c2 : c1 : code)
         uint32_t fL, fH;
         if (j <= 9) {
-            fL = alignbit(c1, en.code, 19 - 2 * j);            // stream bits [e - 11, e + 21)
-            fH = alignbit(c2, c1, 19 - 2 * j);                 // stream bits [e + 21, e + 53)
+            fL = alignbit(c1, code, 19 - 2 * j);            // stream bits [e - 11, e + 21)
+            fH = alignbit(c2, c1, 19 - 2 * j);              // stream bits [e + 21, e + 53)
         } else {
-            const uint32_t fl = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
+            const uint32_t fl = j == 15 ? code : alignbit(c1, code, 30 - 2 * j);
             fL = fl << 11;
-            fH = alignbit(c1, en.code, 51 - 2 * j);
+            fH = alignbit(c1, code, 51 - 2 * j);
         }
         // reverse complement: the value's LSB at Q bit p0 = 34 + 2j; lo window starts at p0 - 11 = 23 + 2j, hi window at p0 + 21 = 55 + 2j
         const int sL = 23 + 2 * j, sH = 55 + 2 * j;
         const uint32_t rL = sL < 32 ? alignbit(Q[2], Q[3], sL) : alignbit(Q[1], Q[2], sL - 32);
         const uint32_t rH = sH < 64 ? alignbit(Q[1], Q[2], sH - 32) : alignbit(Q[0], Q[1], sH - 64);
         const uint32_t tag = lane32 | (uint32_t)(2 * j);
-        const uint64_t kf = ((uint64_t)and_or(fH, mask_hi, marker) << 32) | and_or(fL, mask_lo, tag | fbitF);
-        const uint64_t kr = ((uint64_t)and_or(rH, mask_hi, marker) << 32) | and_or(rL, mask_lo, tag | fbitR);
-        key[j] = min_left<true>(kf, kr);
+        KeyF kf, kr;
+        kf.k = ((uint64_t)and_or(fH, mask_hi, marker) << 32) | and_or(fL, mask_lo, tag | fbitF);
+        kr.k = ((uint64_t)and_or(rH, mask_hi, marker) << 32) | and_or(rL, mask_lo, tag | fbitR);
+        key[j] = key_min(kf, kr);
     }
 }
 
-// One lane of one tile: A[j] = key of the minimizer of the window ending at own byte j (value, strand flag: see the key forms), invw bit
-// 15 - j set = that window is not emitted (a k-mer of it is invalid, or a halo lane).  Lanes 0 and 1 are the k-mer halo of lane_tile,
-// lanes below a.min_halo_lanes hold k-mers that the first emitting lanes' windows need.
-template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64, class XL>
-NTK_HD void minimizer_windows(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, uint64_t (&A)[16], uint32_t &invw)
+// The (value, strand) keys of a lane's 16 k-mers for any k <= 32: both strands' values as stream windows (forward: the 32 bits ending at
+// base j + the previous lane's same word, masked; reverse complement: the stream right-aligned to the value, two windows), one 64-bit compare
+// with the path's tie rule, three selects.  s = 0: forward strand, 1: reverse complement.
+template <int KW, bool TIE_RC, class XL>
+NTK_HD void minimizer_keys_general(const ScanArgs &a, XL &xl, uint32_t code, uint32_t rcode, KeyG (&key)[16])
 {
-    MinimizerSinkG<KW, F64> sink;
-    if constexpr (F64) {
-        minimizer_keys_f64<TIE_RC, ACCEPT_U>(a, xl, raw, lane_base, lane, tail_tile, sink.key, sink.inval);
-    } else {
-        sink.lane16 = lane * 16u;
-        lane_tile<KW, true, TIE_RC, ACCEPT_U, 0>(a, sink, xl, raw, lane_base, lane < (uint32_t)kHaloLanes, tail_tile);
+    const uint32_t c1 = xl.prev_auto(code), r1 = xl.prev_auto(rcode);
+    uint32_t mask_hi = a.mask_hi, mask_lo = a.mask_lo;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(mask_hi)); asm("" : "+v"(mask_lo));   // (in VGPRs: a plain v_and with an SGPR operand issues at half rate)
+#endif
+    uint32_t Q[3];
+    Q[0] = rcode >> a.sh_r;
+    Q[1] = alignbit(rcode, r1, a.sh_r);
+    Q[2] = KW == 2 ? xl.prev_auto(Q[1]) : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 16; j++) {
+        uint32_t fl = j == 15 ? code : alignbit(c1, code, 30 - 2 * j), fh = 0, rl, rh = 0;
+        if (KW == 2) {
+            fh = xl.prev_auto(fl) & mask_hi;
+            rh = win32(Q, 2 * (15 - j)) & mask_hi;
+            rl = win32(Q, 32 + 2 * (15 - j));
+        } else {
+            fl &= a.mask_lo;
+            rl = win32(Q, 2 * (15 - j)) & mask_lo;
+        }
+        const uint64_t f = ((uint64_t)fh << 32) | fl, r = ((uint64_t)rh << 32) | rl;
+        const bool take_rc = TIE_RC ? (r <= f) : (r < f);   // one compare: ties report the reverse complement on the byte path only
+        const uint32_t vl = take_rc ? rl : fl, vh = take_rc ? rh : fh;   // (selected word by word: as one 64-bit select the compiler turns it into a minimum and compares twice)
+        key[j].v = ((uint64_t)vh << 32) | vl;
+        key[j].s = take_rc ? 1u : 0u;
     }
-    // window validity: a k-mer that is invalid takes the w windows it is part of with it (f64 keys with k + w - 1 <= 49: sink.inval holds
-    // the break bits and ONE smear over k + w - 1 does both steps)
-    const uint32_t b1 = xl.prev_auto(sink.inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
-    uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | sink.inval;
-    const bool one_smear = F64 && a.min_smear_kw[0] != 0;
+}
+
+// invw bit 15 - j set = the window ending at own byte j is not emitted: one of its k + w - 1 bytes is a break (bad = the lane's break mask,
+// base i at bit 15 - i), or the lane is one of the tile's a.min_halo_lanes non-emitting lanes.  k + w - 1 <= 49: ONE smear of the break bits
+// over the window ends a break spoils (own 16 + 48 earlier positions fit 64 bits); longer spans: the k smear (k-mers), then the w smear.
+template <class XL>
+NTK_HD uint32_t minimizer_invalid16(const ScanArgs &a, XL &xl, uint32_t bad, int64_t lane_base, uint32_t lane, bool tail_tile)
+{
+    if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
+        const int64_t keep = (int64_t)a.n_bytes - lane_base;
+        bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
+    }
+    uint32_t inval = bad;
+    const bool one_smear = a.min_smear_kw[0] != 0;
+    if (!one_smear) {
+        const uint32_t b1 = xl.prev_auto(bad), b2 = xl.prev_auto(b1);
+        uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | bad;   // windows of k containing a break
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+        inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    }
+    const uint32_t b1 = xl.prev_auto(inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
+    uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | inval;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -556,17 +599,22 @@ NTK_HD void minimizer_windows(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane
         const uint32_t sft = one_smear ? a.min_smear_kw[i] : a.min_smear[i];
         if (sft) bw |= bw >> sft;   // (wave-uniform)
     }
-    invw = lane < a.min_halo_lanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
-    // sliding minimum over W: M doubles while 2q <= W, then two overlapping windows of q make W (every branch is wave-uniform)
+    return lane < a.min_halo_lanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+}
+
+// sliding minimum over W = a.min_w: M doubles while 2q <= W, then two overlapping windows of q make W (every branch is wave-uniform).
+// A[j] = the minimizer's key of the window ending at own byte j.
+template <class Key, class XL>
+NTK_HD void minimizer_slide(const ScanArgs &a, XL &xl, Key (&M)[16], Key (&A)[16])
+{
     const uint32_t W = a.min_w;
-    uint64_t (&M)[16] = sink.key;
-    if (W >= 2) min_shifted<1, F64>(xl, M, M);
-    if (W >= 4) min_shifted<2, F64>(xl, M, M);
-    if (W >= 8) min_shifted<4, F64>(xl, M, M);
-    if (W >= 16) min_shifted<8, F64>(xl, M, M);
-    if (W >= 32) min_shifted<16, F64>(xl, M, M);
+    if (W >= 2) min_shifted<1>(xl, M, M);
+    if (W >= 4) min_shifted<2>(xl, M, M);
+    if (W >= 8) min_shifted<4>(xl, M, M);
+    if (W >= 16) min_shifted<8>(xl, M, M);
+    if (W >= 32) min_shifted<16>(xl, M, M);
     switch (a.min_overlap) {   // W - (M's span): 0 .. 17 for W <= 49
-#define NTK_MIN_CASE(S) case S: min_overlap<S, F64>(xl, A, M); break;
+#define NTK_MIN_CASE(S) case S: min_overlap<S>(xl, A, M); break;
         NTK_MIN_CASE(1) NTK_MIN_CASE(2) NTK_MIN_CASE(3) NTK_MIN_CASE(4) NTK_MIN_CASE(5) NTK_MIN_CASE(6) NTK_MIN_CASE(7) NTK_MIN_CASE(8)
         NTK_MIN_CASE(9) NTK_MIN_CASE(10) NTK_MIN_CASE(11) NTK_MIN_CASE(12) NTK_MIN_CASE(13) NTK_MIN_CASE(14) NTK_MIN_CASE(15)
         NTK_MIN_CASE(16) NTK_MIN_CASE(17)
@@ -578,6 +626,16 @@ NTK_HD void minimizer_windows(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane
             for (int j = 0; j < 16; j++) A[j] = M[j];
     }
 }
+// (value's low 32 bits, bits above them, strand bit as the key form carries it) of a window's minimizer
+NTK_HD void key_fields(KeyF k, uint32_t &lo, uint32_t &hi, uint32_t &sbit)
+{
+    const uint32_t mh = (uint32_t)(k.k >> 32), ml = (uint32_t)k.k;
+    lo = alignbit(mh, ml, 11);
+    hi = mh >> 11;          // (bit 19 = the key's marker bit: taken out by whoever sums these)
+    sbit = ml & 1u;
+}
+NTK_HD void key_fields(KeyG k, uint32_t &lo, uint32_t &hi, uint32_t &sbit) { lo = (uint32_t)k.v; hi = (uint32_t)(k.v >> 32); sbit = k.s; }
+
 // host side: the run-time geometry of a window length (ScanArgs::min_*), w = 1..49
 inline void scan_args_set_window(ScanArgs &a, uint32_t w)
 {
@@ -1162,5 +1220,21 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
     }
 }
 
+// One lane of one tile of the generic fused minimizer kernel: A[j] = key of the minimizer of the window ending at own byte j, invw bit
+// 15 - j set = that window is not emitted.  Lanes 0 and 1 are the k-mer halo, lanes below a.min_halo_lanes hold k-mers that the first
+// emitting lanes' windows need.
+template <bool F64> struct MinKey { typedef KeyG type; };
+template <> struct MinKey<true> { typedef KeyF type; };
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64, class XL>
+NTK_HD void minimizer_lane(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, typename MinKey<F64>::type (&A)[16],
+                           uint32_t &invw)
+{
+    const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
+    typename MinKey<F64>::type M[16];
+    if constexpr (F64) minimizer_keys_f64<TIE_RC>(a, xl, en.code, en.rcode, lane, M);
+    else minimizer_keys_general<KW, TIE_RC>(a, xl, en.code, en.rcode, M);
+    invw = minimizer_invalid16(a, xl, bad16_from_letters(en.ex, en.uu), lane_base, lane, tail_tile);
+    minimizer_slide(a, xl, M, A);
+}
 
 }  // namespace ntk

@@ -328,7 +328,7 @@ void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
     mp.finish(st);
 }
 
-// The generic fused minimizer kernel (minimizer_scan_kernel): the same per-lane source (ntk_tile.hpp minimizer_windows: keys, window validity,
+// The generic fused minimizer kernel (minimizer_scan_kernel): the same per-lane source (ntk_tile.hpp minimizer_lane: scan2 encode, keys, window validity,
 // doubling + two overlapping windows), the kernel's run-time tile geometry (a.min_halo_lanes non-emitting lanes) and its output stage
 // restated on the decoded keys.
 template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64>
@@ -342,13 +342,16 @@ void run_min_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs
         for (uint32_t l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             const int64_t lane_base = (int64_t)(t * stride) - (int64_t)halo_bytes + l * 16;
-            uint64_t A[16];
+            typename MinKey<F64>::type A[16];
             uint32_t invw;
-            minimizer_windows<KW, TIE_RC, ACCEPT_U, F64>(a, xl, load16q(buf, n_padded, lane_base), lane_base, l, tail, A, invw);
+            minimizer_lane<KW, TIE_RC, ACCEPT_U, F64>(a, xl, load16q(buf, n_padded, lane_base), lane_base, l, tail, A, invw);
             for (int j = 0; j < 16; j++) {
                 if ((invw >> (15 - j)) & 1) continue;
-                const uint64_t v = F64 ? (A[j] & ~(1ull << 62)) >> 11 : A[j] >> 1;
-                const bool is_rc = (F64 && TIE_RC) ? !(A[j] & 1) : (A[j] & 1);   // f64 keys: the tie-winning strand carries 0
+                uint32_t lo, hi, sbit;
+                key_fields(A[j], lo, hi, sbit);
+                if (F64) hi &= ~(1u << 19);   // the key's marker bit (the kernel takes it out of its sums once per block)
+                const uint64_t v = ((uint64_t)hi << 32) | lo;
+                const bool is_rc = (F64 && TIE_RC) ? !sbit : (sbit != 0);   // f64 keys: the tie-winning strand carries 0
                 st->n_total++; st->n_fwd += !is_rc; st->sum += v; st->xr ^= v; st->hist[v >> a.bin_shift]++;
             }
         }
