@@ -370,14 +370,17 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
 
 // Generic fused windowed minimizers (ntk_kernels.hpp minimizer_scan_kernel): any k <= 31 and w <= 49 of the canonical paths, with or
 // without a quality stream; the tile geometry depends on w (2 + ceil((w - 1) / 16) non-emitting lanes).
-const void *pick_min_generic(const Mode &m, bool quality, bool f64)   // f64: k <= 25 (one v_min_f64 per minimum, ntk_tile.hpp)
+const void *pick_min_generic(const Mode &m, bool quality, bool f64, uint32_t k)   // f64: k <= 25 (one v_min_f64 per minimum, ntk_tile.hpp)
 {
     const int kw = f64 ? 2 : m.kw;   // (the f64 keys are built from the code streams for any k: one instantiation serves both word counts)
-#define NTK_PICK_MG(KW, T, U, Q, F) if (kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q && f64 == F) return (const void *)&minimizer_scan_kernel<KW, T, U, Q, F>;
-#define NTK_PICK_MG4(KW, Q, F) NTK_PICK_MG(KW, false, false, Q, F) NTK_PICK_MG(KW, false, true, Q, F) NTK_PICK_MG(KW, true, false, Q, F) NTK_PICK_MG(KW, true, true, Q, F)
-    NTK_PICK_MG4(2, false, true) NTK_PICK_MG4(2, true, true)
-    NTK_PICK_MG4(2, false, false) NTK_PICK_MG4(2, true, false)   // 26 <= k <= 31
-    NTK_PICK_MG4(1, false, false) NTK_PICK_MG4(1, true, false)   // (only under NTK_ROUTE_NO_F64, the A/B switch)
+    const int mode = min_gen_mode(k, f64);
+#define NTK_PICK_MG(KW, T, U, Q, F, MD) if (kw == KW && m.tie_rc == T && m.accept_u == U && quality == Q && f64 == F && mode == MD) return (const void *)&minimizer_scan_kernel<KW, T, U, Q, F, MD>;
+#define NTK_PICK_MG4(KW, Q, F, MD) NTK_PICK_MG(KW, false, false, Q, F, MD) NTK_PICK_MG(KW, false, true, Q, F, MD) NTK_PICK_MG(KW, true, false, Q, F, MD) NTK_PICK_MG(KW, true, true, Q, F, MD)
+#define NTK_PICK_MG8(KW, F, MD) NTK_PICK_MG4(KW, false, F, MD) NTK_PICK_MG4(KW, true, F, MD)
+    NTK_PICK_MG8(2, true, 0) NTK_PICK_MG8(2, true, 1) NTK_PICK_MG8(2, true, 3) NTK_PICK_MG8(2, true, 2)   // f64 keys: k <= 7, 8..18, 19..23, 24..25
+    NTK_PICK_MG8(2, false, 2)                                                                             // 26 <= k <= 31
+    NTK_PICK_MG8(2, false, 1) NTK_PICK_MG8(1, false, 0) NTK_PICK_MG8(1, false, 1)                         // (only under NTK_ROUTE_NO_F64, the A/B switch)
+#undef NTK_PICK_MG8
 #undef NTK_PICK_MG4
 #undef NTK_PICK_MG
     return nullptr;
@@ -387,9 +390,10 @@ int run_min_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params 
 {
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;
-    const void *fn = pick_min_generic(m, cutoff != 0, p->k <= 25 && !(c->route_off & NTK_ROUTE_NO_F64));
+    const bool f64 = p->k <= 25 && !(c->route_off & NTK_ROUTE_NO_F64);
+    const void *fn = pick_min_generic(m, cutoff != 0, f64, p->k);
     if (!fn) return NTK_ERR_BAD_ARG;
-    const int threads = 512;   // two blocks per CU, each with its 64 KiB LDS histogram
+    const int threads = min_gen_threads(f64);   // 512: two blocks per CU, 768: one (ntk_kernels.hpp), each with its 64 KiB LDS histogram
     int per_cu = 0;
     auto it = c->occupancy.find(std::make_pair(fn, threads));
     if (it != c->occupancy.end()) per_cu = it->second;

@@ -627,11 +627,11 @@ struct DevMasks2 {
             asm volatile(NTK_R_POS(0, "v_add_u32 %[nfb], %[nfb], %[f0]\n") NTK_R_POS(1, "v_add_u32 %[nfb], %[nfb], %[f1]\n")
                          NTK_R_POS(2, "v_add_u32 %[nfb], %[nfb], %[f2]\n") NTK_R_POS(3, "v_add_u32 %[nfb], %[nfb], %[f3]\n") "s_mov_b64 exec, -1\n"
                          : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [nfb] "+v"(nf_bits), [sd] "=&s"(sd)
-                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory");
         else
             asm volatile(NTK_R_POS(0, "") NTK_R_POS(1, "") NTK_R_POS(2, "") NTK_R_POS(3, "") "s_mov_b64 exec, -1\n"
                          : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [sd] "=&s"(sd)
-                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory");
 #undef NTK_R_IN
 #undef NTK_R_POS
     }
@@ -673,7 +673,7 @@ struct DevMasks2 {
 #define NTK_R_IN(i) [o##i] "v"(off[i]), [l##i] "v"(lo[i]), [h##i] "v"(hi[i]), NTK_R_MASKS(i)
             asm volatile(NTK_R_POS(0) NTK_R_POS(1) NTK_R_POS(2) NTK_R_POS(3) "s_mov_b64 exec, -1\n"
                          : [sumA] "+v"(sum), [sumB] "+v"(sum2), [sumh] "+v"(sumh), [xlo] "+v"(xlo), [xh] "+v"(xh), [sd] "=&s"(sd)
-                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory");
 #undef NTK_R_IN
 #undef NTK_R_POS
         }
@@ -906,10 +906,16 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 //     is part of (w <= 49 keeps that in 64 bits).
 // Tile geometry at run time: ScanArgs::min_halo_lanes non-emitting lanes, stride (64 - that) * 16 bytes.
 // ---------------------------------------------------------------------------------------------
-#ifndef NTK_MINGEN_WAVES
-// waves per SIMD the register allocation has to allow (two 512-thread blocks per CU, each with its 64 KiB histogram: 4 waves per SIMD = 128 VGPRs)
-#define NTK_MINGEN_WAVES 4
+// waves per SIMD the register allocation has to allow, per key form: 4 = two 512-thread blocks per CU (128 VGPRs), 3 = one 768-thread block
+// per CU (168 VGPRs); each block has its 64 KiB histogram
+#ifndef NTK_MINGEN_WAVES_F64
+#define NTK_MINGEN_WAVES_F64 4
 #endif
+#ifndef NTK_MINGEN_WAVES_G
+#define NTK_MINGEN_WAVES_G 4
+#endif
+constexpr int min_gen_waves(bool f64) { return f64 ? NTK_MINGEN_WAVES_F64 : NTK_MINGEN_WAVES_G; }
+constexpr int min_gen_threads(bool f64) { return min_gen_waves(f64) == 3 ? 768 : 512; }
 // The output stage of the generic fused minimizer kernel: per window the side effects on the accumulators, four positions per asm block under
 // the window's validity mask (as the scan2 regions: exec write, v_mad_u64_u32 on the lo word, xor, strand bit, LDS atomic; WIDE: the bits above
 // the lo word summed mod 2^32 and xor-ed as well).  Everything that does not depend on validity is computed outside under the full exec mask.
@@ -949,16 +955,53 @@ struct DevMinOut {
     }
 };
 
+// What minimizer_lane hands its windows to (ntk_tile.hpp): begin() takes the lane's 16 validity flags, emit4() turns four of them into lane
+// masks, forms the accumulator operands of the four windows and runs their region.  M = where the cell's 14 bits come from (minimizer_scan_kernel).
+template <class Key, bool F64, int M>
+struct DevMinSink {
+    DevMinOut &out; uint32_t &nv_lane; uint32_t cell_sh;
+    uint32_t vb = 0;   // the lane's validity flags, next position's on top
+    __device__ __forceinline__ void begin(uint32_t invw)
+    {
+        nv_lane += __popc(~invw & 0xFFFFu);
+        vb = ~invw << 16;
+    }
+    __device__ __forceinline__ void emit4(int, const Key (&g)[4])   // (groups arrive in position order)
+    {
+        // the four validity masks: one flag is shifted out per position (v_add_co_u32 with the mask's SGPR pair as its carry output); made
+        // here, group by group - all 16 at once would hold 32 SGPRs across the sliding minimum and spill
+        uint64_t V[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(vb), "=s"(V[i]));
+        uint32_t lo[4], hi[4], sb[4], off[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            key_fields(g[i], lo[i], hi[i], sb[i]);
+            if constexpr (M == 2) off[i] = (hi[i] >> cell_sh) & 0xFFFCu;
+            else if constexpr (M == 3) {
+                if constexpr (F64) off[i] = ((uint32_t)(g[i].k >> 32) >> cell_sh) & 0xFFFCu;
+                else off[i] = 0;
+            }
+            else if constexpr (M == 1) off[i] = alignbit(hi[i], lo[i], cell_sh) & 0xFFFCu;
+            else off[i] = (lo[i] << cell_sh) & 0xFFFCu;
+        }
+        out.template region<M == 2>(V, off, lo, hi, sb);
+    }
+};
+
 // (keys, minima and window validity: ntk_tile.hpp, minimizer_lane - shared with the host emulation)
 // LDS: a 14-bit histogram (64 KiB, cell = the value's top 14 bits, left-aligned for k < 7) at address 0 - the regions address it with the
 // cell's byte offset alone.  Digests: the lo word of every window's minimizer is summed / xor-ed; k <= 16: that is the value; 17 <= k <= 23:
 // the bits above follow from the histogram when the block writes out (cell and lo word cover every bit, as in the LIGHT scan2 builds);
 // k >= 24: the hi words are accumulated as well (WIDE).
-template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM, bool F64>
-__global__ __launch_bounds__(512, NTK_MINGEN_WAVES) void minimizer_scan_kernel(ScanArgs a)
+// MODE = where the cell's 14 bits come from: 0: k <= 7, the value shifted up; 1: 8 <= k <= 23, a funnel shift of (hi : lo); 2: k >= 24, the hi
+// word alone (these also sum the hi words: WIDE); 3: f64 keys with 19 <= k <= 23, the key's high word alone (min_gen_mode, host side too).
+constexpr int min_gen_mode(uint32_t k, bool f64) { return k >= 24 ? 2 : ((f64 && k >= 19) ? 3 : (k >= 8 ? 1 : 0)); }
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool QM, bool F64, int MODE>
+__global__ __launch_bounds__(min_gen_threads(F64), min_gen_waves(F64)) void minimizer_scan_kernel(ScanArgs a)
 {
     constexpr int HB = 14, kCells = 1 << HB;
-    struct Lds { uint32_t hist[kCells]; uint64_t red[8 * 4]; };
+    struct Lds { uint32_t hist[kCells]; uint64_t red[12 * 4]; };
     __shared__ Lds L;
     uint32_t *const s_hist = L.hist;
     uint64_t *const s_red = L.red;
@@ -981,13 +1024,10 @@ __global__ __launch_bounds__(512, NTK_MINGEN_WAVES) void minimizer_scan_kernel(S
     DevXL xl;
     DevMinOut out;
     uint32_t nv_lane = 0;
-    // where the cell's 14 bits come from (wave-uniform): 0: k <= 7, the value shifted up; 1: 8 <= k <= 23, a funnel shift of (hi : lo);
-    // 2: k >= 24, the hi word alone (these also sum the hi words: WIDE); 3: f64 keys with 19 <= k <= 23, the key's high word alone
     const uint32_t kk = a.k;
-    const int mode = kk >= 24 ? 2 : ((F64 && kk >= 19) ? 3 : (kk >= 8 ? 1 : 0));
     uint32_t cell_sh;   // the shift of the mode, in a VGPR (an SGPR operand would make the full-rate shifts half-rate)
     {
-        const uint32_t s_ = mode == 2 ? 2 * kk - 48 : (mode == 3 ? 2 * kk - 37 : (mode == 1 ? 2 * kk - 16 : 16 - 2 * kk));
+        const uint32_t s_ = MODE == 2 ? 2 * kk - 48 : (MODE == 3 ? 2 * kk - 37 : (MODE == 1 ? 2 * kk - 16 : 16 - 2 * kk));
         asm volatile("v_mov_b32 %0, %1" : "=v"(cell_sh) : "s"(s_));
     }
 
@@ -1029,39 +1069,10 @@ __global__ __launch_bounds__(512, NTK_MINGEN_WAVES) void minimizer_scan_kernel(S
             const bool tail = r >= a.tail_tile_rel;
             Raw16 raw{cur.x, cur.y, cur.z, cur.w};
             if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
-            // keys of the 16 own k-mers, window validity and the 16 window minima (ntk_tile.hpp)
-            Key A[16];
-            uint32_t invw;
-            minimizer_lane<KW, TIE_RC, ACCEPT_U, F64>(a, xl, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane, tail, A, invw);
-            nv_lane += __popc(~invw & 0xFFFFu);
-            // the 16 validity masks: one flag is shifted out per position (v_add_co_u32: the carry lands in the mask's SGPR pair)
-            uint64_t V[16];
-            uint32_t vb = ~invw << 16;
-#pragma unroll
-            for (int j = 0; j < 16; j++) asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(vb), "=s"(V[j]));
-            auto stage = [&](auto mode_tag) {
-                constexpr int M = decltype(mode_tag)::value;
-#pragma unroll
-                for (int jb = 0; jb < 16; jb += 4) {
-                    uint32_t lo[4], hi[4], sb[4], off[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        key_fields(A[jb + i], lo[i], hi[i], sb[i]);
-                        if constexpr (M == 2) off[i] = (hi[i] >> cell_sh) & 0xFFFCu;
-                        else if constexpr (M == 3) {
-                            if constexpr (F64) off[i] = ((uint32_t)(A[jb + i].k >> 32) >> cell_sh) & 0xFFFCu;
-                            else off[i] = 0;
-                        }
-                        else if constexpr (M == 1) off[i] = alignbit(hi[i], lo[i], cell_sh) & 0xFFFCu;
-                        else off[i] = (lo[i] << cell_sh) & 0xFFFCu;
-                    }
-                    out.template region<M == 2>(V + jb, off, lo, hi, sb);
-                }
-            };
-            if (mode == 3) stage(std::integral_constant<int, 3>());
-            else if (mode == 2) stage(std::integral_constant<int, 2>());
-            else if (mode == 1) stage(std::integral_constant<int, 1>());
-            else stage(std::integral_constant<int, 0>());
+            // keys of the 16 own k-mers, window validity and the window minima (ntk_tile.hpp); the windows arrive four at a time
+            // keys of the 16 own k-mers, window validity and the window minima (ntk_tile.hpp); the windows arrive four at a time
+            DevMinSink<Key, F64, MODE> sink{out, nv_lane, cell_sh};
+            minimizer_lane<KW, TIE_RC, ACCEPT_U, F64>(a, xl, sink, raw, (int64_t)tile_byte - halo_bytes + lane * 16, lane, tail);
             cur = nxt; curq = nxtq; voff += stride; tile_byte += stride;
         }
         next = __builtin_amdgcn_readfirstlane(next);

@@ -402,9 +402,10 @@ NTK_HD KeyF key_prev(XL &xl, KeyF v)
 template <class XL>
 NTK_HD KeyG key_prev(XL &xl, KeyG v)
 {
-    const uint32_t hi = xl.prev_auto((uint32_t)(v.v >> 32));
+    uint32_t hi = xl.prev_auto((uint32_t)(v.v >> 32));
     KeyG r;
-    r.v = ((uint64_t)hi << 32) | xl.prev_auto((uint32_t)v.v);
+    uint32_t lo = xl.prev_auto((uint32_t)v.v);
+    r.v = ((uint64_t)hi << 32) | lo;
     r.s = xl.prev_auto(v.s);
     return r;
 }
@@ -440,19 +441,29 @@ NTK_HD void min_shifted(XL &xl, Key (&X)[16], const Key (&Y)[16])
         }
     }
 }
-// A[x] <- min(M[x - S], M[x]) for ANY shift 0 < S <= 31: two overlapping windows of M's span cover span + S positions
-template <int S, class Key, class XL>
-NTK_HD void min_overlap(XL &xl, Key (&A)[16], const Key (&M)[16])
+// window[x] = min(M[x - S], M[x]) for a shift 0 < S < 16: two overlapping windows of M's span cover span + S positions.  The windows leave in
+// groups of four positions (sink.emit4(first position, keys)): whoever consumes them does so at once, so that the 16 results are never all
+// live beside the keys they are made from (register budget).
+template <int S, class Key, class XL, class Sink>
+NTK_HD void min_overlap(XL &xl, Sink &sink, const Key (&M)[16])
 {
+    static_assert(S > 0 && S <= 17, "shifts the two overlapping windows of W <= 49 can need");
+    constexpr int NI = S < 16 ? S : 16;
+    Key imp[NI];   // M[x - S] for the positions whose source lies in the previous lane (S = 17, j = 0: the lane before that)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int j = 0; j < 16; j++) {
-        Key l;
-        if (j >= S) l = M[j - S];
-        else if (j - S + 16 >= 0) l = key_prev(xl, M[j - S + 16]);
-        else l = key_prev(xl, key_prev(xl, M[j - S + 32]));
-        A[j] = key_min(l, M[j]);
+    for (int j = 0; j < NI; j++) imp[j] = (j - S + 16 >= 0) ? key_prev(xl, M[(j - S + 16) & 15]) : key_prev(xl, key_prev(xl, M[(j - S + 32) & 15]));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jb = 0; jb < 16; jb += 4) {
+        Key g[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; i++) { const int j = jb + i; g[i] = key_min(j >= S ? M[(j - S) & 15] : imp[j < NI ? j : 0], M[j]); }
+        sink.emit4(jb, g);
     }
 }
 
@@ -471,6 +482,42 @@ NTK_HD uint32_t bad16_from_letters(const uint32_t (&ex)[4], const uint32_t (&uu)
         if (d < 2) hi = dot4(nz, wt, hi); else lo = dot4(nz, wt, lo);
     }
     return (hi << 1) | (lo >> 7);
+}
+
+// invw bit 15 - j set = the window ending at own byte j is not emitted: one of its k + w - 1 bytes is a break (bad = the lane's break mask,
+// base i at bit 15 - i), or the lane is one of the tile's a.min_halo_lanes non-emitting lanes.  k + w - 1 <= 49: ONE smear of the break bits
+// over the window ends a break spoils (own 16 + 48 earlier positions fit 64 bits); longer spans: the k smear (k-mers), then the w smear.
+// (Round 5 tried the scalar form instead - the bytes compared into lane masks, window_masks_runtime below for the windows: 28 VALU instead of
+//  63 - and dropped it: the 64 mask SGPRs do not fit beside this kernel's other scalar state and travel through v_writelane / v_readlane,
+//  ~75 VALU per tile; profiles/r05b/README.md.)
+template <class XL>
+NTK_HD uint32_t minimizer_invalid16(const ScanArgs &a, XL &xl, uint32_t bad, int64_t lane_base, uint32_t lane, bool tail_tile)
+{
+    if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
+        const int64_t keep = (int64_t)a.n_bytes - lane_base;
+        bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
+    }
+    uint32_t inval = bad;
+    const bool one_smear = a.min_smear_kw[0] != 0;
+    if (!one_smear) {
+        const uint32_t b1 = xl.prev_auto(bad), b2 = xl.prev_auto(b1);
+        uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | bad;   // windows of k containing a break
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
+        inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    }
+    const uint32_t b1 = xl.prev_auto(inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
+    uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | inval;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 6; i++) {
+        const uint32_t sft = one_smear ? a.min_smear_kw[i] : a.min_smear[i];
+        if (sft) bw |= bw >> sft;   // (wave-uniform)
+    }
+    return lane < a.min_halo_lanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
 }
 
 // The f64 keys of a lane's 16 k-mers (k <= 25) straight from the code streams, both strands, no compare and no select: the key of a strand is
@@ -505,8 +552,10 @@ NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, uint32_t code, uint32_
     // the three wave-uniform operands of the 64 v_bitop3 below, held in VGPRs: with an SGPR operand a v_bitop3 issues at half rate
     asm("" : "+v"(mask_lo)); asm("" : "+v"(mask_hi)); asm("" : "+v"(marker));
 #endif
-    const uint32_t lane32 = lane << 5;
+    // (the tag's per-position part, 2 j, goes in AFTER the strand choice - both strands carry the same position - as one v_or with an inline
+    //  constant: with it inside, the compiler keeps 32 loop-invariant tag words in registers and the kernel spills)
     constexpr uint32_t fbitF = TIE_RC ? 1u : 0u, fbitR = TIE_RC ? 0u : 1u;
+    const uint32_t tagF = (lane << 5) | fbitF, tagR = (lane << 5) | fbitR;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -523,13 +572,13 @@ NTK_HD void minimizer_keys_f64(const ScanArgs &a, XL &xl, uint32_t code, uint32_
         }
         // reverse complement: the value's LSB at Q bit p0 = 34 + 2j; lo window starts at p0 - 11 = 23 + 2j, hi window at p0 + 21 = 55 + 2j
         const int sL = 23 + 2 * j, sH = 55 + 2 * j;
-        const uint32_t rL = sL < 32 ? alignbit(Q[2], Q[3], sL) : alignbit(Q[1], Q[2], sL - 32);
-        const uint32_t rH = sH < 64 ? alignbit(Q[1], Q[2], sH - 32) : alignbit(Q[0], Q[1], sH - 64);
-        const uint32_t tag = lane32 | (uint32_t)(2 * j);
+        uint32_t rL = sL < 32 ? alignbit(Q[2], Q[3], sL) : alignbit(Q[1], Q[2], sL - 32);
+        uint32_t rH = sH < 64 ? alignbit(Q[1], Q[2], sH - 32) : alignbit(Q[0], Q[1], sH - 64);
         KeyF kf, kr;
-        kf.k = ((uint64_t)and_or(fH, mask_hi, marker) << 32) | and_or(fL, mask_lo, tag | fbitF);
-        kr.k = ((uint64_t)and_or(rH, mask_hi, marker) << 32) | and_or(rL, mask_lo, tag | fbitR);
+        kf.k = ((uint64_t)and_or(fH, mask_hi, marker) << 32) | and_or(fL, mask_lo, tagF);
+        kr.k = ((uint64_t)and_or(rH, mask_hi, marker) << 32) | and_or(rL, mask_lo, tagR);
         key[j] = key_min(kf, kr);
+        key[j].k |= (uint64_t)(2 * j);
     }
 }
 
@@ -569,61 +618,93 @@ NTK_HD void minimizer_keys_general(const ScanArgs &a, XL &xl, uint32_t code, uin
     }
 }
 
-// invw bit 15 - j set = the window ending at own byte j is not emitted: one of its k + w - 1 bytes is a break (bad = the lane's break mask,
-// base i at bit 15 - i), or the lane is one of the tile's a.min_halo_lanes non-emitting lanes.  k + w - 1 <= 49: ONE smear of the break bits
-// over the window ends a break spoils (own 16 + 48 earlier positions fit 64 bits); longer spans: the k smear (k-mers), then the w smear.
-template <class XL>
-NTK_HD uint32_t minimizer_invalid16(const ScanArgs &a, XL &xl, uint32_t bad, int64_t lane_base, uint32_t lane, bool tail_tile)
+// Windows of W >= 17 k-mers by prefix / suffix minima over the lanes' blocks of 16 (van Herk / Gil-Werman): such a window holds the lane's own
+// positions 0 .. j (the prefix minimum P[j]), H or H - 1 whole lanes before them and a suffix of one lane more.  With W - 1 = 16 H + D:
+//     j >= D:  min(S_-H[j - D], F_(H-1), P[j])          j < D:  min(S_-(H+1)[16 + j - D], F_H, P[j])
+// S_-h = the suffix minima of the lane h lanes back, F_m = the minimum over the m whole lanes before this one.  Operands are always ordered
+// older first, so the leftmost rule holds for both key forms.  30 + 16 + D (+ 16 + H for H > 1) minima where doubling takes 16 per round -
+// 48 instead of 80 at W = 19 - and 16 H + D + H imported keys.  D is a template constant (it indexes registers), H a wave-uniform loop count.
+template <int D, class Key, class XL, class Sink>
+NTK_HD void min_van_herk(uint32_t H, XL &xl, Sink &sink, const Key (&M)[16])
 {
-    if (tail_tile) {  // wave-uniform: this tile reaches the end of the input; bytes at or beyond n_bytes are breaks
-        const int64_t keep = (int64_t)a.n_bytes - lane_base;
-        bad |= keep >= 16 ? 0u : (keep <= 0 ? 0xFFFFu : (0xFFFFu >> (uint32_t)keep));
-    }
-    uint32_t inval = bad;
-    const bool one_smear = a.min_smear_kw[0] != 0;
-    if (!one_smear) {
-        const uint32_t b1 = xl.prev_auto(bad), b2 = xl.prev_auto(b1);
-        uint64_t bw = ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | bad;   // windows of k containing a break
+    // (register budget: the suffix minima T and the keys M are all that stays live - the prefix minimum runs along with the windows, which
+    //  leave in groups of four; the lane's whole minimum is T[0])
+    Key T[16];
+    T[15] = M[15];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int i = 0; i < 5; i++) bw |= bw >> a.smear[i];
-        inval = lane < (uint32_t)kHaloLanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
-    }
-    const uint32_t b1 = xl.prev_auto(inval), b2 = xl.prev_auto(b1), b3 = xl.prev_auto(b2);
-    uint64_t bw = ((uint64_t)b3 << 48) | ((uint64_t)b2 << 32) | ((uint64_t)b1 << 16) | inval;
+    for (int j = 14; j >= 0; j--) T[j] = key_min(M[j], T[j + 1]);
+    // hop the suffix minima and the lane minimum back lane by lane; Fa = F_(H-1), Fb = F_H (oldest lane first in every minimum)
+    Key f = T[0], Fa = T[0], Fb = T[0];      // (Fa is not used when H == 1)
+    for (uint32_t h = 1; h <= H; h++) {      // wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 6; i++) {
-        const uint32_t sft = one_smear ? a.min_smear_kw[i] : a.min_smear[i];
-        if (sft) bw |= bw >> sft;   // (wave-uniform)
+        for (int i = 0; i < 16; i++) T[i] = key_prev(xl, T[i]);
+        f = key_prev(xl, f);                 // the whole-lane minimum of lane -h
+        Fa = Fb;
+        Fb = h == 1 ? f : key_min(f, Fb);
     }
-    return lane < a.min_halo_lanes ? 0xFFFFu : ((uint32_t)bw & 0xFFFFu);
+    Key p = M[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int jb = 0; jb < 16; jb += 4) {
+        Key g[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; i++) {
+            const int j = jb + i;
+            if (j) p = key_min(p, M[j]);
+            if (j >= D) {
+                Key l = T[j >= D ? j - D : 0];
+                if (H > 1) l = key_min(l, Fa);
+                g[i] = key_min(l, p);
+            } else {
+                g[i] = key_min(key_min(key_prev(xl, T[j < D ? 16 - D + j : 0]), Fb), p);   // S_-(H+1)[16 + j - D]: one hop more
+            }
+        }
+        sink.emit4(jb, g);
+    }
 }
 
-// sliding minimum over W = a.min_w: M doubles while 2q <= W, then two overlapping windows of q make W (every branch is wave-uniform).
-// A[j] = the minimizer's key of the window ending at own byte j.
-template <class Key, class XL>
-NTK_HD void minimizer_slide(const ScanArgs &a, XL &xl, Key (&M)[16], Key (&A)[16])
+// sliding minimum over W = a.min_w.  W <= 16: M doubles while 2q <= W, then two overlapping windows of q make W; W >= 17: prefix / suffix
+// minima (above).  Every branch is wave-uniform.  A[j] = the minimizer's key of the window ending at own byte j.
+template <class Key, class XL, class Sink>
+NTK_HD void minimizer_slide(const ScanArgs &a, XL &xl, Key (&M)[16], Sink &sink)
 {
     const uint32_t W = a.min_w;
+    constexpr bool kVanHerk = sizeof(Key) == sizeof(KeyF);   // (the (value, strand) triples need 96 registers for it and spill: they double on)
+    if (kVanHerk && W >= 17) {
+        const uint32_t H = (W - 1) >> 4;
+        switch ((W - 1) & 15) {
+#define NTK_VH_CASE(D) case D: min_van_herk<D>(H, xl, sink, M); break;
+            NTK_VH_CASE(0) NTK_VH_CASE(1) NTK_VH_CASE(2) NTK_VH_CASE(3) NTK_VH_CASE(4) NTK_VH_CASE(5) NTK_VH_CASE(6) NTK_VH_CASE(7)
+            NTK_VH_CASE(8) NTK_VH_CASE(9) NTK_VH_CASE(10) NTK_VH_CASE(11) NTK_VH_CASE(12) NTK_VH_CASE(13) NTK_VH_CASE(14) NTK_VH_CASE(15)
+#undef NTK_VH_CASE
+        }
+        return;
+    }
     if (W >= 2) min_shifted<1>(xl, M, M);
     if (W >= 4) min_shifted<2>(xl, M, M);
     if (W >= 8) min_shifted<4>(xl, M, M);
     if (W >= 16) min_shifted<8>(xl, M, M);
-    if (W >= 32) min_shifted<16>(xl, M, M);
-    switch (a.min_overlap) {   // W - (M's span): 0 .. 17 for W <= 49
-#define NTK_MIN_CASE(S) case S: min_overlap<S>(xl, A, M); break;
-        NTK_MIN_CASE(1) NTK_MIN_CASE(2) NTK_MIN_CASE(3) NTK_MIN_CASE(4) NTK_MIN_CASE(5) NTK_MIN_CASE(6) NTK_MIN_CASE(7) NTK_MIN_CASE(8)
-        NTK_MIN_CASE(9) NTK_MIN_CASE(10) NTK_MIN_CASE(11) NTK_MIN_CASE(12) NTK_MIN_CASE(13) NTK_MIN_CASE(14) NTK_MIN_CASE(15)
-        NTK_MIN_CASE(16) NTK_MIN_CASE(17)
+    if (!kVanHerk && W >= 32) min_shifted<16>(xl, M, M);
+    switch (a.min_overlap) {   // W - (M's span): 0 .. 7 for W <= 16, 0 .. 17 for W <= 49
+#define NTK_MIN_CASE(S) case S: min_overlap<S>(xl, sink, M); break;
+        NTK_MIN_CASE(1) NTK_MIN_CASE(2) NTK_MIN_CASE(3) NTK_MIN_CASE(4) NTK_MIN_CASE(5) NTK_MIN_CASE(6) NTK_MIN_CASE(7)
+#define NTK_MIN_CASE_G(S) case S: if constexpr (!kVanHerk) min_overlap<S>(xl, sink, M); break;
+        NTK_MIN_CASE_G(8) NTK_MIN_CASE_G(9) NTK_MIN_CASE_G(10) NTK_MIN_CASE_G(11) NTK_MIN_CASE_G(12) NTK_MIN_CASE_G(13) NTK_MIN_CASE_G(14)
+        NTK_MIN_CASE_G(15) NTK_MIN_CASE_G(16) NTK_MIN_CASE_G(17)
+#undef NTK_MIN_CASE_G
 #undef NTK_MIN_CASE
         default:
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int j = 0; j < 16; j++) A[j] = M[j];
+            for (int jb = 0; jb < 16; jb += 4) { Key g[4] = {M[jb], M[jb + 1], M[jb + 2], M[jb + 3]}; sink.emit4(jb, g); }
     }
 }
 // (value's low 32 bits, bits above them, strand bit as the key form carries it) of a window's minimizer
@@ -843,10 +924,10 @@ NTK_HD void window_masks1(const uint64_t (&G)[16], uint64_t (&OK)[16])
 
 // window_masks1 with the last AND left open (OK[j] = A[j] & B[j], see window_masks_ab): the scan2 builds form exec with it.
 template <int K>
-NTK_HD void window_masks1_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
+NTK_HD void window_masks1_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16], const uint64_t kNoHalo = ~3ull)
 {
     static_assert(K >= 1 && K <= 16, "k <= 16 variant");
-    constexpr uint64_t kAll = ~0ull, kNoHalo = ~3ull;   // halo lanes 0/1 emit nothing
+    constexpr uint64_t kAll = ~0ull;   // kNoHalo: halo lanes (0 / 1 in the k-mer kernels) emit nothing
     if constexpr (K >= 9) {
         uint64_t P[16], S[16], S8[8], P8[16];
         P[0] = G[0] & kNoHalo;            // cleared in every window that contains own byte 0 ...
@@ -899,6 +980,50 @@ template <int KM>
 NTK_HD void window_masks_ab_any(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
 {
     if constexpr (KM >= 17) window_masks_ab<KM>(G, A, B); else window_masks1_ab<KM>(G, A, B);
+}
+
+// The same for a window length known only at RUN TIME, any L >= 1 (written for the generic fused minimizer kernel, L = k + w - 1 <= 79; that
+// kernel does not use it - see minimizer_invalid16 - and it stays as the tested run-time form of the algebra).  L >= 17: with
+// L - 2 = 16 q + C the window ending at own byte j needs the lane's own bytes 0 .. j (A[j], the prefix), q whole lanes before it and the
+// last C + 1 - j bytes of the lane before those (j <= C) - or q - 1 whole lanes and the last 17 + C - j bytes (j > C).  C indexes registers and
+// is a template constant (a 16-way switch on it), q is a shift count; a lane shift is a 1-bit shift of a mask.  keep = the lanes that may emit.
+template <int C>
+NTK_HD void window_masks_span(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16], uint32_t q, uint64_t keep)
+{
+    uint64_t S[16];
+    S[15] = G[15];
+#pragma unroll
+    for (int i = 14; i >= 0; i--) S[i] = S[i + 1] & G[i];
+    uint64_t Fq1 = ~0ull;                                   // the q - 1 lanes before this one are whole
+    for (uint32_t i = 1; i < q; i++) Fq1 &= S[0] << i;      // (wave-uniform: q <= 4)
+    const uint64_t Fq = q ? (Fq1 & (S[0] << q)) : ~0ull;    // ... the q lanes
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j <= C) B[j] = (S[(15 - C + j) & 15] << (q + 1)) & Fq;
+        else B[j] = (S[(j - C - 1) & 15] << q) & Fq1;
+    }
+    A[0] = G[0] & keep;
+#pragma unroll
+    for (int j = 1; j < 16; j++) A[j] = A[j - 1] & G[j];
+}
+NTK_HD void window_masks_runtime(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16], uint32_t L, uint64_t keep)
+{
+    if (L >= 17) {
+        const uint32_t q = (L - 2) >> 4;
+        switch ((L - 2) & 15) {
+#define NTK_WM_CASE(C) case C: window_masks_span<C>(G, A, B, q, keep); break;
+            NTK_WM_CASE(0) NTK_WM_CASE(1) NTK_WM_CASE(2) NTK_WM_CASE(3) NTK_WM_CASE(4) NTK_WM_CASE(5) NTK_WM_CASE(6) NTK_WM_CASE(7)
+            NTK_WM_CASE(8) NTK_WM_CASE(9) NTK_WM_CASE(10) NTK_WM_CASE(11) NTK_WM_CASE(12) NTK_WM_CASE(13) NTK_WM_CASE(14) NTK_WM_CASE(15)
+#undef NTK_WM_CASE
+        }
+        return;
+    }
+    switch (L) {
+#define NTK_WM_CASE(K) case K: window_masks1_ab<K>(G, A, B, keep); break;
+        NTK_WM_CASE(1) NTK_WM_CASE(2) NTK_WM_CASE(3) NTK_WM_CASE(4) NTK_WM_CASE(5) NTK_WM_CASE(6) NTK_WM_CASE(7) NTK_WM_CASE(8)
+        NTK_WM_CASE(9) NTK_WM_CASE(10) NTK_WM_CASE(11) NTK_WM_CASE(12) NTK_WM_CASE(13) NTK_WM_CASE(14) NTK_WM_CASE(15) NTK_WM_CASE(16)
+#undef NTK_WM_CASE
+    }
 }
 
 template <bool CANON, bool TIE_RC, int K, class Sink, class XL, class MP>
@@ -1220,21 +1345,20 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
     }
 }
 
-// One lane of one tile of the generic fused minimizer kernel: A[j] = key of the minimizer of the window ending at own byte j, invw bit
-// 15 - j set = that window is not emitted.  Lanes 0 and 1 are the k-mer halo, lanes below a.min_halo_lanes hold k-mers that the first
-// emitting lanes' windows need.
+// One lane of one tile of the generic fused minimizer kernel: sink.begin(invw) with invw bit 15 - j set = the window ending at own byte j is
+// not emitted, then sink.emit4(jb, keys) for jb = 0, 4, 8, 12 with the minimizers' keys of the windows ending at bytes jb .. jb + 3.  Lanes 0
+// and 1 are the k-mer halo, lanes below a.min_halo_lanes hold k-mers that the first emitting lanes' windows need.
 template <bool F64> struct MinKey { typedef KeyG type; };
 template <> struct MinKey<true> { typedef KeyF type; };
-template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64, class XL>
-NTK_HD void minimizer_lane(const ScanArgs &a, XL &xl, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile, typename MinKey<F64>::type (&A)[16],
-                           uint32_t &invw)
+template <int KW, bool TIE_RC, bool ACCEPT_U, bool F64, class XL, class Sink>
+NTK_HD void minimizer_lane(const ScanArgs &a, XL &xl, Sink &sink, Raw16 raw, int64_t lane_base, uint32_t lane, bool tail_tile)
 {
     const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
     typename MinKey<F64>::type M[16];
     if constexpr (F64) minimizer_keys_f64<TIE_RC>(a, xl, en.code, en.rcode, lane, M);
     else minimizer_keys_general<KW, TIE_RC>(a, xl, en.code, en.rcode, M);
-    invw = minimizer_invalid16(a, xl, bad16_from_letters(en.ex, en.uu), lane_base, lane, tail_tile);
-    minimizer_slide(a, xl, M, A);
+    sink.begin(minimizer_invalid16(a, xl, bad16_from_letters(en.ex, en.uu), lane_base, lane, tail_tile));
+    minimizer_slide(a, xl, M, sink);
 }
 
 }  // namespace ntk

@@ -342,18 +342,23 @@ void run_min_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs
         for (uint32_t l = 0; l < 64; l++) {
             xl.next_lane(l == 0);
             const int64_t lane_base = (int64_t)(t * stride) - (int64_t)halo_bytes + l * 16;
-            typename MinKey<F64>::type A[16];
-            uint32_t invw;
-            minimizer_lane<KW, TIE_RC, ACCEPT_U, F64>(a, xl, load16q(buf, n_padded, lane_base), lane_base, l, tail, A, invw);
-            for (int j = 0; j < 16; j++) {
-                if ((invw >> (15 - j)) & 1) continue;
-                uint32_t lo, hi, sbit;
-                key_fields(A[j], lo, hi, sbit);
-                if (F64) hi &= ~(1u << 19);   // the key's marker bit (the kernel takes it out of its sums once per block)
-                const uint64_t v = ((uint64_t)hi << 32) | lo;
-                const bool is_rc = (F64 && TIE_RC) ? !sbit : (sbit != 0);   // f64 keys: the tie-winning strand carries 0
-                st->n_total++; st->n_fwd += !is_rc; st->sum += v; st->xr ^= v; st->hist[v >> a.bin_shift]++;
-            }
+            struct Sink {
+                HostStats *st; uint32_t bin_shift; uint32_t invw = 0;
+                void begin(uint32_t inv) { invw = inv; }
+                void emit4(int jb, const typename MinKey<F64>::type (&g)[4])
+                {
+                    for (int i = 0; i < 4; i++) {
+                        if ((invw >> (15 - (jb + i))) & 1) continue;
+                        uint32_t lo, hi, sbit;
+                        key_fields(g[i], lo, hi, sbit);
+                        if (F64) hi &= ~(1u << 19);   // the key's marker bit (the kernel takes it out of its sums once per block)
+                        const uint64_t v = ((uint64_t)hi << 32) | lo;
+                        const bool is_rc = (F64 && TIE_RC) ? !sbit : (sbit != 0);   // f64 keys: the tie-winning strand carries 0
+                        st->n_total++; st->n_fwd += !is_rc; st->sum += v; st->xr ^= v; st->hist[v >> bin_shift]++;
+                    }
+                }
+            } sink{st, a.bin_shift};
+            minimizer_lane<KW, TIE_RC, ACCEPT_U, F64>(a, xl, sink, load16q(buf, n_padded, lane_base), lane_base, l, tail);
         }
     }
 }
@@ -515,6 +520,17 @@ int emu_window_masks(const uint64_t *g16, uint32_t k, uint64_t *ok16, uint64_t *
 #undef EMU_WM
     }
     return -1;
+}
+
+// window_masks_runtime: the run-time form of the mask algebra (the generic fused minimizer kernel), any window length L = 1 .. 79
+int emu_window_masks_runtime(const uint64_t *g16, uint32_t L, uint32_t halo_lanes, uint64_t *ok16)
+{
+    if (L < 1 || L > 79 || halo_lanes > 63) return -1;
+    uint64_t G[16], A[16], B[16];
+    memcpy(G, g16, sizeof(G));
+    window_masks_runtime(G, A, B, L, ~((1ull << halo_lanes) - 1ull));
+    for (int j = 0; j < 16; j++) ok16[j] = A[j] & B[j];
+    return 0;
 }
 
 void emu_encode16(const uint8_t *raw16, int accept_u, uint32_t *out3)

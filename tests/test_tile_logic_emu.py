@@ -398,3 +398,31 @@ def test_emu_generic_minimizers_with_a_quality_stream(emu):
             got = {"n_total": int(out[0]), "n_fwd": int(out[1]), "n_rc": int(out[0] - out[1]), "sum": int(out[2]), "xor": int(out[3]), "hist": out[4:].copy()}
             want = O.minimizers_reduce(O.quality_mask(b, q.tobytes(), cutoff), k, w, accept_u=True, tie_rc=True)
             assert_stats_equal(got, want, (trial, k, w, cutoff, f64))
+
+
+def test_emu_window_masks_at_run_time(emu):
+    """window_masks_runtime (the generic fused minimizer kernel's validity: window length L = k + w - 1 known at run time, 1 .. 79; a 16-way
+    switch on (L - 2) mod 16 around the compile-time-indexed prefix / suffix algebra) against the definition: the window of L bytes ending at
+    byte j of lane l is emitted iff lane l >= halo lanes and bytes 16 l + j - L + 1 .. 16 l + j are all bases (positions before the tile are not)."""
+    emu.emu_window_masks_runtime.restype = C.c_int
+    emu.emu_window_masks_runtime.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        p_break = [0.0, 0.01, 0.03, 0.1, 0.3, 0.6][trial % 6]
+        good = rng.random(1024) >= p_break                      # byte p = 16 * lane + i
+        if trial == 7:
+            good[:] = True
+        g = np.zeros(16, dtype=np.uint64)
+        for i in range(16):
+            g[i] = sum(1 << l for l in range(64) if good[16 * l + i])
+        run = np.zeros(1024, dtype=np.int64)                    # length of the run of bases ending at p
+        for p in range(1024):
+            run[p] = (run[p - 1] + 1 if p else 1) if good[p] else 0
+        for L in range(1, 80):
+            halo = 2 + (max(L - 31, 0) + 15) // 16              # the kernel's: 2 lanes of k-mer halo + ceil((w - 1) / 16) with k = 31 (any split of L does)
+            halo = min(halo, 5)
+            ok = np.zeros(16, dtype=np.uint64)
+            assert emu.emu_window_masks_runtime(g.ctypes.data, L, halo, ok.ctypes.data) == 0
+            for j in range(16):
+                want = sum(1 << l for l in range(halo, 64) if run[16 * l + j] >= L)
+                assert int(ok[j]) == want, (trial, L, j, hex(int(ok[j])), hex(want))

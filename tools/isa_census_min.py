@@ -32,16 +32,16 @@ def issue_class(line):
 
 
 names = re.findall(r"^(_ZN3ntk21minimizer_scan_kernel\S+):", text, re.M)
-print("minimizer_scan_kernel<KW, TIE_RC, ACCEPT_U, QM, F64>: registers per instantiation")
+print("minimizer_scan_kernel<KW, TIE_RC, ACCEPT_U, QM, F64, MODE>: registers per instantiation")
 for nm in names:
     body = text[text.index(nm + ":"):]
-    t = re.search(r"ILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", nm).groups()
+    t = re.search(r"ILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)E", nm).groups()
     vg = re.search(r"[.]amdhsa_next_free_vgpr (\d+)", body).group(1)
     sc = re.search(r"; ScratchSize: (\d+)", body).group(1)
     oc = re.search(r"; Occupancy: (\d+)", body).group(1)
-    print(f"  <{t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}>  VGPRs {vg:>3}  scratch {sc:>3}  waves per SIMD {oc}")
-for f64, label in (("1", "f64 keys (k <= 25)"), ("0", "general keys (26 <= k <= 31)")):
-    nm = f"_ZN3ntk21minimizer_scan_kernelILi2ELb1ELb1ELb0ELb{f64}EEEvNS_8ScanArgsE"
+    print(f"  <{t[0]}, {t[1]}, {t[2]}, {t[3]}, {t[4]}, {t[5]}>  VGPRs {vg:>3}  scratch {sc:>3}  waves per SIMD {oc}")
+for f64, md, label in (("1", "3", "f64 keys, 19 <= k <= 23"), ("0", "2", "general keys (26 <= k <= 31)")):
+    nm = f"_ZN3ntk21minimizer_scan_kernelILi2ELb1ELb1ELb0ELb{f64}ELi{md}EEEvNS_8ScanArgsE"
     body = text[text.index(nm + ":"):]
     body = body[:body.index(".end_amdhsa_kernel")]
     blocks, cur = [], ["entry", []]
