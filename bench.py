@@ -416,6 +416,40 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
             if not (np.array_equal(pos_i, arrs[3][o:o + n_i].astype(np.int64)) and np.array_equal(rbits[pos_i], arrs[4][o:o + n_i])):
                 raise SystemExit("secondary: the bit planes and the item arrays disagree on record %d" % i)
             o += n_i
+        # Sequence::bit_kmers(21, true) in the same form (ntk_bit_kmers_batch_planes): planes + DENSE values (8.25 B per position back), and the
+        # planes alone (the host packs an emitted window's value from its bases); counts against the resident bit-path scan, values of a
+        # prefix of the records against the item arrays of ntk_bit_kmers_batch
+        ctx.accum_reset()
+        ctx.reduce_device(k21_seq, c_reads * (read_len + 1), 21, nt.PATH_BITS_CANONICAL, nt.PRE_NONE)
+        ref_b = ctx.accum_read()
+        hv, vals = pinned(cap_w * 16 * 8, np.uint64)
+        bit_lines = {}
+        for with_values in (True, False):
+            best_b = None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                L.check(L.lib().ntk_bit_kmers_batch_planes(ctx._h, C.cast(arrs[0].ctypes.data, C.c_char_p), arrs[1].ctypes.data, c_reads, 21, 1,
+                                                           rec_bit.ctypes.data, v16.ctypes.data, r16.ctypes.data, vals.ctypes.data if with_values else None,
+                                                           cap_w, C.byref(nw), C.byref(tot)), "ntk_bit_kmers_batch_planes")
+                dt = time.perf_counter() - t0
+                best_b = dt if best_b is None else min(best_b, dt)
+            if not (tot.value == popc(v16) == ref_b["n_total"] and popc(r16) == ref_b["n_rc"]):
+                raise SystemExit("secondary: the bit-path plane face differs from the resident scan")
+            bit_lines["with_dense_values" if with_values else "planes_only"] = {
+                "seconds": round(best_b, 4), "Gbases_s": round(c_reads * read_len / best_b / 1e9, 2),
+                "bytes_out_per_position": 8.25 if with_values else 0.25}
+        # the values: every emitted window of the first 2000 records against the oracle's iterator
+        for i in range(2000):
+            b0 = int(rec_bit[i])
+            rec_i = arrs[0][int(arrs[1][i]): int(arrs[1][i + 1])].tobytes()
+            for p_, (v_, _k), f_ in O.bit_kmers(rec_i, 21, True):
+                if int(vals[b0 + p_]) != v_:
+                    raise SystemExit("secondary: ntk_bit_kmers_batch_planes value differs from the oracle's BitNuclKmer on record %d" % i)
+        L.lib().ntk_pinned_free(hv)
+        del vals
+        out["compat_bit_planes_k21"] = {"call": "ntk_bit_kmers_batch_planes", "records": c_reads, "items": int(ref_b["n_total"]), **bit_lines,
+                                        "note": "Sequence::bit_kmers(21, true) for a batch: emitted / was_rc planes per window start (+ one u64 per position), "
+                                                "page-locked arrays, PCIe-inclusive; the item-array form (ntk_bit_kmers_batch) returns 17 B per item"}
         # sequence::minimizer (reference src/sequence.rs:139-152) for every record of the same batch in one call (ntk_minimizer_batch);
         # a prefix against the oracle's per-record function
         mh = [pinned(nb, dt_) for nb, dt_ in ((c_reads * 21, np.uint8), (c_reads * 8, np.uint64), (c_reads, np.uint8))]

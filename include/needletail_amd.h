@@ -33,9 +33,10 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): + ntk_canonical_kmers_batch_planes, ntk_ctx_trim, ntk_comm_allreduce_time_ms; round 3 had added ntk_device_count,
- * ntk_pinned_alloc / ntk_pinned_free under version 1.  ntk_abi_version() of the loaded library says what it exports. */
-#define NTK_ABI_VERSION 2
+/* 3 (round 5): + ntk_ctx_set_option (the library no longer reads A/B switches from the environment), ntk_gunzip / ntk_gunzip_free,
+ * ntk_bit_kmers_batch_planes.  2 (round 4): + ntk_canonical_kmers_batch_planes, ntk_ctx_trim, ntk_comm_allreduce_time_ms; round 3 had added
+ * ntk_device_count, ntk_pinned_alloc / ntk_pinned_free under version 1.  ntk_abi_version() of the loaded library says what it exports. */
+#define NTK_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -339,6 +340,18 @@ int ntk_pinned_alloc(uint64_t bytes, void **out);   /* hipHostMalloc: for the ar
 int ntk_canonical_kmers_batch_planes(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k,
                                      uint64_t *rec_bit, uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words,
                                      uint64_t *total);
+/* Sequence::bit_kmers(k, canonical) (reference src/bitkmer.rs:97-108: items (pos, (value, k), was_rc)) for a batch in the same form: the two
+ * planes per window START - "emitted" and "was_rc" (ties keep the forward k-mer, was_rc = 0, src/bitkmer.rs:136-143; canonical = 0: the
+ * forward k-mer of every window, was_rc plane all 0) - and, when values != NULL, the items' packed values DENSE, one u64 per plane position
+ * (values[rec_bit[r] + p] for the window starting at byte p of record r; 0 where nothing is emitted; 16 * cap_words u64): 8.25 bytes per
+ * position come back instead of the 17 per item of ntk_bit_kmers_batch, with no compaction pass and no positions (the download of the
+ * values is the call's bound; with values == NULL a quarter byte per base comes back and the host can pack the value of an emitted window from
+ * its k bases, A0 C1 G2 T3, first base most significant).  Alphabet acgtACGT, k <= 32; geometry, capacity protocol and rec_bit exactly as
+ * ntk_canonical_kmers_batch_planes.  Host iterators: BitKmersPlanes (needletail_amd.hpp), AmdBitKmersPlanes (rust/src/amd.rs),
+ * needletail_amd.bit_kmers_planes. */
+int ntk_bit_kmers_batch_planes(ntk_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,
+                               uint64_t *rec_bit, uint16_t *valid16, uint16_t *rc16, uint64_t *values, uint64_t cap_words, uint64_t *n_words,
+                               uint64_t *total);
 /* Releases what the batched calls and the compat face keep between calls (staging, device buffers); they are re-made on demand. */
 int ntk_ctx_trim(ntk_ctx *ctx);
 void ntk_pinned_free(void *p);

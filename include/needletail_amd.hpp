@@ -126,6 +126,36 @@ private:
     uint64_t k_; std::vector<uint64_t> offsets_, rec_bit_; std::vector<uint16_t> valid16_, rc16_; uint64_t total_ = 0;
 };
 
+// The items of Sequence::bit_kmers(k, canonical) for a whole batch of records from ONE call (ntk_bit_kmers_batch_planes): per window start
+// "emitted" and "was_rc" as bit planes, the packed values dense (one u64 per plane position).  for_each(i, f) hands f what the reference
+// iterator yields for record i, in its order: (pos, value, k, was_rc) (reference src/bitkmer.rs:97-108).
+class BitKmersPlanes {
+public:
+    BitKmersPlanes(const uint8_t *seq, const std::vector<uint64_t> &offsets, uint8_t k, bool canonical, Context &c = Context::global())
+        : k_(k), offsets_(offsets), rec_bit_(offsets.size())
+    {
+        if (offsets.empty()) return;   // no offsets at all = zero records
+        const uint64_t n = offsets.size() - 1, cap = (offsets[n] - offsets[0]) / 16 + n + 1;
+        valid16_.resize(cap); rc16_.resize(cap); values_.resize(cap * 16);
+        uint64_t words = 0;
+        check(ntk_bit_kmers_batch_planes(c.get(), seq, offsets_.data(), n, k, canonical ? 1 : 0, rec_bit_.data(), valid16_.data(), rc16_.data(),
+                                         values_.data(), cap, &words, &total_), "ntk_bit_kmers_batch_planes");
+        valid16_.resize(words); rc16_.resize(words); values_.resize(words * 16);
+    }
+    uint64_t total() const { return total_; }
+    template <class F> void for_each(size_t i, F &&f) const {
+        const uint64_t len = offsets_[i + 1] - offsets_[i], b0 = rec_bit_[i];
+        if (len < k_) return;
+        for (uint64_t p = 0; p + k_ <= len; p++) {
+            const uint64_t b = b0 + p;
+            if (!((valid16_[b >> 4] >> (15 - (b & 15))) & 1)) continue;
+            f((size_t)p, values_[b], (uint8_t)k_, (bool)((rc16_[b >> 4] >> (15 - (b & 15))) & 1));
+        }
+    }
+private:
+    uint64_t k_; std::vector<uint64_t> offsets_, rec_bit_, values_; std::vector<uint16_t> valid16_, rc16_; uint64_t total_ = 0;
+};
+
 // QualitySequence (reference src/sequence.rs:273-303) for a (sequence, quality) pair.
 class QualitySequence : public Sequence {
 public:

@@ -10,7 +10,7 @@ from .parser import (FastxReader, NeedletailError, Record, decode_phred, parse_f
                      write_fasta, write_fastq,
                      scan_file_parallel)
 from .sequence import (bit_kmers, bit_kmers_arrays, bit_kmers_batch, canonical_kmers, canonical_kmers_arrays,
-                       canonical_kmers_batch, canonical_kmers_planes, CanonicalKmersPlanes, kmers, normalize,
+                       canonical_kmers_batch, canonical_kmers_planes, CanonicalKmersPlanes, bit_kmers_planes, BitKmersPlanes, kmers, normalize,
                        normalize_opt, normalize_seq, reverse_complement, strip_returns, minimizer, minimizer_batch, canonical, mask_header_tabs,
                        mask_header_utf8, bit_minimizers, quality_mask, bit_reverse_complement, bit_canonical,
                        bitmer_to_bytes, bytes_to_bitmer)
@@ -23,5 +23,5 @@ __all__ = [
     "normalize", "normalize_opt", "normalize_seq", "strip_returns", "reverse_complement",
     "minimizer", "minimizer_batch", "canonical", "mask_header_tabs", "mask_header_utf8", "bit_minimizers", "quality_mask", "bit_reverse_complement", "bit_canonical", "bitmer_to_bytes",
     "bytes_to_bitmer",
-    "kmers", "canonical_kmers", "canonical_kmers_arrays", "bit_kmers", "bit_kmers_arrays", "bit_kmers_batch", "canonical_kmers_batch", "canonical_kmers_planes", "CanonicalKmersPlanes",
+    "kmers", "canonical_kmers", "canonical_kmers_arrays", "bit_kmers", "bit_kmers_arrays", "bit_kmers_batch", "canonical_kmers_batch", "canonical_kmers_planes", "CanonicalKmersPlanes", "bit_kmers_planes", "BitKmersPlanes",
 ]

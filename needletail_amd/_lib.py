@@ -32,7 +32,7 @@ SYMBOLS = [
     "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_append_quality", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
     "ntk_batch_release",
     "ntk_normalize", "ntk_strip_returns", "ntk_reverse_complement", "ntk_canonical_kmers", "ntk_bit_kmers", "ntk_canonical_kmers_batch", "ntk_bit_kmers_batch", "ntk_pinned_alloc", "ntk_pinned_free",
-    "ntk_canonical_kmers_batch_planes", "ntk_ctx_trim", "ntk_minimizer_batch",
+    "ntk_canonical_kmers_batch_planes", "ntk_bit_kmers_batch_planes", "ntk_ctx_trim", "ntk_minimizer_batch",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
     "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_position", "ntk_reader_close",
     "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points", "ntk_gunzip", "ntk_gunzip_free",
@@ -141,6 +141,7 @@ def lib() -> C.CDLL:
     L.ntk_pinned_free.restype = None
     L.ntk_pinned_free.argtypes = [vp]
     L.ntk_canonical_kmers_batch_planes.argtypes = [vp, C.c_char_p, vp, u64, u32, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.ntk_bit_kmers_batch_planes.argtypes = [vp, C.c_char_p, vp, u64, u32, i32, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.ntk_ctx_trim.argtypes = [vp]
     L.ntk_synth_reads_device.argtypes = [vp, u64, u64, u64, u32, u32, vp]
     L.ntk_reverse_complement_records_device.argtypes = [vp, vp, vp, u64, u32, u32]

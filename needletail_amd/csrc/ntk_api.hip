@@ -1232,8 +1232,11 @@ int compat_batch(ntk_ctx *c, const CompatJob &j, uint64_t n_records, uint64_t *t
 // of the compat face marks the windows, and the two planes come back: 1/4 byte per input byte.  Chunks of <= 16 MiB, the same three
 // banks: upload and kernels of chunk i + 1 overlap the download of chunk i.  Each chunk starts on a 16-position word boundary of the
 // planes; rec_bit[r] is the plane position of record r's first byte.
+// kind 0: the byte path (CanonicalKmers, raw-byte compare, any k <= 255); 1 / 2: the bit path, canonical / forward-only (BitNuclKmer, k <= 32),
+// with values != nullptr also the items' packed values, one u64 per plane position (0 where nothing is emitted): 8 more bytes per input byte
+// come back then, and the download is the call's bound.
 int compat_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, uint64_t *rec_bit,
-                  uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words, uint64_t *total)
+                  uint16_t *valid16, uint16_t *rc16, uint64_t cap_words, uint64_t *n_words, uint64_t *total, int kind = 0, uint64_t *values = nullptr)
 {
     for (uint64_t r = 0; r < n_records; r++) if (offsets[r] > offsets[r + 1]) return NTK_ERR_BAD_ARG;
     const uint64_t chunk_bytes = c->compat_chunk;
@@ -1282,6 +1285,7 @@ int compat_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint6
         if ((r = bank_scratch(c, b, 3, nt / 8 + 16))) return r;
         if ((r = bank_scratch(c, b, 4, 64))) return r;
         if ((r = bank_scratch(c, b, 6, (size_t)((nt >> 5) + 2) * 4))) return r;
+        if (values && (r = bank_scratch(c, b, 1, (size_t)nt * 8))) return r;
         hipError_t e;
         if ((e = hipMemcpyAsync(b.d[0].p, seq + offsets[ch.r0], ch.nb, hipMemcpyHostToDevice, c->copy_stream))) return hip_fail(e);
         if ((e = hipMemcpyAsync(b.d[5].p, offsets + ch.r0, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, c->copy_stream))) return hip_fail(e);
@@ -1300,15 +1304,26 @@ int compat_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint6
         hipLaunchKernelGGL(mark_record_starts_kernel, dim3(grid_for(nrec, 256)), dim3(256), 0, c->stream, (const uint64_t *)b.d[5].p, nrec, nb,
                            (uint32_t *)b.d[6].p);
         const uint64_t tiles = (nb + kPlTile - 1) / kPlTile;
-        hipLaunchKernelGGL(canonical_bytes_planes_kernel, dim3((unsigned)(tiles < (uint64_t)c->n_cu * 8 ? tiles : (uint64_t)c->n_cu * 8)), dim3(kPlThreads), 0,
-                           c->stream, (const uint8_t *)b.d[0].p, nb, nt + 16, k, (const uint16_t *)(c->d_lut + 768), (const uint32_t *)b.d[6].p, sb_words,
-                           (uint16_t *)b.d[2].p, (uint16_t *)b.d[3].p, (unsigned long long *)b.d[4].p);
+        const dim3 grid((unsigned)(tiles < (uint64_t)c->n_cu * 8 ? tiles : (uint64_t)c->n_cu * 8));
+        if (kind == 0)
+            hipLaunchKernelGGL(canonical_bytes_planes_kernel, grid, dim3(kPlThreads), 0, c->stream, (const uint8_t *)b.d[0].p, nb, nt + 16, k,
+                               (const uint16_t *)(c->d_lut + 768), (const uint32_t *)b.d[6].p, sb_words, (uint16_t *)b.d[2].p, (uint16_t *)b.d[3].p,
+                               (unsigned long long *)b.d[4].p);
+        else if (kind == 1)
+            hipLaunchKernelGGL(bit_kmers_planes_kernel<true>, grid, dim3(kPlThreads), 0, c->stream, (const uint8_t *)b.d[0].p, nb, nt + 16, k,
+                               (const uint32_t *)b.d[6].p, sb_words, (uint16_t *)b.d[2].p, (uint16_t *)b.d[3].p, values ? (uint64_t *)b.d[1].p : nullptr,
+                               (unsigned long long *)b.d[4].p);
+        else
+            hipLaunchKernelGGL(bit_kmers_planes_kernel<false>, grid, dim3(kPlThreads), 0, c->stream, (const uint8_t *)b.d[0].p, nb, nt + 16, k,
+                               (const uint32_t *)b.d[6].p, sb_words, (uint16_t *)b.d[2].p, (uint16_t *)b.d[3].p, values ? (uint64_t *)b.d[1].p : nullptr,
+                               (unsigned long long *)b.d[4].p);
         if ((e = hipGetLastError())) return hip_fail(e);
         if ((e = hipMemcpyAsync(b.h_total, b.d[4].p, 8, hipMemcpyDeviceToHost, c->stream))) return hip_fail(e);
         if ((e = hipEventRecord(b.ev_scattered, c->stream))) return hip_fail(e);
         if ((e = hipStreamWaitEvent(c->down_stream, b.ev_scattered, 0))) return hip_fail(e);
         if ((e = hipMemcpyAsync(valid16 + ch.wbase, b.d[2].p, (size_t)nw * 2, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
         if ((e = hipMemcpyAsync(rc16 + ch.wbase, b.d[3].p, (size_t)nw * 2, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
+        if (values && (e = hipMemcpyAsync(values + ch.wbase * 16, b.d[1].p, (size_t)nw * 16 * 8, hipMemcpyDeviceToHost, c->down_stream))) return hip_fail(e);
         if ((e = hipEventRecord(b.ev_done, c->down_stream))) return hip_fail(e);
         b.busy = true;
         return NTK_OK;
@@ -1432,6 +1447,20 @@ int ntk_canonical_kmers_batch_planes(ntk_ctx *c, const uint8_t *seq, const uint6
     if ((!valid16 || !rc16) && cap_words) return NTK_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));
     return compat_planes(c, seq, offsets, n_records, k, rec_bit, valid16, rc16, cap_words, n_words, total);
+}
+
+int ntk_bit_kmers_batch_planes(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,
+                               uint64_t *rec_bit, uint16_t *valid16, uint16_t *rc16, uint64_t *values, uint64_t cap_words, uint64_t *n_words,
+                               uint64_t *total)
+{
+    if (!c || !offsets || !rec_bit || !n_words || !total || (!seq && offsets[n_records] > offsets[0])) return NTK_ERR_BAD_ARG;
+    if (k < 1 || k > 32) return NTK_ERR_BAD_K;
+    *total = 0; *n_words = 0;
+    rec_bit[0] = 0;
+    if (n_records == 0) return NTK_OK;
+    if ((!valid16 || !rc16) && cap_words) return NTK_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    return compat_planes(c, seq, offsets, n_records, k, rec_bit, valid16, rc16, cap_words, n_words, total, canonical ? 1 : 2, values);
 }
 
 int ntk_bit_kmers_batch(ntk_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint64_t n_records, uint32_t k, int canonical,

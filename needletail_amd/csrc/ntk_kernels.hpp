@@ -1391,6 +1391,88 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_planes_kernel(cons
     }
 }
 
+// BitNuclKmer (reference src/bitkmer.rs:39-109, Sequence::bit_kmers src/sequence.rs:250-252) in the same bit-plane form, for
+// ntk_bit_kmers_batch_planes: per window START "emitted" and "was_rc", plus (optionally) the item's packed value as a dense u64 per window
+// start (0 where nothing is emitted).  Same staging as above; a thread walks the 8 + k - 1 bytes of its 8 starts once with the run length of
+// bases (acgtACGT only: src/bitkmer.rs:8-15), the rolling forward value and the rolling reverse-complement value (extend_kmer, :26-36, and
+// reverse_complement, :112-132, one base at a time); CANON: the smaller of the two, ties keep the forward k-mer (:136-143).
+template <bool CANON>
+__global__ __launch_bounds__(kPlThreads) void bit_kmers_planes_kernel(const uint8_t *seq, uint64_t n, uint64_t n_readable, uint32_t k, const uint32_t *startbits,
+                                                                      uint64_t sb_words, uint16_t *valid16, uint16_t *rc16, uint64_t *values,
+                                                                      unsigned long long *total)
+{
+    __shared__ __align__(16) uint8_t s_b[kPlTile + 256 + 16];
+    __shared__ uint32_t s_sb[(kPlTile + 256) / 32 + 2];
+    __shared__ uint8_t s_v[kPlThreads], s_r[kPlThreads];
+    __shared__ uint32_t s_cnt[kPlThreads / 64];
+    const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile, n_words = (n + 15) >> 4;
+    const uint32_t need = kPlTile + k - 1;
+    const uint64_t vmask_k = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t top = 2 * k - 2;
+    uint32_t mine = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * kPlTile;
+        __syncthreads();   // the previous tile's readers are done
+        for (uint32_t v = threadIdx.x; v * 16 < need; v += kPlThreads) {
+            const uint64_t p = t0 + (uint64_t)v * 16;
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (p + 16 <= n_readable) x = *reinterpret_cast<const u32x4 *>(seq + p);
+            *reinterpret_cast<u32x4 *>(&s_b[v * 16]) = x;
+        }
+        for (uint32_t w = threadIdx.x; w < need / 32 + 2; w += kPlThreads) {
+            const uint64_t gw = (t0 >> 5) + w;
+            s_sb[w] = gw < sb_words ? startbits[gw] : 0u;
+        }
+        __syncthreads();
+        const uint32_t s = threadIdx.x * kPlPer;
+        uint32_t run = 0, vmask = 0, rmask = 0;
+        uint64_t fwd = 0, rc = 0, out[kPlPer];
+#pragma unroll
+        for (int j = 0; j < kPlPer; j++) out[j] = 0;
+        for (uint32_t i = 0; i < kPlPer + k - 1; i++) {
+            const uint32_t idx = s + i;
+            const uint8_t c = s_b[idx], cu = c & 0xDF;
+            const bool good = t0 + idx < n && (cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T');
+            const bool start = (s_sb[idx >> 5] >> (idx & 31)) & 1u;
+            const uint32_t x = (c >> 1) & 3u, code = x ^ (x >> 1);   // A0 C1 G2 T3
+            run = good ? (start ? 1u : run + 1u) : 0u;
+            fwd = ((fwd << 2) | code) & vmask_k;
+            rc = (rc >> 2) | ((uint64_t)(3u - code) << top);
+            if (i + 1 >= k && run >= k) {
+                const uint32_t j = i + 1 - k;
+                const bool was_rc = CANON && fwd > rc;
+                vmask |= 0x80u >> j;
+                if (was_rc) rmask |= 0x80u >> j;
+#pragma unroll
+                for (int q = 0; q < kPlPer; q++) if ((uint32_t)q == j) out[q] = was_rc ? rc : fwd;
+            }
+        }
+        s_v[threadIdx.x] = (uint8_t)vmask; s_r[threadIdx.x] = (uint8_t)rmask;
+        mine += __popc(vmask);
+        if (values) {
+#pragma unroll
+            for (int q = 0; q < kPlPer; q++) if (t0 + s + q < ((n + 15) & ~(uint64_t)15)) values[t0 + s + q] = out[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < kPlThreads / 2) {
+            const uint64_t w = (t0 >> 4) + threadIdx.x;
+            if (w < n_words) {
+                valid16[w] = (uint16_t)(((uint32_t)s_v[2 * threadIdx.x] << 8) | s_v[2 * threadIdx.x + 1]);
+                rc16[w] = (uint16_t)(((uint32_t)s_r[2 * threadIdx.x] << 8) | s_r[2 * threadIdx.x + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kPlThreads / 64; w++) t += s_cnt[w];
+        if (t) atomicAdd(total, t);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // batched compat face: the items of a whole batch of records, compacted on the device
 // (Sequence::canonical_kmers / bit_kmers for every record of a FastxReader batch in one call, reference

@@ -200,6 +200,57 @@ def canonical_kmers_planes(records, k: int, ctx: Context = None) -> CanonicalKme
     return CanonicalKmersPlanes(k, np.diff(offs.astype(np.int64)), rec_bit, valid16[: nw.value], rc16[: nw.value], tot.value)
 
 
+class BitKmersPlanes(CanonicalKmersPlanes):
+    """The items of Sequence::bit_kmers(k, canonical) for a batch of records (ntk_bit_kmers_batch_planes): per window start "emitted" and
+    "was_rc" as bit planes, and the packed values dense, one u64 per plane position.  `iter(i)` yields exactly what the reference iterator
+    yields for record i - (pos, (value, k), was_rc), reference src/bitkmer.rs:97-108 - and `arrays(i)` the (pos, value, was_rc) arrays.
+    Without values (values=False at the call) a quarter byte per base crosses PCIe and the values are packed here from the window's bases."""
+
+    def __init__(self, k, lengths, rec_bit, valid16, rc16, total, values, records):
+        super().__init__(k, lengths, rec_bit, valid16, rc16, total)
+        self.values, self.records = values, records
+
+    def arrays(self, i):
+        pos, flg = super().arrays(i)
+        if self.values is not None:
+            return pos, self.values[int(self.rec_bit[i]) + pos.astype(np.int64)], flg
+        # the value of an emitted window from its bases: A0 C1 G2 T3, first base most significant (reference src/bitkmer.rs:5-36); the
+        # reverse complement's value where was_rc says so (src/bitkmer.rs:112-132)
+        rec = np.frombuffer(self.records[i], dtype=np.uint8)
+        x = (rec >> 1) & 3
+        code = (x ^ (x >> 1)).astype(np.uint64)
+        vals = np.zeros(len(pos), dtype=np.uint64)
+        for m in range(self.k):
+            fwd = code[pos.astype(np.int64) + m]
+            rcv = np.uint64(3) - code[pos.astype(np.int64) + self.k - 1 - m]
+            vals = (vals << np.uint64(2)) | np.where(flg != 0, rcv, fwd)
+        return pos, vals, flg
+
+    def iter(self, i):
+        pos, val, flg = self.arrays(i)
+        for p, v, f in zip(pos.tolist(), val.tolist(), flg.tolist()):
+            yield (p, (v, self.k), bool(f))
+
+
+def bit_kmers_planes(records, k: int, canonical: bool, ctx: Context = None, values: bool = True) -> BitKmersPlanes:
+    """Sequence::bit_kmers(k, canonical) for a whole batch of records in one device pass, bit-plane result + dense values (see BitKmersPlanes)."""
+    c = _ctx(ctx)
+    if k < 1 or k > 32:
+        raise ValueError("k must be 1..32")
+    seq, offs = _pack_records(records)
+    cap = int(offs[-1]) // 16 + len(records) + 1
+    rec_bit = np.zeros(len(records) + 1, dtype=np.uint64)
+    valid16 = np.zeros(cap, dtype=np.uint16)
+    rc16 = np.zeros(cap, dtype=np.uint16)
+    vals = np.zeros(cap * 16, dtype=np.uint64) if values else None
+    nw, tot = C.c_uint64(0), C.c_uint64(0)
+    L.check(L.lib().ntk_bit_kmers_batch_planes(c._h, seq, offs.ctypes.data, len(records), k, int(canonical), rec_bit.ctypes.data, valid16.ctypes.data,
+                                               rc16.ctypes.data, vals.ctypes.data if values else None, cap, C.byref(nw), C.byref(tot)),
+            "ntk_bit_kmers_batch_planes")
+    return BitKmersPlanes(k, np.diff(offs.astype(np.int64)), rec_bit, valid16[: nw.value], rc16[: nw.value], tot.value,
+                          vals[: nw.value * 16] if values else None, list(records))
+
+
 def minimizer(seq: bytes, length: int, ctx: Context = None) -> bytes:
     """sequence::minimizer (reference src/sequence.rs:139-152)."""
     c = _ctx(ctx)

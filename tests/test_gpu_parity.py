@@ -1369,3 +1369,36 @@ def test_minimizer_batch_matches_the_reference_function_per_record(ctx, restore_
     # a record shorter than m: the call fails before computing anything and names the record
     with pytest.raises(ValueError, match="record 1 "):
         nt.minimizer_batch([b"ACGTACGT", b"ACG", b"ACGTACGT"], 5, ctx)
+
+
+@pytest.mark.parametrize("chunk_bytes", [None, 97, 4096])
+def test_bit_kmers_planes_face_matches_the_iterator_per_record(ctx, chunk_bytes, restore_options):
+    """ntk_bit_kmers_batch_planes = Sequence::bit_kmers(k, canonical) (reference src/sequence.rs:250-252, src/bitkmer.rs:39-143) for every record
+    of a batch as "emitted" / "was_rc" planes per window start + dense packed values: element-wise against the oracle's literal iterator,
+    record by record - every k 1..32, canonical and forward-only, ragged / empty / all-N records, mixed case, U (a break on this path), palindromes
+    (ties keep the forward k-mer), records touching chunk boundaries (the three-bank pipeline over hundreds of chunks) - with the values
+    downloaded and with the values packed on the host from the planes."""
+    ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, chunk_bytes or 0)
+    rng = np.random.default_rng(57)
+    alphabet = np.frombuffer(b"ACGTACGTACGTacgtNnU-", dtype=np.uint8)
+    records = [b"", b"A", b"N" * 40, b"ACGT" * 10, b"acgtACGTnACGTTGCA" * 3, b"AATT", b"GAATTC" * 6]
+    for _ in range(300):
+        records.append(bytes(alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 400)))]))
+    records.append(bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8)))
+    for k in (1, 2, 4, 11, 16, 17, 21, 31, 32):
+        for canonical in (True, False):
+            pl = nt.bit_kmers_planes(records, k, canonical, ctx)
+            total = 0
+            for i, r in enumerate(records):
+                want = O.bit_kmers(r, k, canonical)
+                assert list(pl.iter(i)) == want, (k, canonical, i)
+                total += len(want)
+            assert pl.total == total
+    # values packed on the host from the planes alone (values=False: a quarter byte per base crosses PCIe)
+    for k, canonical in ((21, True), (4, True), (32, False)):
+        pl = nt.bit_kmers_planes(records, k, canonical, ctx, values=False)
+        for i, r in enumerate(records):
+            assert list(pl.iter(i)) == O.bit_kmers(r, k, canonical), (k, canonical, i, "host-packed")
+    assert nt.bit_kmers_planes([], 5, True, ctx).total == 0
+    with pytest.raises(ValueError):
+        nt.bit_kmers_planes(records, 33, True, ctx)
