@@ -502,12 +502,12 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
-        st = nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=th, batch_bytes=8 << 20, data=text)
+        st = nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=th, batch_bytes=4 << 20, data=text)
         dt = time.perf_counter() - t0
         if not (stats_equal(st, want) and st["n_records"] == p_reads):
             raise SystemExit("secondary: the pipeline result differs from the resident scan")
         best = dt if best is None else min(best, dt)
-    out["pipeline_fastq_h2d_inclusive"] = {"reads": p_reads, "parser_threads": th, "seconds": round(best, 4),
+    out["pipeline_fastq_h2d_inclusive"] = {"reads": p_reads, "parser_threads": th, "batch_MiB": 4, "copy_streams": 2, "seconds": round(best, 4),
                                            "Gbases_s": round(p_reads * read_len / best / 1e9, 2),
                                            "fastq_GB_s": round(len(text) / best / 1e9, 2)}
     try:
@@ -608,7 +608,7 @@ def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
-            st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
+            st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=4 << 20, w=w, streaming_fallback=False)
             dt = time.perf_counter() - t0
             if not (stats_equal(st, want) and st["n_records"] == reads):
                 raise SystemExit("secondary: config 5 (gzip + minimizers) differs from the resident minimizer run")
@@ -655,7 +655,7 @@ def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
         bbest = None
         for _ in range(2):
             t0 = time.perf_counter()
-            st = nt.scan_file_parallel(ctx, bpath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
+            st = nt.scan_file_parallel(ctx, bpath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=4 << 20, w=w, streaming_fallback=False)
             dt = time.perf_counter() - t0
             if not (stats_equal(st, want) and st["n_records"] == reads):
                 raise SystemExit("secondary: config 5 (block gzip + minimizers) differs from the resident minimizer run")

@@ -133,8 +133,11 @@ int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
  *                                  builds, the generic fused kernel (both off = materialise + window-min), the v_min_f64 keys of the
  *                                  generic kernel (k <= 25 then runs the general keys) - so that each route can be checked against
  *                                  the others on the same input
- *   NTK_OPT_COMPAT_PACK_THREADS    host threads that pack a chunk of the item-array compat faces (default 8) */
-enum { NTK_OPT_COMPAT_CHUNK_BYTES = 1, NTK_OPT_MINIMIZER_CHUNK_BYTES = 2, NTK_OPT_MINIMIZER_ROUTE = 3, NTK_OPT_COMPAT_PACK_THREADS = 4 };
+ *   NTK_OPT_COMPAT_PACK_THREADS    host threads that pack a chunk of the item-array compat faces (default 8)
+ *   NTK_OPT_COPY_STREAMS           HIP streams that take the pinned batches' H2D copies in turn (1 or 2; default 2: the next batch's copy is
+ *                                  queued while one runs - measured +14 % on the H2D-inclusive FASTQ pipeline with 4 MiB batches) */
+enum { NTK_OPT_COMPAT_CHUNK_BYTES = 1, NTK_OPT_MINIMIZER_CHUNK_BYTES = 2, NTK_OPT_MINIMIZER_ROUTE = 3, NTK_OPT_COMPAT_PACK_THREADS = 4,
+       NTK_OPT_COPY_STREAMS = 5 };
 #define NTK_ROUTE_NO_REGFUSED 1u
 #define NTK_ROUTE_NO_GENERIC 2u
 #define NTK_ROUTE_NO_F64 4u

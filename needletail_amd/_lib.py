@@ -17,7 +17,7 @@ HIST_BINS = 4096
 ACC_N_TOTAL, ACC_N_FWD, ACC_N_RC, ACC_SUM, ACC_XOR, ACC_HIST = 0, 1, 2, 3, 4, 8
 ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 # ntk_ctx_set_option (test / A-B support)
-OPT_COMPAT_CHUNK_BYTES, OPT_MINIMIZER_CHUNK_BYTES, OPT_MINIMIZER_ROUTE, OPT_COMPAT_PACK_THREADS = 1, 2, 3, 4
+OPT_COMPAT_CHUNK_BYTES, OPT_MINIMIZER_CHUNK_BYTES, OPT_MINIMIZER_ROUTE, OPT_COMPAT_PACK_THREADS, OPT_COPY_STREAMS = 1, 2, 3, 4, 5
 ROUTE_NO_REGFUSED, ROUTE_NO_GENERIC, ROUTE_NO_F64 = 1, 2, 4
 ROUTE_TWO_PASS = ROUTE_NO_REGFUSED | ROUTE_NO_GENERIC
 

@@ -110,6 +110,9 @@ struct ntk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream (kernels, compat-face copies)
     hipStream_t copy_stream = nullptr;  // H2D copies of pinned batches
+    hipStream_t copy_stream2 = nullptr; // ... every second batch's when NTK_OPT_COPY_STREAMS is 2: the next copy is queued on the other DMA queue
+                                        // while one runs, so the link does not idle between batches
+    uint32_t copy_streams = 2, copy_rr = 0;
     hipStream_t down_stream = nullptr;  // D2H copies of the bit-plane compat face (its uploads keep the copy stream to themselves)
     bool owns_stream = false;
     int n_cu = 256;
@@ -493,6 +496,7 @@ int init_ctx(ntk_ctx *c, void *stream, bool borrow)
     if (borrow) { c->stream = (hipStream_t)stream; c->owns_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_acc_own, NTK_ACC_WORDS * sizeof(uint64_t)));
     c->d_acc = c->d_acc_own;
@@ -559,6 +563,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->owns_stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->copy_stream2) (void)hipStreamSynchronize(c->copy_stream2);
     if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
     for (auto &p : c->ev_used) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
@@ -579,6 +584,7 @@ void ntk_ctx_destroy(ntk_ctx *c)
     }
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream2) (void)hipStreamDestroy(c->copy_stream2);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     delete c;
 }
@@ -588,6 +594,7 @@ int ntk_ctx_synchronize(ntk_ctx *c)
     if (!c) return NTK_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(c->device));   // (a process may drive several devices: every entry point selects its ctx's own)
     HIPCHK(hipStreamSynchronize(c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream2));
     HIPCHK(hipStreamSynchronize(c->stream));
     return NTK_OK;
 }
@@ -613,6 +620,10 @@ int ntk_ctx_set_option(ntk_ctx *c, int option, uint64_t value)
     case NTK_OPT_MINIMIZER_ROUTE:
         if (value & ~(uint64_t)(NTK_ROUTE_NO_REGFUSED | NTK_ROUTE_NO_GENERIC | NTK_ROUTE_NO_F64)) return NTK_ERR_BAD_ARG;
         c->route_off = (uint32_t)value;
+        return NTK_OK;
+    case NTK_OPT_COPY_STREAMS:            // 0 = default (2); 1 or 2 HIP streams take the pinned batches' H2D copies in turn
+        if (value > 2) return NTK_ERR_BAD_ARG;
+        c->copy_streams = value ? (uint32_t)value : 2u;
         return NTK_OK;
     case NTK_OPT_COMPAT_PACK_THREADS: {   // 0 = default (8); capped by the hardware threads and 64
         uint64_t v = value ? value : 8;
@@ -784,7 +795,18 @@ static int batch_append_impl(ntk_batch *b, const uint8_t *seq, const uint8_t *qu
     // Line by line (memchr for LF): a line without any other byte of the deleted class - the usual case, checked by a
     // branch-free reduction the compiler vectorises - is one memcpy; wrapped FASTA contigs cost a memchr + memcpy per line.
     const bool ws = pre != NTK_PRE_STRIP_RETURNS;
-    if (pre == NTK_PRE_NONE) {
+    bool plain = pre == NTK_PRE_NONE;
+    if (!plain && n <= 4096) {
+        // a short record (a read): ONE branch-free pass says whether any byte of the deleted class is in it at all - the usual answer is no,
+        // and the record is one memcpy (the line-by-line walk below costs a memchr and a second pass per line)
+        unsigned any = 0;
+        for (uint64_t j = 0; j < n; j++) {
+            const uint8_t ch = seq[j];
+            any |= (unsigned)(ch == '\n') | (unsigned)(ch == '\r') | ((unsigned)ws & ((unsigned)(ch == ' ') | (unsigned)(ch == '\t')));
+        }
+        plain = !any;
+    }
+    if (plain) {
         memcpy(o, seq, n); w = n;
         if (oq) { if (qual) memcpy(oq, qual, n); else memset(oq, 0xFF, n); }
     } else {
@@ -857,16 +879,17 @@ int ntk_batch_submit(ntk_ctx *c, ntk_batch *b, const ntk_params *p)
     if (b->n_bytes) {
         const uint64_t padded = (b->n_bytes + 15) & ~(uint64_t)15;
         for (uint64_t i = b->n_bytes; i < padded; i++) b->h_seq[i] = '\n';
-        HIPCHK(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, c->copy_stream));
+        hipStream_t cs = (c->copy_streams > 1 && (c->copy_rr++ & 1u)) ? c->copy_stream2 : c->copy_stream;
+        HIPCHK(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, cs));
         // the quality stream travels only when a cutoff is set and some record of this fill carries qualities
         const uint8_t *d_qual = nullptr;
         if (b->has_qual && quality_cutoff(p) != b->qual_cutoff) return NTK_ERR_BAD_ARG;
         if (quality_cutoff(p) && b->has_qual) {
             for (uint64_t i = b->n_bytes; i < padded; i++) b->h_qual[i] = 0xFF;
-            HIPCHK(hipMemcpyAsync(b->d_qual, b->h_qual, padded, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(hipMemcpyAsync(b->d_qual, b->h_qual, padded, hipMemcpyHostToDevice, cs));
             d_qual = b->d_qual;
         }
-        HIPCHK(hipEventRecord(b->ev_copied, c->copy_stream));
+        HIPCHK(hipEventRecord(b->ev_copied, cs));
         HIPCHK(hipStreamWaitEvent(c->stream, b->ev_copied, 0));
         rc = (p->flags & 0xFFu) ? minimizers_reduce_impl(c, b->d_seq, d_qual, b->n_bytes, p, p->flags & 0xFFu)
                                : run_scan(c, b->d_seq, b->n_bytes, p, m, true, nullptr, nullptr, nullptr, d_qual);

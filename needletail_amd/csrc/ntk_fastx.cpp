@@ -295,6 +295,15 @@ bool FastxReader::sniff()
         zin_.assign(kBufSize, 0);
         zin_[0] = two[0]; zin_[1] = two[1];
         zin_pos_ = 0; zin_len_ = 2;
+    } else if (mem_ && !fp_) {
+        // plain text in the caller's memory (which outlives the reader): records are parsed where they lie - no pass through the
+        // reader's own buffer (copying every byte once and moving record tails to the buffer's front cost a third of the time
+        // a parser thread of the parallel producer spends per record)
+        view_ = mem_;
+        len_ = (size_t)mem_n_;
+        mem_pos_ = mem_n_;
+        eof_ = true;
+        buf_.clear(); buf_.shrink_to_fit();
     } else {
         buf_[0] = two[0]; buf_[1] = two[1];
         len_ = 2;
@@ -304,9 +313,10 @@ bool FastxReader::sniff()
         if (err_kind_) return false;
         if (len_ == 0) return fail(kErrEmptyFile, "Failed to read the first two bytes. Is the file empty?", 0);
     }
-    if (buf_[0] == '>') format_ = kFasta;
-    else if (buf_[0] == '@') format_ = kFastq;
-    else return fail(kErrUnknownFormat, "Expected '@' or '>' at the start of the file but found '" + escape_byte(buf_[0]) + "'.", 0);
+    const uint8_t first = data()[0];
+    if (first == '>') format_ = kFasta;
+    else if (first == '@') format_ = kFastq;
+    else return fail(kErrUnknownFormat, "Expected '@' or '>' at the start of the file but found '" + escape_byte(first) + "'.", 0);
     started_ = true;
     line_ = 1;
     return true;
@@ -399,7 +409,7 @@ int FastxReader::next_fasta(FastxRecord *rec)
     // line.  Offsets are relative to start_ so that they survive make_room() / grow() inside fill().
     size_t scan = 1, first_nl = (size_t)-1, last_nl = (size_t)-1, rec_len = 0;
     for (;;) {
-        const uint8_t *base = buf_.data() + start_;
+        const uint8_t *base = data() + start_;
         const size_t avail = len_ - start_;
         bool complete = false;
         if (first_nl == (size_t)-1 && scan < avail) {
@@ -429,7 +439,7 @@ int FastxReader::next_fasta(FastxRecord *rec)
         rec_len = avail;
         break;
     }
-    const uint8_t *base = buf_.data() + start_;
+    const uint8_t *base = data() + start_;
     rec->format = kFasta;
     rec->line = line_;
     rec->id = base + 1;
@@ -497,8 +507,14 @@ int FastxReader::next_fastq(FastxRecord *rec)
     size_t nl[4];
     int found = 0;
     for (;;) {
-        const uint8_t *base = buf_.data() + start_;
+        const uint8_t *base = data() + start_;
         const size_t avail = len_ - start_;
+        if (view_ && avail > 4096) {   // records parsed where they lie come straight from DRAM: ask for the lines a few records ahead now
+            // (without it the zero-copy path was SLOWER than the copying one, 69 against 44 ns per 150-base record: the copy had been the
+            //  prefetch; with it 37 ns, and the record's bytes are still in L1 when the packer copies them)
+            __builtin_prefetch(base + 2048); __builtin_prefetch(base + 2112); __builtin_prefetch(base + 2176);
+            __builtin_prefetch(base + 2240); __builtin_prefetch(base + 2304);
+        }
         found = find_newlines(base, avail, nl, 4);
         if (found == 4) break;
         if (!eof_) {
@@ -519,7 +535,7 @@ int FastxReader::next_fastq(FastxRecord *rec)
         fail(kErrUnexpectedEnd, "Unexpected end of input", line_ + (uint64_t)found, id);
         return -1;
     }
-    const uint8_t *base = buf_.data() + start_;
+    const uint8_t *base = data() + start_;
     const size_t seq0 = nl[0] + 1, sep0 = nl[1] + 1, qual0 = nl[2] + 1, end = nl[3];
     // validate, reference src/parser/fastq.rs:240-285
     if (base[0] != '@') {

@@ -79,6 +79,8 @@ private:
     size_t read_plain(uint8_t *dst, size_t cap);   // after optional inflate; 0 = EOF; (size_t)-1 = error
     // record buffer
     std::vector<uint8_t> buf_; size_t len_ = 0, start_ = 0; bool eof_ = false;
+    const uint8_t *view_ = nullptr;   // plain in-memory input: the caller's bytes themselves (buf_ unused)
+    const uint8_t *data() const { return view_ ? view_ : buf_.data(); }
     size_t fill();             // appends to buf_, returns bytes added (0 at EOF)
     void make_room_or_grow();
     int format_ = kFasta; bool started_ = false, finished_ = false;

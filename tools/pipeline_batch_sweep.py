@@ -18,8 +18,10 @@ rec[:, 1 + idw] = 10; rec[:, 2 + idw:2 + idw + RL] = seqs[:, :RL]; rec[:, 2 + id
 rec[:, 3 + idw + RL] = ord("+"); rec[:, 4 + idw + RL] = 10; rec[:, 5 + idw + RL:5 + idw + 2 * RL] = ord("I"); rec[:, 5 + idw + 2 * RL] = 10
 text = rec.tobytes(); del rec, seqs
 ctx.accum_reset(); ctx.reduce_device(dev, reads * (RL + 1), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE); want = ctx.accum_read()
-for th in (16, 32):
-    for bb in (2 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20, 64 << 20):
+from needletail_amd import _lib as NL
+for cs, th, bb in [(c_, t_, b_) for c_ in (1, 2) for t_ in (16, 24, 32) for b_ in (4 << 20, 8 << 20, 16 << 20, 32 << 20)]:
+    if True:
+        ctx.set_option(NL.OPT_COPY_STREAMS, cs)
         best = None
         for _ in range(3):
             t0 = time.perf_counter()
@@ -27,4 +29,5 @@ for th in (16, 32):
             dt = time.perf_counter() - t0
             assert st["n_total"] == want["n_total"] and st["sum"] == want["sum"] and st["n_records"] == reads
             best = dt if best is None else min(best, dt)
-        print(f"threads {th:3d} batch {bb >> 20:3d} MiB: {best * 1e3:7.1f} ms  {reads * RL / best / 1e9:6.2f} Gbases/s", flush=True)
+        print(f"copy streams {cs} threads {th:3d} batch {bb >> 20:3d} MiB: {best * 1e3:7.1f} ms  {reads * RL / best / 1e9:6.2f} Gbases/s", flush=True)
+# where the workers' time goes at the bench's setting (NTK_PIPE_STATS: per-thread phase times on stderr)
