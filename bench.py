@@ -498,16 +498,18 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     ctx.reduce_device(k21_seq, p_reads * (read_len + 1), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
     want = ctx.accum_read()
     del rec, seqs
-    th = min(32, os.cpu_count() or 1)
+    # 24 parser threads on the 16 granted CPUs, 8 MiB batches, two copy streams: the best cell of tools/pipeline_batch_sweep.py
+    # (profiles/r05c/pipeline_sweep.txt; the parser threads are the bound, the copies hide behind them)
+    th = min(24, os.cpu_count() or 1)
     best = None
-    for _ in range(3):
+    for _ in range(4):
         t0 = time.perf_counter()
-        st = nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=th, batch_bytes=4 << 20, data=text)
+        st = nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=th, batch_bytes=8 << 20, data=text)
         dt = time.perf_counter() - t0
         if not (stats_equal(st, want) and st["n_records"] == p_reads):
             raise SystemExit("secondary: the pipeline result differs from the resident scan")
         best = dt if best is None else min(best, dt)
-    out["pipeline_fastq_h2d_inclusive"] = {"reads": p_reads, "parser_threads": th, "batch_MiB": 4, "copy_streams": 2, "seconds": round(best, 4),
+    out["pipeline_fastq_h2d_inclusive"] = {"reads": p_reads, "parser_threads": th, "batch_MiB": 8, "copy_streams": 2, "seconds": round(best, 4),
                                            "Gbases_s": round(p_reads * read_len / best / 1e9, 2),
                                            "fastq_GB_s": round(len(text) / best / 1e9, 2)}
     try:
