@@ -627,11 +627,11 @@ struct DevMasks2 {
             asm volatile(NTK_R_POS(0, "v_add_u32 %[nfb], %[nfb], %[f0]\n") NTK_R_POS(1, "v_add_u32 %[nfb], %[nfb], %[f1]\n")
                          NTK_R_POS(2, "v_add_u32 %[nfb], %[nfb], %[f2]\n") NTK_R_POS(3, "v_add_u32 %[nfb], %[nfb], %[f3]\n") "s_mov_b64 exec, -1\n"
                          : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [nfb] "+v"(nf_bits), [sd] "=&s"(sd)
-                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory");
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
         else
             asm volatile(NTK_R_POS(0, "") NTK_R_POS(1, "") NTK_R_POS(2, "") NTK_R_POS(3, "") "s_mov_b64 exec, -1\n"
                          : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [sd] "=&s"(sd)
-                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory");
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
 #undef NTK_R_IN
 #undef NTK_R_POS
     }
@@ -673,7 +673,7 @@ struct DevMasks2 {
 #define NTK_R_IN(i) [o##i] "v"(off[i]), [l##i] "v"(lo[i]), [h##i] "v"(hi[i]), NTK_R_MASKS(i)
             asm volatile(NTK_R_POS(0) NTK_R_POS(1) NTK_R_POS(2) NTK_R_POS(3) "s_mov_b64 exec, -1\n"
                          : [sumA] "+v"(sum), [sumB] "+v"(sum2), [sumh] "+v"(sumh), [xlo] "+v"(xlo), [xh] "+v"(xh), [sd] "=&s"(sd)
-                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory");
+                         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "scc");   // (s_and_b64 writes SCC)
 #undef NTK_R_IN
 #undef NTK_R_POS
         }

@@ -220,6 +220,41 @@ def test_launch_geometry_invariance(ctx):
         ctx.set_launch(0, 0)   # back to the automatic geometry: the ctx is shared by the module's tests
 
 
+def test_every_kernel_family_with_many_tiles_per_wave(ctx):
+    """Few blocks on a few MB: every wave runs MANY tiles and several chunks, so whatever the compiler keeps live across the masked asm regions
+    from one tile to the next (tile offsets, 64-bit carries in SCC, exec) is exercised for every kernel family - the default geometry gives
+    a wave ONE tile on inputs of this size.  Regression: the forward-only and fused-minimizer regions once lost their "scc" clobber and the
+    64-bit tile offset's carry with it (found by tools/gpu_fuzz.py under a forced 7-block launch, profiles/r05e/)."""
+    buf = O.synth_reads(0x5EED0002, 7, 14000, 150, 1).tobytes()   # ~2.1 MB, an N every ~1024 bases
+    n = len(buf)
+    t = to_dev(buf)
+    rng = np.random.default_rng(77)
+    qual = rng.integers(33, 75, size=n, dtype=np.uint8).tobytes()
+    tq = _qual_dev(qual)
+    masked = O.quality_mask(buf, qual, 40)
+    kmers = [(k, mode) for k in (3, 6, 7, 11, 15, 16, 17, 21, 23, 24, 31, 32) for mode in range(3)]
+    mins = [(21, 11, 0), (15, 10, 0), (19, 12, 1), (23, 11, 0), (25, 33, 1), (31, 19, 0), (27, 11, 1), (12, 5, 0), (21, 19, 1)]
+    try:
+        for launch in ((7, 0), (2, 512), (0, 0)):
+            ctx.set_launch(*launch)
+            for k, mode in kmers:
+                path, pre, canon, tie_rc, accept_u = MODES[mode]
+                ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre)
+                assert_stats_equal(ctx.accum_read(), O.reduce_fused(buf, k, canon, tie_rc, accept_u), ("k-mers", launch, k, mode))
+            for k, w, bits in mins:
+                path, pre, tie, u = (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False) if bits else (nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True)
+                ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre, w=w)
+                assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie), ("minimizers", launch, k, w, bits))
+            for k in (4, 21, 31):
+                ctx.accum_reset(); ctx.reduce_device(t, n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, d_qual=tq, quality_cutoff=40)
+                assert_stats_equal(ctx.accum_read(), O.reduce_fused(masked, k, True, True, True), ("quality", launch, k))
+            for k, w in ((21, 11), (23, 11)):
+                ctx.accum_reset(); ctx.reduce_device(t, n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w, d_qual=tq, quality_cutoff=40)
+                assert_stats_equal(ctx.accum_read(), O.minimizers_reduce(masked, k, w, True, True), ("quality minimizers", launch, k, w))
+    finally:
+        ctx.set_launch(0, 0)
+
+
 def test_unsupported_and_bad_args_are_errors(ctx):
     t = to_dev(b"ACGT" * 100)
     with pytest.raises(nt.NtkError) as e:

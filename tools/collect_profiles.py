@@ -12,7 +12,7 @@ src = os.path.join("gpurun_out", tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 for f in ("bench.json", "bench_under_rocprof.json", "bench_rccl_1rank.json", "ablation.txt", "ubench.txt", "ubench3.txt", "quality_bench.json",
-          "pipeline_and_materialize.json", "path_sweep.txt", "path_pmc.txt", "min_grid.txt", "compat_bench.txt", "pytest_gpu.log", "gpu_fuzz.log", "wbw.txt", "min_generic.txt"):
+          "pipeline_and_materialize.json", "path_sweep.txt", "path_pmc.txt", "min_grid.txt", "compat_bench.txt", "pytest_gpu.log", "gpu_fuzz.log", "wbw.txt", "min_generic.txt", "min_ab.txt", "min_generic_contigs.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 ks = os.path.join(src, "trace", "p_kernel_stats.csv")

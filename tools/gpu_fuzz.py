@@ -94,23 +94,30 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--minimizers-only", action="store_true", help="windowed minimizers only, byte path (ties -> rc, U) and bit path (ties -> fwd)")
+    ap.add_argument("--replay-it", type=int, default=0, help="replay: consume the generator as the run with this seed did, do the device work of iteration N only")
+    ap.add_argument("--replay-from", type=int, default=0, help="with --replay-it N: do the device work from this iteration on (default N)")
+    ap.add_argument("--dump", default="", help="with --replay-it: write iteration N's input bytes to this file and stop (needs no GPU)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
-    ctx = nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = None if args.dump else nt.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     t_end = time.time() + args.seconds
     counts = {"reduce": 0, "materialize": 0, "minimizers": 0, "quality": 0, "compat_batch": 0, "compat_planes": 0}
     n_bytes = 0
     it = 0
-    while time.time() < t_end:
+    while time.time() < t_end or args.replay_it:
         it += 1
+        if args.replay_it and it > args.replay_it:
+            break
+        skip = it < (args.replay_from or args.replay_it)   # replay: the generator is consumed exactly as in the original run, the device work is skipped
         k = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 11, 15, 16, 17, 18, 20, 21, 22, 23, 24, 27, 30, 31, 32]))
         path, pre, canon, tie, u = MODES[int(rng.integers(0, len(MODES)))]
         a = make_input(rng, k)
         n = len(a)
         n_bytes += n
-        t = torch.full(((n + 1023) // 1024 * 1024 + 1024,), 0x41, dtype=torch.uint8, device="cuda")
-        if n:
-            t[:n] = torch.from_numpy(a).cuda()
+        if not skip and not args.dump:
+            t = torch.full(((n + 1023) // 1024 * 1024 + 1024,), 0x41, dtype=torch.uint8, device="cuda")
+            if n:
+                t[:n] = torch.from_numpy(a).cuda()
         buf = a.tobytes()
         what = rng.integers(0, 10)
         if args.minimizers_only:
@@ -118,11 +125,47 @@ def main():
             path, pre, canon, tie, u = MODES[int(rng.integers(0, 2))]
         # launch geometry: mostly the library's choice, sometimes forced (few / many blocks, small / large blocks: the shard, chunk
         # and work-counter arithmetic of the scan must not depend on it)
-        if rng.random() < 0.3:
-            ctx.set_launch(int(rng.choice([1, 2, 7, 64, 300, 512, 1024, 2048])), int(rng.choice([0, 64, 128, 256, 512, 768, 1024])))
-        else:
-            ctx.set_launch(0, 0)
-        tag = f"it {it} seed {args.seed} k {k} path {path} pre {pre} n {n}"
+        launch = (int(rng.choice([1, 2, 7, 64, 300, 512, 1024, 2048])), int(rng.choice([0, 64, 128, 256, 512, 768, 1024]))) if rng.random() < 0.3 else (0, 0)
+        tag = f"it {it} seed {args.seed} k {k} path {path} pre {pre} n {n} launch {launch}"
+        if args.dump and not skip:
+            open(args.dump, "wb").write(buf)
+            print("dumped", tag, "what", int(what)); return 0
+        if not skip:
+            ctx.set_launch(*launch)
+        if args.dump and skip and it + 6 > args.replay_it:
+            print("before:", tag, "what", int(what))
+        if skip:
+            # the draws of the branch this iteration took, without its device work
+            if what < 5 or (what < 6 and n <= 400000):
+                pass
+            elif what < 8 and canon and (path, pre) in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE)):
+                if rng.random() < 0.4:
+                    if rng.random() < 0.5: rng.choice([1, 2, 9, 10, 11, 12, 16, 33])
+                    if not rng.random() < 0.5: rng.choice([15, 16, 17, 18, 19, 20, 21, 22])
+                else:
+                    if rng.random() < 0.8: rng.integers(1, 52)
+                    else: rng.choice([15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 64])
+                    rng.integers(1, 33)
+            elif what < 9:
+                rng.integers(33, 75, n, dtype=np.uint8)
+                if n and rng.random() < 0.5:
+                    rng.integers(0, n, max(1, n // 50))
+                rng.integers(33, 76)
+                if canon and path == nt.PATH_BYTES_CANONICAL and pre == nt.PRE_NORMALIZE and rng.random() < 0.4:
+                    rng.integers(0, 4)
+            elif n <= 300000:
+                cuts = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, int(rng.integers(0, 30)))])).astype(np.int64)
+                if len(cuts) > 1:
+                    if rng.random() < 0.25:
+                        rng.choice([1, 2, 5, k, 31, 40])
+                    else:
+                        u3 = rng.random()
+                        if u3 < 0.34:
+                            rng.choice([k, k, int(rng.integers(1, 64)), int(rng.integers(64, 256))])
+                            if rng.random() < 0.5: rng.choice([64, 97, 1000, 4096, 1 << 16])
+                        elif u3 >= 0.67:
+                            rng.integers(0, 2)
+            continue
         if what < 5:
             ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre)
             if not stats_equal(ctx.accum_read(), O.reduce_fused(buf, k, canon, tie, u)):
