@@ -163,6 +163,9 @@ def main():
                         if u3 < 0.34:
                             rng.choice([k, k, int(rng.integers(1, 64)), int(rng.integers(64, 256))])
                             if rng.random() < 0.5: rng.choice([64, 97, 1000, 4096, 1 << 16])
+                        elif u3 >= 0.84:
+                            rng.integers(0, 2); rng.integers(0, 2)
+                            if rng.random() < 0.5: rng.choice([64, 97, 1000, 4096, 1 << 16])
                         elif u3 >= 0.67:
                             rng.integers(0, 2)
             continue
@@ -254,6 +257,23 @@ def main():
                 if not ok:
                     print("MISMATCH compat planes", tag, "k", kp); return 1
                 counts["compat_planes"] += 1
+                continue
+            if u3 >= 0.84:
+                # Sequence::bit_kmers per record as bit planes (+ dense values, or values rebuilt on the host)
+                c2, with_values = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+                ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, int(rng.choice([64, 97, 1000, 4096, 1 << 16])) if rng.random() < 0.5 else 0)
+                pl = nt.bit_kmers_planes(recs, k, c2, ctx, values=with_values)
+                ctx.set_option(NL.OPT_COMPAT_CHUNK_BYTES, 0)
+                ok, tot = True, 0
+                for i, r in enumerate(recs):
+                    p_, v_, f_ = O.bit_kmers_arrays(r, k, c2)
+                    gp, gv, gf = pl.arrays(i)
+                    ok = ok and np.array_equal(gp, np.asarray(p_, dtype=np.uint64)) and np.array_equal(gv, np.asarray(v_, dtype=np.uint64)) and \
+                        np.array_equal(gf, np.asarray(f_, dtype=np.uint8))
+                    tot += len(p_)
+                if not (ok and pl.total == tot):
+                    print("MISMATCH bit planes", tag, "canonical", c2, "values", with_values); return 1
+                counts["bit_planes"] = counts.get("bit_planes", 0) + 1
                 continue
             if u3 < 0.67:
                 cnt, pos, flg = nt.canonical_kmers_batch(recs, k, ctx=ctx)

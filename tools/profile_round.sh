@@ -40,5 +40,5 @@ python tools/min_ab.py > $O/min_ab.txt 2>/dev/null
 python tools/min_generic_contigs.py > $O/min_generic_contigs.txt 2>&1
 python tools/gpu_fuzz.py --seconds 100 --seed 50${RANDOM:0:2} > $O/gpu_fuzz.log 2>&1
 python tools/gpu_fuzz.py --seconds 60 --seed 51${RANDOM:0:2} --minimizers-only >> $O/gpu_fuzz.log 2>&1
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log
 ls $O
