@@ -177,7 +177,11 @@ void ntk_comm_destroy(ntk_comm *comm);
  * round_up(n_bytes, 16).
  * Replaces, per record: seq.normalize(..) / strip_returns(), seq.reverse_complement(),
  * seq.canonical_kmers(k,&rc) or seq.bit_kmers(k,canonical) and the user's counting loop
- * (reference src/lib.rs:22-31, benches/benchmark.rs:32-41,55-64). */
+ * (reference src/lib.rs:22-31, benches/benchmark.rs:32-41,55-64).
+ * NTK_PATH_BYTES_CANONICAL with pre = NONE / STRIP_RETURNS (bytes the caller did not normalise): the reference iterator compares RAW
+ * bytes (src/kmer.rs:121-128; lower case sorts above upper case), so reduce mode runs a raw-byte kernel for it (slower than the
+ * packed-value scan, exact on mixed case); dense values (ntk_materialize_device), quality masking and windowed minimizers on such
+ * input are NTK_ERR_UNSUPPORTED - normalize first, as the reference's documented chain does. */
 int ntk_accum_reset(ntk_ctx *ctx);
 int ntk_reduce_device(ntk_ctx *ctx, const uint8_t *d_seq, uint64_t n_bytes, const ntk_params *p); /* async */
 /* Quality masking fused into the scan: `(seq, qual).quality_mask(cutoff)` (reference

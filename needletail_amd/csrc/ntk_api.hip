@@ -184,7 +184,7 @@ int ensure_partials(ntk_ctx *c, int blocks)
     return NTK_OK;
 }
 
-struct Mode { int kw; bool canon, tie_rc, accept_u; };
+struct Mode { int kw; bool canon, tie_rc, accept_u; bool raw_bytes = false; };
 inline uint32_t quality_cutoff(const ntk_params *p) { return (p->flags >> 8) & 0xFFu; }
 
 int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
@@ -197,9 +197,9 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
     switch (p->path) {
     case NTK_PATH_BYTES_CANONICAL:
         // The byte path compares RAW bytes (reference src/kmer.rs:124); that equals the 2-bit order only when
-        // every base has the same case, which normalize guarantees.  Un-normalised byte-path input goes through
-        // ntk_canonical_kmers (raw-byte kernel); the packed-value scan refuses it rather than approximate.
-        if (batch_face && p->pre < NTK_PRE_NORMALIZE) return NTK_ERR_UNSUPPORTED;
+        // every base has the same case, which normalize guarantees.  Un-normalised byte-path input takes the raw-byte kernels
+        // (reduce mode: canonical_bytes_reduce_kernel; items: ntk_canonical_kmers*); the packed-value scan never approximates it.
+        m->raw_bytes = batch_face && p->pre < NTK_PRE_NORMALIZE;
         m->canon = true; m->tie_rc = true; break;
     case NTK_PATH_BITS: m->canon = false; m->tie_rc = false; break;
     case NTK_PATH_BITS_CANONICAL: m->canon = true; m->tie_rc = false; break;
@@ -259,6 +259,32 @@ int get_event(ntk_ctx *c, hipEvent_t *e)
     return NTK_OK;
 }
 
+// CanonicalKmers over raw (un-normalised) bytes into the accumulators: canonical_bytes_reduce_kernel + fold (ntk_kernels.hpp).
+int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, bool zero_first)
+{
+    if (zero_first) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile;
+    const uint64_t max_blocks = c->launch_blocks > 0 ? (uint64_t)c->launch_blocks : (uint64_t)c->n_cu * 8;
+    const int blocks = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
+    int rc = ensure_partials(c, blocks);
+    if (rc) return rc;
+    const uint32_t pb = p->k < 6 ? p->k : 6;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        rc = get_event(c, &e0); if (rc) return rc;
+        rc = get_event(c, &e1); if (rc) { c->ev_free.push_back(e0); return rc; }
+        HIPCHK(hipEventRecord(e0, c->stream));
+    }
+    hipLaunchKernelGGL(canonical_bytes_reduce_kernel, dim3(blocks), dim3(kPlThreads), 0, c->stream, d_seq, n, (n + 15) & ~(uint64_t)15, p->k,
+                       2u * (p->k - pb), (const uint16_t *)(c->d_lut + 768), c->d_part_hist, c->d_part_scalars);
+    HIPCHK(hipGetLastError());
+    if (c->timing) { HIPCHK(hipEventRecord(e1, c->stream)); c->ev_used.emplace_back(e0, e1); }
+    hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
+                       (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, (uint32_t *)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    return NTK_OK;
+}
+
 // One scan over d_seq[0, n): launches cover at most kMaxTilesPerLaunch tiles each so that per-block u32
 // histogram cells and 32-bit buffer offsets cannot overflow.
 int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
@@ -271,6 +297,12 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     }
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
+    if (m.raw_bytes) {
+        // byte path on input that was not normalised: reduce mode has its raw-byte kernel; dense values, quality masking and windowed
+        // minimizers on such input are not built (normalize first, as the reference's documented chain does)
+        if (!reduce || cutoff || fused_min_fn) return NTK_ERR_UNSUPPORTED;
+        return run_raw_bytes_reduce(c, d_seq, n, p, zero_first);
+    }
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
     const void *fn = fused_min_fn ? fused_min_fn
                    : cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
@@ -1553,6 +1585,7 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     int rc = resolve_mode(p, true, &m);
     if (rc) return rc;
     if (!m.canon) return NTK_ERR_BAD_ARG;
+    if (m.raw_bytes) return NTK_ERR_UNSUPPORTED;   // windowed minimizers are defined on normalised input (values, not raw bytes)
     HIPCHK(hipSetDevice(c->device));
     // fused build (one pass, nothing written to HBM) where one exists - with a quality stream: the quality-masked builds
     if (n) {

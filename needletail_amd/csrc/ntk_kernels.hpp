@@ -1391,6 +1391,78 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_planes_kernel(cons
     }
 }
 
+// CanonicalKmers on bytes the caller did NOT normalise, folded into the accumulators (ntk_reduce_device with NTK_PATH_BYTES_CANONICAL and
+// pre = NONE / STRIP_RETURNS): the reference compares the RAW bytes of the window with the raw bytes of the reverse complement's window
+// (src/kmer.rs:121-128) and lower case sorts above upper case, so on mixed-case input the strand is not the smaller 2-bit value and the
+// packed-value scan cannot serve it.  Records lie back to back with a break byte each (the batch layout: any byte that is not acgtACGT ends a
+// run).  Same staging as the plane kernels; a thread walks the 8 + k - 1 bytes of its 8 starts once with the run length of bases and the
+// rolling 2-bit values of both strands; where a window is emitted the strand is the byte-wise compare (ties -> rc), the value the chosen
+// strand's.  Per-block partials in the layout fold_kernel sums.  k <= 32 (the digests are defined on 2-bit values).
+__global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(const uint8_t *seq, uint64_t n, uint64_t n_readable, uint32_t k, uint32_t bin_shift,
+                                                                            const uint16_t *comp_lut, uint32_t *part_hist, uint64_t *part_scalars)
+{
+    __shared__ __align__(16) uint8_t s_b[kPlTile + 256 + 16];
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint8_t s_comp[256];
+    __shared__ uint64_t s_red[kPlThreads / 64][4];
+    s_comp[threadIdx.x] = (uint8_t)comp_lut[threadIdx.x];
+    for (int i = threadIdx.x; i < kHistBins; i += kPlThreads) s_hist[i] = 0;
+    const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile;
+    const uint32_t need = kPlTile + k - 1;
+    const uint64_t vmask_k = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t top = 2 * k - 2;
+    uint64_t nv = 0, nf = 0, sum = 0, xr = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * kPlTile;
+        __syncthreads();   // the previous tile's readers are done (and s_comp / s_hist are set up)
+        for (uint32_t v = threadIdx.x; v * 16 < need; v += kPlThreads) {
+            const uint64_t p = t0 + (uint64_t)v * 16;
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (p + 16 <= n_readable) x = *reinterpret_cast<const u32x4 *>(seq + p);
+            *reinterpret_cast<u32x4 *>(&s_b[v * 16]) = x;
+        }
+        __syncthreads();
+        const uint32_t s = threadIdx.x * kPlPer;
+        uint32_t run = 0;
+        uint64_t fwd = 0, rc = 0;
+        for (uint32_t i = 0; i < kPlPer + k - 1; i++) {
+            const uint32_t idx = s + i;
+            const uint8_t c = s_b[idx], cu = c & 0xDF;
+            const bool good = t0 + idx < n && (cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T');
+            const uint32_t x = (c >> 1) & 3u, code = x ^ (x >> 1);   // A0 C1 G2 T3, either case
+            run = good ? run + 1u : 0u;
+            fwd = ((fwd << 2) | code) & vmask_k;
+            rc = (rc >> 2) | ((uint64_t)(3u - code) << top);
+            if (i + 1 >= k && run >= k) {
+                const uint32_t a0 = idx + 1 - k;
+                bool is_rc = true;   // equal slices -> rc (src/kmer.rs:124-128)
+                for (uint32_t m = 0; m < k; m++) {
+                    const uint8_t a = s_b[a0 + m], b = s_comp[s_b[a0 + k - 1 - m]];
+                    if (a != b) { is_rc = !(a < b); break; }
+                }
+                const uint64_t v = is_rc ? rc : fwd;
+                nv++; nf += is_rc ? 0u : 1u; sum += v; xr ^= v;
+                atomicAdd(&s_hist[(uint32_t)(v >> bin_shift)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *ph = part_hist + (size_t)blockIdx.x * kHistBins;
+    for (int i = threadIdx.x; i < kHistBins; i += kPlThreads) ph[i] = s_hist[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nv += __shfl_xor(nv, o, 64); nf += __shfl_xor(nf, o, 64); sum += __shfl_xor(sum, o, 64); xr ^= __shfl_xor(xr, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = nv; s_red[threadIdx.x >> 6][1] = nf; s_red[threadIdx.x >> 6][2] = sum; s_red[threadIdx.x >> 6][3] = xr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
+        for (int w = 0; w < kPlThreads / 64; w++) { tv += s_red[w][0]; tf += s_red[w][1]; ts += s_red[w][2]; tx ^= s_red[w][3]; }
+        uint64_t *ps = part_scalars + (size_t)blockIdx.x * 4;
+        ps[0] = tv; ps[1] = tf; ps[2] = ts; ps[3] = tx;
+    }
+}
+
 // BitNuclKmer (reference src/bitkmer.rs:39-109, Sequence::bit_kmers src/sequence.rs:250-252) in the same bit-plane form, for
 // ntk_bit_kmers_batch_planes: per window START "emitted" and "was_rc", plus (optionally) the item's packed value as a dense u64 per window
 // start (0 where nothing is emitted).  Same staging as above; a thread walks the 8 + k - 1 bytes of its 8 starts once with the run length of

@@ -255,10 +255,61 @@ def test_every_kernel_family_with_many_tiles_per_wave(ctx):
         ctx.set_launch(0, 0)
 
 
+def test_reduce_on_bytes_that_were_not_normalised(ctx):
+    """ntk_reduce_device / the pinned-batch face with NTK_PATH_BYTES_CANONICAL and pre = NONE or STRIP_RETURNS: the reference iterator
+    compares RAW bytes (src/kmer.rs:121-128), so on mixed-case input the strand is not the smaller 2-bit value (`acgTT`, k = 3, SURVEY.md
+    A.5).  Against the oracle's literal chain per record (reverse_complement -> CanonicalKmers on the bytes as they are)."""
+    rng = np.random.default_rng(4242)
+    def records(n_rec, lo, hi, p_lower, p_junk):
+        out = []
+        for _ in range(n_rec):
+            n = int(rng.integers(lo, hi))
+            a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+            m = rng.random(n)
+            a[m < p_lower] |= 0x20
+            j = m > 1 - p_junk
+            a[j] = np.frombuffer(b"NnUuRYKM-.*\x00\xff", dtype=np.uint8)[rng.integers(0, 13, int(j.sum()))]
+            out.append(a.tobytes())
+        return out
+    assert [x for x in O.canonical_kmers(b"acgTT", O.reverse_complement(b"acgTT"), 3)] == [(0, b"acg", False), (1, b"Acg", True), (2, b"AAc", True)]
+    sets = [records(300, 0, 400, 0.3, 0.02), records(40, 3000, 9000, 0.5, 0.001), records(200, 1, 80, 0.1, 0.1), [b"acgTT", b"", b"A", b"ACGT" * 50, b"acgt" * 50]]
+    try:
+        for si, recs in enumerate(sets):
+            buf = b"\n".join(recs) + b"\n"
+            t = to_dev(buf)
+            for k in (1, 3, 4, 6, 7, 11, 16, 17, 21, 31, 32):
+                for pre in (nt.PRE_NONE, nt.PRE_STRIP_RETURNS):
+                    want = O.reduce_records(recs, k, nt.PATH_BYTES_CANONICAL, pre)
+                    for launch in ((0, 0), (3, 0)):
+                        ctx.set_launch(*launch)
+                        ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, pre)
+                        assert_stats_equal(ctx.accum_read(), want, ("raw bytes", si, k, pre, launch))
+        ctx.set_launch(0, 0)
+        # where every base has one case the packed-value scan and the raw-byte kernel must agree
+        up = b"\n".join(r.upper() for r in sets[0]) + b"\n"
+        a = gpu_reduce(ctx, up, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+        b = gpu_reduce(ctx, up, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+        nou = O.reduce_records([r.upper() for r in sets[0]], 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+        assert_stats_equal(a, nou, "upper case, raw kernel")
+        if b"U" not in up:
+            assert_stats_equal(b, nou, "upper case, packed-value scan")
+        # the pinned-batch face with the reset flag
+        st = _run_records(ctx, sets[0], 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+        assert_stats_equal(st, O.reduce_records(sets[0], 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE), "batch face")
+    finally:
+        ctx.set_launch(0, 0)
+
+
 def test_unsupported_and_bad_args_are_errors(ctx):
     t = to_dev(b"ACGT" * 100)
+    # un-normalised byte-path input: reduce mode has its raw-byte kernel (test_reduce_on_bytes_that_were_not_normalised); dense values and
+    # windowed minimizers on such input are not built and say so
     with pytest.raises(nt.NtkError) as e:
-        ctx.reduce_device(t, 400, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+        ctx.reduce_device(t, 400, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, w=11)
+    assert e.value.status == 6
+    vals = torch.zeros(512, dtype=torch.int64, device="cuda"); v16 = torch.zeros(64, dtype=torch.int16, device="cuda"); r16 = torch.zeros_like(v16)
+    with pytest.raises(nt.NtkError) as e:
+        ctx.materialize_device(t, 400, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, vals, v16, r16)
     assert e.value.status == 6
     for k in (0, 33):
         with pytest.raises(nt.NtkError) as e:
