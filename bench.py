@@ -610,7 +610,7 @@ def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
-            st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=4 << 20, w=w, streaming_fallback=False)
+            st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
             dt = time.perf_counter() - t0
             if not (stats_equal(st, want) and st["n_records"] == reads):
                 raise SystemExit("secondary: config 5 (gzip + minimizers) differs from the resident minimizer run")
@@ -657,7 +657,7 @@ def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
         bbest = None
         for _ in range(2):
             t0 = time.perf_counter()
-            st = nt.scan_file_parallel(ctx, bpath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=4 << 20, w=w, streaming_fallback=False)
+            st = nt.scan_file_parallel(ctx, bpath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
             dt = time.perf_counter() - t0
             if not (stats_equal(st, want) and st["n_records"] == reads):
                 raise SystemExit("secondary: config 5 (block gzip + minimizers) differs from the resident minimizer run")

@@ -136,7 +136,9 @@ def main():
             print("before:", tag, "what", int(what))
         if skip:
             # the draws of the branch this iteration took, without its device work
-            if what < 5 or (what < 6 and n <= 400000):
+            if what < 5:
+                if path == nt.PATH_BYTES_CANONICAL: rng.random()
+            elif what < 6 and n <= 400000:
                 pass
             elif what < 8 and canon and (path, pre) in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE)):
                 if rng.random() < 0.4:
@@ -170,6 +172,13 @@ def main():
                             rng.integers(0, 2)
             continue
         if what < 5:
+            if path == nt.PATH_BYTES_CANONICAL and rng.random() < 0.3:
+                # the byte path on input that is NOT normalised: raw-byte strand compare (mixed case), against the literal chain per record
+                ctx.accum_reset(); ctx.reduce_device(t, n, k, path, nt.PRE_NONE)
+                if not stats_equal(ctx.accum_read(), O.reduce_records(buf.split(b"\n"), k, path, nt.PRE_NONE)):
+                    print("MISMATCH raw-byte reduce", tag); return 1
+                counts["raw_bytes"] = counts.get("raw_bytes", 0) + 1
+                continue
             ctx.accum_reset(); ctx.reduce_device(t, n, k, path, pre)
             if not stats_equal(ctx.accum_read(), O.reduce_fused(buf, k, canon, tie, u)):
                 print("MISMATCH reduce", tag); return 1
