@@ -8,19 +8,23 @@
 
 static std::string deflate_gz(const std::string &t, int level, int strategy, size_t flush_every, std::mt19937_64 &rng)
 {
-    std::string z(compressBound(t.size()) + t.size() / (flush_every ? flush_every : t.size() + 1) * 16 + 256, 0);
+    std::string z;
+    char buf[1 << 16];
     z_stream zs{};
     deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, strategy);
-    zs.next_out = (Bytef *)z.data(); zs.avail_out = (uInt)z.size();
     size_t pos = 0;
-    while (pos < t.size()) {
+    do {
         const size_t n = flush_every ? std::min(flush_every, t.size() - pos) : t.size() - pos;
+        const int how = pos + n == t.size() ? Z_FINISH : (rng() & 1 ? Z_FULL_FLUSH : Z_SYNC_FLUSH);
         zs.next_in = (Bytef *)t.data() + pos; zs.avail_in = (uInt)n;
-        deflate(&zs, pos + n == t.size() ? Z_FINISH : (rng() & 1 ? Z_FULL_FLUSH : Z_SYNC_FLUSH));
+        int r;
+        do {   // until this piece is consumed and flushed (an output buffer that fills up is not the end of the piece)
+            zs.next_out = (Bytef *)buf; zs.avail_out = sizeof buf;
+            r = deflate(&zs, how);
+            z.append(buf, sizeof buf - zs.avail_out);
+        } while (zs.avail_out == 0 || (how == Z_FINISH && r != Z_STREAM_END));
         pos += n;
-    }
-    if (t.empty()) deflate(&zs, Z_FINISH);
-    z.resize(z.size() - zs.avail_out);
+    } while (pos < t.size());
     deflateEnd(&zs);
     return z;
 }
@@ -28,6 +32,8 @@ static std::string deflate_gz(const std::string &t, int level, int strategy, siz
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 400;
+    const int only = argc > 2 ? atoi(argv[2]) : -1;          // replay: inflate iteration `only` alone (the generator is consumed as in the full run)
+    const char *dump = argc > 3 ? argv[3] : nullptr;         // ... and write its stream to this file
     std::mt19937_64 rng(20260927);
     uint64_t ok = 0, rejected = 0, survived = 0, bytes = 0;
     for (int it = 0; it < iters; it++) {
@@ -60,6 +66,8 @@ int main(int argc, char **argv)
             if (rng() & 1) z.erase(a, n); else z.insert(a, z.substr(a, n));
         }
         const uint32_t threads = (uint32_t[]){1, 2, 3, 5, 8}[rng() % 5];
+        if (only >= 0 && it != only) continue;
+        if (dump) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(z.data(), 1, z.size(), f); fclose(f); } fprintf(stderr, "it %d: %zu bytes of gzip, %zu of text, mutation %d, %d member(s), %u threads\n", it, z.size(), whole.size(), mut, members, threads); }
         uint8_t *out = nullptr; uint64_t out_n = 0; ntk::PgzStats st;
         const int rc = ntk::pgz_inflate((const uint8_t *)z.data(), z.size(), threads, (uint64_t)64 << 20, &out, &out_n, &st);
         bytes += z.size();
