@@ -41,6 +41,10 @@ def test_asm_blocks_that_write_scc_say_so():
             if SCC_WRITERS.search(body):
                 seen += 1
                 assert '"scc"' in body, f"{os.path.basename(path)}:{line}: inline asm writes SCC without the clobber:\n{stmt[:300]}"
+            # the same for VCC: an instruction string that names vcc (v_cmp ... vcc, v_cndmask ... vcc) needs the "vcc" clobber
+            if re.search(r'"[^"]*\bvcc\b[^"]*\\n', body) or re.search(r'"[^"]*\bvcc\b[^"]*"\s*(?::|\))', body):
+                if re.search(r'"[^"]*\b(v_cmp|s_bcnt1|v_cndmask)\w*[^"]*\bvcc\b', body):
+                    assert '"vcc"' in body, f"{os.path.basename(path)}:{line}: inline asm uses VCC without the clobber:\n{stmt[:300]}"
     assert seen >= 5   # the masked regions of DevMasks2 (canonical, wide, plain, forward-only) and the round-1 regions
 
 
