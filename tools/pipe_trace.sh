@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pipe_trace
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-THREADS=32 READS=10000000 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/t -o p -- python $R/tools/pipeline_sweep.py > $O/out.txt 2> $O/err.txt
+THREADS=24 BATCH_MIB=8 READS=10000000 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/t -o p -- python $R/tools/pipeline_sweep.py > $O/out.txt 2> $O/err.txt
 cd $R
 python3 - <<'PY'
 import csv, glob, os
@@ -29,6 +29,11 @@ for c in big[1:]:
 runs.append(cur)
 for r in runs[-3:]:
     span = (r[-1][1] - r[0][0]) / 1e6; busy = sum(c[1] - c[0] for c in r) / 1e6
+    # two copy streams: copies may overlap - the time at least one is in flight
+    u, end = 0, r[0][0]
+    for a, b, _ in sorted(r):
+        if b > end: u += b - max(a, end); end = b
+    print(f"  at least one copy in flight {u / 1e6:.1f} ms of {span:.1f} ms = {u / 1e6 / span:.2f}; bytes per ms of span: see out.txt")
     gaps = sorted((r[i + 1][0] - r[i][1]) / 1e3 for i in range(len(r) - 1))
     print(f"run of {len(r)} copies: span {span:.1f} ms, busy {busy:.1f} ms, mean copy {busy / len(r) * 1e3:.0f} us, gap p50 {gaps[len(gaps)//2]:.0f} us p90 {gaps[len(gaps)*9//10]:.0f} us max {gaps[-1]:.0f} us")
 PY
