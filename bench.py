@@ -321,9 +321,17 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
         ctx.accum_reset()
         ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
         if not stats_equal(ctx.accum_read(), O.minimizers_reduce(hs, 23, 11, True, True)):
-            raise SystemExit("secondary: generic fused minimizers (k = 23) differ from the oracle on the prefix")
+            raise SystemExit("secondary: fused minimizers (k = 23) differ from the oracle on the prefix")
         ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 23, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)), 6)
-        out["minimizers_w11_k23_generic_resident"] = {"kernel": "minimizer_scan_kernel (k <= 25: one v_min_f64 per minimum on (value, position, strand) keys)",
+        out["minimizers_w11_k23_resident"] = {"kernel": "scan2_kernel<23, ..., W = 11> (register-fused since round 5: windows of 33 bytes, three halo lanes; rounds 4 / 5a: "
+                                                        "the generic kernel, key minimizers_w11_k23_generic_resident)",
+                                              "kernel_ms": round(ms, 4), "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
+        ctx.accum_reset()
+        ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 25, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)
+        if not stats_equal(ctx.accum_read(), O.minimizers_reduce(hs, 25, 11, True, True)):
+            raise SystemExit("secondary: generic fused minimizers (k = 25) differ from the oracle on the prefix")
+        ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 25, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=11)), 6)
+        out["minimizers_w11_k25_generic_resident"] = {"kernel": "minimizer_scan_kernel (k <= 25: one v_min_f64 per minimum on (value, position, strand) keys)",
                                                        "kernel_ms": round(ms, 4), "Gbases_s": round(reads * read_len / (ms * 1e-3) / 1e9, 1)}
     except nt.NtkError as e:  # pragma: no cover
         out["minimizers_w11_k21_resident"] = {"error": str(e)}

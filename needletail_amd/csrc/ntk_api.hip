@@ -288,8 +288,10 @@ int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk
 // One scan over d_seq[0, n): launches cover at most kMaxTilesPerLaunch tiles each so that per-block u32
 // histogram cells and 32-bit buffer offsets cannot overflow.
 int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
-             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16, const uint8_t *d_qual = nullptr, const void *fused_min_fn = nullptr)
+             uint64_t *d_values, uint16_t *d_valid16, uint16_t *d_rc16, const uint8_t *d_qual = nullptr, const void *fused_min_fn = nullptr,
+             int halo_lanes = kHaloLanes)   // 3 for the fused-minimizer builds whose windows need more than 32 bytes (ntk_tile.hpp Sv2Geom)
 {
+    const uint64_t tile_slots = 64 - (uint64_t)halo_lanes, tile_stride = tile_slots * 16;
     bool zero_first = reduce && (p->flags & NTK_FLAG_RESET);   // the first launch zeroes the accumulators in its prologue
     if (n == 0) {
         if (zero_first) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
@@ -348,7 +350,7 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     scan_args_set_k(a, p->k);
     a.seq = d_seq;
     a.n_bytes = n;
-    a.n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
+    a.n_tiles = ((n + 15) / 16 + tile_slots - 1) / tile_slots;
     a.values = d_values; a.valid16 = d_valid16; a.rc16 = d_rc16;
     if (cutoff) { const QualityCut qc = quality_cut(cutoff); a.qual = d_qual; a.q_add = qc.add; a.q_sel = qc.sel; }
     // per launch: a shard holds <= 2^22 tiles so that the per-block u32 histogram cells (a block can at most drain its
@@ -363,7 +365,7 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         const int blocks = (int)(want_blocks < (uint64_t)blocks_max ? want_blocks : (uint64_t)blocks_max);
         a.tile_begin = tb; a.tile_end = te;
         {   // tiles t with (t + 1) * 992 > n_bytes touch the end of the input: t >= n_bytes / 992
-            const uint64_t first_tail = n / kTileStride;
+            const uint64_t first_tail = n / tile_stride;
             a.tail_tile_rel = first_tail < tb ? 0u : (first_tail - tb > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)(first_tail - tb));
         }
         a.n_shards = blocks < kMaxShards ? (uint32_t)blocks : (uint32_t)kMaxShards;
@@ -1592,7 +1594,7 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
         const bool masked = d_qual && quality_cutoff(p);
         const void *fn = (c->route_off & NTK_ROUTE_NO_REGFUSED) ? nullptr : pick_scan_min(m, p->k, w, masked);   // (route bits: ntk_ctx_set_option)
         if (fn)
-            return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, masked ? d_qual : nullptr, fn);
+            return run_scan(c, d_seq, n, p, m, true, nullptr, nullptr, nullptr, masked ? d_qual : nullptr, fn, p->k + w - 1 > 32 ? 3 : 2);
         // every other (k <= 31, w <= 49): the generic fused kernel (one pass as well, run-time k and w)
         if (p->k <= 31 && w <= 49 && !(c->route_off & NTK_ROUTE_NO_GENERIC))
             return run_min_scan(c, d_seq, n, p, m, w, masked ? d_qual : nullptr);

@@ -701,9 +701,12 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
 {
     static_assert(K >= 1 && K <= 32 && (HB == 12 || HB == 14), "sv2 covers 1 <= k <= 32");
     static_assert(W == 0 || Sv2MinFused<K, W>::value, "fused minimizers: see ntk_tile.hpp");
+    static_assert(W == 0 || K <= 16 || Sv2Light<K, HB>::value, "fused minimizers sum the lo word only: the cell must cover the bits above it");
     constexpr bool WORD = K <= 16;                        // one-word values (lane_tile_sv2w): digests kept left-aligned
     constexpr bool LIGHT = Sv2Light<K, HB>::value && !WORD;
     constexpr int kCells = 1 << HB;
+    using Geo = Sv2Geom<(W ? K + W - 1 : K)>;   // halo lanes / stride: 2 / 992 bytes; fused minimizers whose windows need more than 32 bytes: 3 / 976
+    constexpr uint32_t kStride = Geo::kStride, kHaloB = Geo::kHaloBytes;
     // One LDS object, histogram first: the masked regions address the histogram with the cell's byte offset alone, which
     // is only right while the histogram sits at LDS address 0 (checked below; the kernel has no other LDS object).
     struct Lds { uint32_t hist[kCells]; uint64_t red[16 * 6]; };
@@ -744,8 +747,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         if (r1 > shard_end) r1 = shard_end;
         if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
         const uint64_t t0 = a.tile_begin + r0;
-        const uint64_t run_byte = t0 * kTileStride;
-        const uint32_t halo = t0 ? 32u : 0u;
+        const uint64_t run_byte = t0 * kStride;
+        const uint32_t halo = t0 ? kHaloB : 0u;
         const uint64_t cbase = (uint64_t)a.seq + run_byte - halo;
         uint64_t rem = ((a.n_bytes + 15) & ~(uint64_t)15) - (run_byte - halo);
         if (rem > 0xFFFFFF00ull) rem = 0xFFFFFF00ull;
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             const uint32_t qhi = __builtin_amdgcn_readfirstlane((uint32_t)(qbase >> 32));
             rq = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)qhi << 32) | qlo), 0, nrec, 0x00020000);
         }
-        uint32_t voff = lane * 16u - (32u - halo);
+        uint32_t voff = lane * 16u - (kHaloB - halo);
         uint64_t tile_byte = run_byte;
 #ifdef NTK_ABL_FLOOR
         auto load_tile = [&](uint32_t off) { (void)rs; return u32x4{off, off, off, off}; };
@@ -790,14 +793,14 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
             lane_tile_sv2<TIE_RC, K>(sink, xl, mp, fl_code, fl_rcode);
 #else
             const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
-            mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
+            mp.template compute<(W ? K + W - 1 : K)>(en, tail, (int64_t)tile_byte - (int64_t)kHaloB + lane * 16, a.n_bytes);
             after_encode();
             if constexpr (W > 0) lane_tile_sv2_min<TIE_RC, K, W>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (WORD) lane_tile_sv2w<TIE_RC, K, FWD>(sink, xl, mp, en.code, en.rcode);
             else if constexpr (FWD) lane_tile_sv2_fwd<K>(sink, xl, mp, en.code);
             else lane_tile_sv2<TIE_RC, K>(sink, xl, mp, en.code, en.rcode);
 #endif
-            voff += kTileStride; tile_byte += kTileStride;
+            voff += kStride; tile_byte += kStride;
 #ifdef NTK_V_CLOCKS
             dbg_tiles++;
 #endif
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         // profiles/r04b).
         for (uint32_t r = r0; r < r1; r++)
             process(ta, qa, r, [&] {
-                if (r + 1 < r1) { ta = load_tile(voff + kTileStride); if constexpr (QM) qa = load_qual(voff + kTileStride); }
+                if (r + 1 < r1) { ta = load_tile(voff + kStride); if constexpr (QM) qa = load_qual(voff + kStride); }
             });
         next = __builtin_amdgcn_readfirstlane(next);
     }

@@ -975,12 +975,17 @@ NTK_HD void window_masks1_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_
     }
 }
 
-// OK[j] = A[j] & B[j] for any window length 1 .. 32
-template <int KM>
-NTK_HD void window_masks_ab_any(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
-{
-    if constexpr (KM >= 17) window_masks_ab<KM>(G, A, B); else window_masks1_ab<KM>(G, A, B);
-}
+// Tile geometry of the sv2 kernels as a function of the bytes a window needs (KM = K, or K + W - 1 for the fused minimizers): up to 32 bytes
+// reach at most into the lane before the previous one - lanes 0 / 1 are halo, a tile advances by 62 lanes; 33 .. 48 bytes (fused minimizers
+// such as (23, 11)) reach one lane further: three halo lanes, 61 emitting ones.
+template <int KM> struct Sv2Geom {
+    static_assert(KM >= 1 && KM <= 48, "window of at most 48 bytes");
+    static constexpr int kHalo = KM <= 32 ? 2 : 3;
+    static constexpr int kSlots = 64 - kHalo;
+    static constexpr int kStride = kSlots * 16;
+    static constexpr int kHaloBytes = kHalo * 16;
+    static constexpr uint64_t kKeep = ~((1ull << kHalo) - 1ull);   // lanes that emit
+};
 
 // The same for a window length known only at RUN TIME, any L >= 1 (written for the generic fused minimizer kernel, L = k + w - 1 <= 79; that
 // kernel does not use it - see minimizer_invalid16 - and it stays as the tested run-time form of the algebra).  L >= 17: with
@@ -1005,6 +1010,14 @@ NTK_HD void window_masks_span(const uint64_t (&G)[16], uint64_t (&A)[16], uint64
     A[0] = G[0] & keep;
 #pragma unroll
     for (int j = 1; j < 16; j++) A[j] = A[j - 1] & G[j];
+}
+// OK[j] = A[j] & B[j] for any compile-time window length 1 .. 48 (Sv2Geom<KM> says which lanes are halo)
+template <int KM>
+NTK_HD void window_masks_ab_any(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
+{
+    if constexpr (KM > 32) window_masks_span<(KM - 2) & 15>(G, A, B, (uint32_t)((KM - 2) >> 4), Sv2Geom<KM>::kKeep);
+    else if constexpr (KM >= 17) window_masks_ab<KM>(G, A, B);
+    else window_masks1_ab<KM>(G, A, B);
 }
 NTK_HD void window_masks_runtime(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16], uint32_t L, uint64_t keep)
 {
@@ -1245,13 +1258,13 @@ NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 // The digests follow the LIGHT scheme of lane_tile_sv2 (K <= 22): lo word per position, high parts from the histogram.
 // ---------------------------------------------------------------------------------------------
 template <int K, int W> struct Sv2MinFused {
-    static constexpr bool value = K >= 15 && K <= 22 && W >= 9 && W <= 16 && K + W - 1 <= 32;   // (W <= 16: a window reaches one lane back)
+    static constexpr bool value = K >= 15 && K <= 23 && W >= 9 && W <= 16 && K + W - 1 <= 48;   // (W <= 16: the keys of a window reach one lane back; K + W - 1 > 32: three halo lanes, Sv2Geom)
 };
 
 template <bool TIE_RC, int K, int W, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
 {
-    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 22, 9 <= W <= 16, K + W - 1 <= 32");
+    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 23, 9 <= W <= 16, K + W - 1 <= 48");
     constexpr int D = K > 16 ? K - 16 : 0;
     constexpr int HS = K > 16 ? 58 - 2 * K : 26;           // key hi word = T >> HS (| bit 30); K <= 16: the value is one word, T = value
     constexpr uint32_t kBit62 = 1u << (HS - 2);            // alignbit(kBit62, T, HS) == (T >> HS) | 0x40000000

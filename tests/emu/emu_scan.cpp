@@ -297,15 +297,16 @@ struct EmuNoSink {};
 template <bool TIE_RC, bool ACCEPT_U, int K, int HB, int W = 0, bool FWD = false>
 void run_sv2(const uint8_t *buf, uint64_t n, uint64_t n_padded, HostStats *st)
 {
-    const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
+    using Geo = Sv2Geom<(W ? K + W - 1 : K)>;   // the kernel's tile geometry: 2 halo lanes, or 3 where a window needs more than 32 bytes
+    const uint64_t n_tiles = ((n + 15) / 16 + Geo::kSlots - 1) / Geo::kSlots;
     EmuMP2<K, HB> mp;
     EmuNoSink sink;
     for (uint64_t t = 0; t < n_tiles; t++) {
-        const bool tail = (t + 1) * kTileStride > n;
+        const bool tail = (t + 1) * Geo::kStride > n;
         EncSV2 en[64];
         uint64_t G[16] = {0};
         for (int l = 0; l < 64; l++) {
-            const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
+            const int64_t lane_base = (int64_t)(t * Geo::kStride) - Geo::kHaloBytes + l * 16;
             en[l] = encode16_sv2<ACCEPT_U>(load16q(buf, n_padded, lane_base));
             for (int i = 0; i < 16; i++) {
                 bool good = !sv2_base_is_break(en[l], i);
@@ -465,6 +466,7 @@ int emu_minimizers(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k
     EMU_MIN4(17, 11) EMU_MIN4(18, 11) EMU_MIN4(19, 11) EMU_MIN4(20, 11) EMU_MIN4(21, 11) EMU_MIN4(22, 11)
     EMU_MIN4(21, 9) EMU_MIN4(21, 10) EMU_MIN4(21, 12) EMU_MIN4(17, 16) EMU_MIN4(19, 14)
     EMU_MIN4(15, 10) EMU_MIN4(15, 9) EMU_MIN4(16, 12) EMU_MIN4(16, 16) EMU_MIN4(15, 16) EMU_MIN4(19, 10) EMU_MIN4(22, 9) EMU_MIN4(20, 13)
+    EMU_MIN4(23, 9) EMU_MIN4(23, 10) EMU_MIN4(23, 11) EMU_MIN4(23, 12) EMU_MIN4(22, 12) EMU_MIN4(21, 16) EMU_MIN4(23, 16)   // k = 23; windows of 33 .. 38 bytes: three halo lanes
     if (done) {
         out[0] = st->n_total; out[1] = st->n_fwd; out[2] = st->sum; out[3] = st->xr;
         memcpy(out + 4, st->hist, sizeof(st->hist));

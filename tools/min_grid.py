@@ -1,4 +1,4 @@
-"""Fused-minimizer grid on the config-2 batch: kernel ms per (k, w) of the fused builds (k = 15..22 x w = 9..12, k + w - 1 <= 32),
+"""Fused-minimizer grid on the config-2 batch: kernel ms per (k, w) of the fused builds (k = 15..23 x w = 9..12),
 a prefix checked against the oracle first; the quality-masked builds of (21, 11) and (15, 10) next to them."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,9 +27,8 @@ def run(k, w, q):
         ctx.reduce_device(seq, n, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=w, reset=True, **kw)
     ms, nl = ctx.scan_time_ms(); ctx.enable_timing(False)
     print(f"k={k:2d} w={w:2d} {'quality-masked ' if q else ''}{ms / 20:.4f} ms per pass ({nl // 20} launch(es))  prefix {'== oracle' if ok else 'DIFFERS FROM THE ORACLE'}", flush=True)
-for k in range(15, 23):
+for k in range(15, 24):
     for w in (9, 10, 11, 12):
-        if k + w - 1 <= 32:
-            run(k, w, False)
+        run(k, w, False)   # (22, 12), (23, 11), (23, 12): windows of 33 / 34 bytes, the builds with three halo lanes (round 5)
 run(21, 11, True); run(15, 10, True)
-run(23, 11, False)   # no register-fused build: the generic fused kernel (round 4; tools/min_generic_bench.py times it against the two-pass path)
+run(24, 11, False)   # no register-fused build: the generic fused kernel (tools/min_generic_bench.py times it against the two-pass path)
