@@ -242,7 +242,7 @@ const void *pick_scan(const Mode &m, uint32_t k)
     }
 }
 
-// Fused windowed-minimizer builds of the sv2 kernel (ntk_tile.hpp lane_tile_sv2_min): k = 15..22 x w = 9..12 with k + w - 1 <= 32,
+// Fused windowed-minimizer builds of the sv2 kernel (ntk_tile.hpp lane_tile_sv2_min): k = 15..23 x w = 5, 9..12 (windows of up to 34 bytes),
 // and quality-masked builds of (21, 11) and (15, 10) (ntk_scan2.hip); every other (k, w) takes the two-pass path (materialise +
 // window-min).
 const void *pick_scan_min(const Mode &m, uint32_t k, uint32_t w, bool quality)

@@ -64,12 +64,12 @@ const void *ntk_pick_scan2_q(int k, bool canonical, bool tie_rc, bool accept_u)
 #else
 // (compiled with -DNTK_SCAN2_MIN_BUILDS=1 / =2 and the DEFAULT scheduler into ntk_scan2_min.o / ntk_scan2_min2.o: the iterative one
 // crashes the register allocator on these builds)
-// Fused windowed-minimizer builds (ntk_tile.hpp lane_tile_sv2_min): every k = 15..23 x w = 9..12 - the sketch
+// Fused windowed-minimizer builds (ntk_tile.hpp lane_tile_sv2_min): every k = 15..23 x w = 5, 9..12 - the sketch
 // parameters in common use ((15, 10), (19, 10), (21, 11): configs[4]) and their neighbours - plus quality-masked builds of
 // (21, 11) and (15, 10); every other (k, w) takes the generic fused kernel (k <= 31, w <= 49) or the two-pass path.
 #define NTK_PICK_MIN(KF, WF, T, U, Q) if (k == KF && w == WF && tie_rc == T && accept_u == U && quality == Q) return (const void *)&scan2_kernel<KF, T, U, Q, kScan2HistBits, WF>;
 #define NTK_PICK_MIN4(KF, WF, Q) NTK_PICK_MIN(KF, WF, false, false, Q) NTK_PICK_MIN(KF, WF, false, true, Q) NTK_PICK_MIN(KF, WF, true, false, Q) NTK_PICK_MIN(KF, WF, true, true, Q)
-#define NTK_PICK_MINW(KF) NTK_PICK_MIN4(KF, 9, false) NTK_PICK_MIN4(KF, 10, false) NTK_PICK_MIN4(KF, 11, false) NTK_PICK_MIN4(KF, 12, false)
+#define NTK_PICK_MINW(KF) NTK_PICK_MIN4(KF, 5, false) NTK_PICK_MIN4(KF, 9, false) NTK_PICK_MIN4(KF, 10, false) NTK_PICK_MIN4(KF, 11, false) NTK_PICK_MIN4(KF, 12, false)
 #if NTK_SCAN2_MIN_BUILDS == 1
 const void *ntk_pick_scan2_min_a(int k, int w, bool tie_rc, bool accept_u, bool quality)
 {
@@ -81,8 +81,7 @@ const void *ntk_pick_scan2_min_a(int k, int w, bool tie_rc, bool accept_u, bool 
 const void *ntk_pick_scan2_min_b(int k, int w, bool tie_rc, bool accept_u, bool quality)
 {
     NTK_PICK_MINW(19) NTK_PICK_MINW(20) NTK_PICK_MINW(21)
-    NTK_PICK_MIN4(22, 9, false) NTK_PICK_MIN4(22, 10, false) NTK_PICK_MIN4(22, 11, false)
-    NTK_PICK_MIN4(22, 12, false) NTK_PICK_MINW(23)   // round 5: k = 23, and windows of 33 / 34 bytes ((22, 12), (23, 11), (23, 12): three halo lanes)
+    NTK_PICK_MINW(22) NTK_PICK_MINW(23)   // round 5: k = 23, windows of 33 / 34 bytes ((22, 12), (23, 11), (23, 12): three halo lanes), and w = 5
     NTK_PICK_MIN4(21, 11, true)
     return nullptr;
 }

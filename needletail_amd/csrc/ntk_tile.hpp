@@ -1258,13 +1258,13 @@ NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 // The digests follow the LIGHT scheme of lane_tile_sv2 (K <= 22): lo word per position, high parts from the histogram.
 // ---------------------------------------------------------------------------------------------
 template <int K, int W> struct Sv2MinFused {
-    static constexpr bool value = K >= 15 && K <= 23 && W >= 9 && W <= 16 && K + W - 1 <= 48;   // (W <= 16: the keys of a window reach one lane back; K + W - 1 > 32: three halo lanes, Sv2Geom)
+    static constexpr bool value = K >= 15 && K <= 23 && W >= 2 && W <= 16 && K + W - 1 <= 48;   // (W <= 16: the keys of a window reach one lane back; K + W - 1 > 32: three halo lanes, Sv2Geom)
 };
 
 template <bool TIE_RC, int K, int W, class Sink, class XL, class MP>
 NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rcode)
 {
-    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 23, 9 <= W <= 16, K + W - 1 <= 48");
+    static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 23, 2 <= W <= 16, K + W - 1 <= 48");
     constexpr int D = K > 16 ? K - 16 : 0;
     constexpr int HS = K > 16 ? 58 - 2 * K : 26;           // key hi word = T >> HS (| bit 30); K <= 16: the value is one word, T = value
     constexpr uint32_t kBit62 = 1u << (HS - 2);            // alignbit(kBit62, T, HS) == (T >> HS) | 0x40000000
@@ -1311,6 +1311,30 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
             key[j] = mp.min64(kf, kr);
         }
     }
+    uint64_t win[16];
+    if constexpr (W <= 8) {
+        // short windows (the w = 5 of several sketching presets): the W - 1 keys before own position 0 are the previous lane's last ones (index
+        // - 16: older than every own key), then a sliding minimum by doubling over the 16 + W - 1 keys: M_2q[i] = min(M_q[i], M_q[i + q]) while
+        // 2q <= W, and two overlapping windows of q make W (3 - 3.5 minima per position; the prefix / suffix scheme below needs 2W - 3 >= 15)
+        constexpr int E = W - 1, N = 16 + E;
+        uint64_t M[N];
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const int a = 16 - E + i;
+            const uint32_t lo = xl.prev_add(kSlotSufLo + a, (uint32_t)key[a], 0u - 32u);
+            const uint32_t hi = xl.prev(kSlotSufHi + a, (uint32_t)(key[a] >> 32));
+            M[i] = ((uint64_t)hi << 32) | lo;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) M[E + j] = key[j];
+        constexpr int Q = W >= 8 ? 8 : (W >= 4 ? 4 : (W >= 2 ? 2 : 1));   // the largest power of two <= W
+#pragma unroll
+        for (int q = 1; q < Q; q *= 2)
+#pragma unroll
+            for (int i = 0; i + q < N; i++) M[i] = mp.min64(M[i], M[i + q]);   // (M[i + q] is still the previous round's: i ascends)
+#pragma unroll
+        for (int j = 0; j < 16; j++) win[j] = W == Q ? M[j] : mp.min64(M[j], M[j + W - Q]);
+    } else {
     // suffix minima of the own keys, handed to the next lane; the previous lane's arrive with 16 taken off their index
     constexpr int A0 = 17 - W;                             // the previous lane's positions A0 .. 15 can be in a window of ours
     uint64_t suf[16], imp[16];
@@ -1323,7 +1347,6 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
         const uint32_t hi = xl.prev(kSlotSufHi + a, (uint32_t)(suf[a] >> 32));
         imp[a] = ((uint64_t)hi << 32) | lo;
     }
-    uint64_t win[16];
     // windows reaching into the previous lane: j = 0 .. W-2
     uint64_t pre = key[0];
 #pragma unroll
@@ -1341,6 +1364,7 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
     for (int j = W - 1; j < 16; j++) {
         if (j > W - 1) pfx = mp.min64(pfx, key[j]);
         win[j] = j - W + 1 <= W - 2 ? mp.min64(sfx[j - W + 1], pfx) : pfx;
+    }
     }
 #pragma unroll
     for (int jb = 0; jb < 16; jb += 4) {

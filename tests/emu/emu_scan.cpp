@@ -466,6 +466,7 @@ int emu_minimizers(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k
     EMU_MIN4(17, 11) EMU_MIN4(18, 11) EMU_MIN4(19, 11) EMU_MIN4(20, 11) EMU_MIN4(21, 11) EMU_MIN4(22, 11)
     EMU_MIN4(21, 9) EMU_MIN4(21, 10) EMU_MIN4(21, 12) EMU_MIN4(17, 16) EMU_MIN4(19, 14)
     EMU_MIN4(15, 10) EMU_MIN4(15, 9) EMU_MIN4(16, 12) EMU_MIN4(16, 16) EMU_MIN4(15, 16) EMU_MIN4(19, 10) EMU_MIN4(22, 9) EMU_MIN4(20, 13)
+    EMU_MIN4(15, 5) EMU_MIN4(19, 5) EMU_MIN4(21, 5) EMU_MIN4(23, 5) EMU_MIN4(16, 2) EMU_MIN4(17, 3) EMU_MIN4(18, 4) EMU_MIN4(20, 6) EMU_MIN4(22, 7) EMU_MIN4(19, 8)   // short windows: doubling
     EMU_MIN4(23, 9) EMU_MIN4(23, 10) EMU_MIN4(23, 11) EMU_MIN4(23, 12) EMU_MIN4(22, 12) EMU_MIN4(21, 16) EMU_MIN4(23, 16)   // k = 23; windows of 33 .. 38 bytes: three halo lanes
     if (done) {
         out[0] = st->n_total; out[1] = st->n_fwd; out[2] = st->sum; out[3] = st->xr;

@@ -233,7 +233,7 @@ def test_every_kernel_family_with_many_tiles_per_wave(ctx):
     tq = _qual_dev(qual)
     masked = O.quality_mask(buf, qual, 40)
     kmers = [(k, mode) for k in (3, 6, 7, 11, 15, 16, 17, 21, 23, 24, 31, 32) for mode in range(3)]
-    mins = [(21, 11, 0), (15, 10, 0), (19, 12, 1), (23, 11, 0), (23, 12, 1), (22, 12, 0), (24, 11, 0), (25, 33, 1), (31, 19, 0), (27, 11, 1), (12, 5, 0), (21, 19, 1)]
+    mins = [(21, 11, 0), (15, 10, 0), (19, 12, 1), (23, 11, 0), (23, 12, 1), (22, 12, 0), (15, 5, 0), (19, 5, 1), (24, 11, 0), (25, 33, 1), (31, 19, 0), (27, 11, 1), (12, 5, 0), (21, 19, 1)]
     try:
         for launch in ((7, 0), (2, 512), (0, 0)):
             ctx.set_launch(*launch)
@@ -1290,8 +1290,9 @@ def test_fused_minimizers_match_the_oracle_and_the_two_pass_path(ctx, restore_op
     buf = bytes(alphabet[rng.integers(0, len(alphabet), 60_000)]) + h + O.reverse_complement(h) + b"A" * 90 + b"T" * 90 + \
         O.synth_reads(0x5EED0002, 9, 3000, 150, 8).tobytes()
     t = to_dev(buf)
-    # (22, 12), (23, 11), (23, 12): windows of 33 / 34 bytes - the fused builds with three halo lanes; (24, 11), (21, 5): the generic kernel
-    for k, w in ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12), (23, 9), (23, 10), (23, 11), (23, 12), (22, 12), (24, 11), (21, 5)):
+    # (22, 12), (23, 11), (23, 12): windows of 33 / 34 bytes - the fused builds with three halo lanes; w = 5: the short-window fused builds;
+    # (24, 11), (21, 6): the generic kernel
+    for k, w in ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12), (23, 9), (23, 10), (23, 11), (23, 12), (22, 12), (24, 11), (21, 5), (15, 5), (19, 5), (23, 5), (21, 6)):
         for path, pre, tie, u in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, True, True), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE, False, False)):
             want = O.minimizers_reduce(buf, k, w, accept_u=u, tie_rc=tie)
             ctx.accum_reset(); ctx.reduce_device(t, len(buf), k, path, pre, w=w)

@@ -295,6 +295,7 @@ def emu_minimizers(L, buf: bytes, k, w, tie_rc, accept_u, hb14):
 # (k <= 16: the value is one word and the key is built from it; the product ships k = 15..22 x w = 9..12 with k + w - 1 <= 32)
 FUSED_KW = ((21, 11), (17, 11), (18, 11), (19, 11), (20, 11), (22, 11), (21, 9), (21, 10), (21, 12),
             (15, 10), (15, 9), (16, 12), (16, 16), (15, 16), (19, 10), (22, 9), (20, 13),
+            (15, 5), (19, 5), (21, 5), (23, 5), (16, 2), (17, 3), (18, 4), (20, 6), (22, 7), (19, 8),   # short windows (w <= 8): the doubling path
             (23, 9), (23, 10), (23, 11), (23, 12), (22, 12), (21, 16), (23, 16))   # k = 23; windows of 33 .. 38 bytes: three halo lanes (Sv2Geom)
 
 

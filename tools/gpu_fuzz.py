@@ -142,7 +142,7 @@ def main():
                 pass
             elif what < 8 and canon and (path, pre) in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE)):
                 if rng.random() < 0.4:
-                    if rng.random() < 0.5: rng.choice([1, 2, 9, 10, 11, 12, 16, 33])
+                    if rng.random() < 0.5: rng.choice([1, 2, 5, 9, 10, 11, 12, 16, 33])
                     if not rng.random() < 0.5: rng.choice([15, 16, 17, 18, 19, 20, 21, 22, 23])
                 else:
                     if rng.random() < 0.8: rng.integers(1, 52)
@@ -203,7 +203,7 @@ def main():
         elif what < 8 and canon and (path, pre) in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE)):
             u4 = rng.random()
             if u4 < 0.4:     # the register-fused grid and its edges
-                w = int(rng.choice([1, 2, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
+                w = int(rng.choice([1, 2, 5, 9, 10, 11, 12, 16, 33])) if rng.random() < 0.5 else 11
                 kk = k if rng.random() < 0.5 else int(rng.choice([15, 16, 17, 18, 19, 20, 21, 22, 23]))
             else:            # anything: the generic fused kernel (k <= 31, w <= 49), the two-pass path beyond it
                 w = int(rng.integers(1, 52)) if rng.random() < 0.8 else int(rng.choice([15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 64]))

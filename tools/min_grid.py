@@ -28,7 +28,7 @@ def run(k, w, q):
     ms, nl = ctx.scan_time_ms(); ctx.enable_timing(False)
     print(f"k={k:2d} w={w:2d} {'quality-masked ' if q else ''}{ms / 20:.4f} ms per pass ({nl // 20} launch(es))  prefix {'== oracle' if ok else 'DIFFERS FROM THE ORACLE'}", flush=True)
 for k in range(15, 24):
-    for w in (9, 10, 11, 12):
+    for w in (5, 9, 10, 11, 12):
         run(k, w, False)   # (22, 12), (23, 11), (23, 12): windows of 33 / 34 bytes, the builds with three halo lanes (round 5)
 run(21, 11, True); run(15, 10, True)
 run(24, 11, False)   # no register-fused build: the generic fused kernel (tools/min_generic_bench.py times it against the two-pass path)
