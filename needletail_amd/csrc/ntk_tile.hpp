@@ -1267,7 +1267,14 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
     static_assert(Sv2MinFused<K, W>::value, "fused minimizers: 15 <= K <= 23, 2 <= W <= 16, K + W - 1 <= 48");
     constexpr int D = K > 16 ? K - 16 : 0;
     constexpr int HS = K > 16 ? 58 - 2 * K : 26;           // key hi word = T >> HS (| bit 30); K <= 16: the value is one word, T = value
+    // The key's high word = T >> HS: fewer than 2^20, so the key's exponent field is zero and the key is a DENORMAL double - which v_min_f64
+    // orders like any other positive double (f64 denormals are never flushed in the mode HIP kernels run in), so no marker bit has to make it a
+    // normal one: a full-rate shift instead of the funnel shift that merged the marker in (32 of them per tile; NTK_MINKEY_MARKER=1 restores it).
+#ifndef NTK_MINKEY_MARKER
+#define NTK_MINKEY_MARKER 0
+#endif
     constexpr uint32_t kBit62 = 1u << (HS - 2);            // alignbit(kBit62, T, HS) == (T >> HS) | 0x40000000
+    auto key_hi = [](uint32_t t) -> uint32_t { return NTK_MINKEY_MARKER ? alignbit(kBit62, t, HS) : (t >> HS); };
     constexpr uint32_t fbitF = TIE_RC ? 1u : 0u, fbitR = TIE_RC ? 0u : 1u;
     uint32_t fw[16 + D + 1], rw[16 + D + 1];   // index g + D  (+ 1: never a zero-length array)
     const uint32_t c1 = xl.prev(kSlotCode, code), r1 = xl.prev(kSlotRcode, rcode);
@@ -1295,8 +1302,8 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
         if constexpr (K > 16) {
             const uint32_t lf = j <= 12 ? and_or(fw[D + (j <= 12 ? j + 3 : j)], kTagMask, idx2 | fbitF) : ((fw[D + j] << 6) | (idx2 | fbitF));
             const uint32_t lr = j >= 3 ? and_or(rw[j >= 3 ? j - 3 : j], kTagMask, idx2 | fbitR) : ((rw[j] << 6) | (idx2 | fbitR));
-            const uint64_t kf = ((uint64_t)alignbit(kBit62, fw[j], HS) << 32) | lf;
-            const uint64_t kr = ((uint64_t)alignbit(kBit62, rw[D + j], HS) << 32) | lr;
+            const uint64_t kf = ((uint64_t)key_hi(fw[j]) << 32) | lf;
+            const uint64_t kr = ((uint64_t)key_hi(rw[D + j]) << 32) | lr;
             key[j] = mp.min64(kf, kr);
         } else {
             // K <= 16 (the common (15, 10) sketch): the value is the low 2K bits of the forward word ending at base j / the top 2K
@@ -1306,8 +1313,8 @@ NTK_HD void lane_tile_sv2_min(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_
             const uint32_t vf = K == 16 ? fw[j] : (fw[j] & vmask), vr = K == 16 ? rw[j] : (rw[j] >> ((32 - 2 * K) & 31));
             const uint32_t lf = j <= 12 ? and_or(fw[j <= 12 ? j + 3 : j], vmask << 6, idx2 | fbitF) : ((vf << 6) | (idx2 | fbitF));
             const uint32_t lr = j >= G ? and_or(rw[j >= G ? j - G : j], kTagMask, idx2 | fbitR) : ((vr << 6) | (idx2 | fbitR));
-            const uint64_t kf = ((uint64_t)alignbit(kBit62, vf, HS) << 32) | lf;
-            const uint64_t kr = ((uint64_t)alignbit(kBit62, vr, HS) << 32) | lr;
+            const uint64_t kf = ((uint64_t)key_hi(vf) << 32) | lf;
+            const uint64_t kr = ((uint64_t)key_hi(vr) << 32) | lr;
             key[j] = mp.min64(kf, kr);
         }
     }
