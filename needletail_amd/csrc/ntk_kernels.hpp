@@ -411,7 +411,7 @@ struct DevMasks2 {
 #endif
     }
 
-    // unsigned minimum of two keys that are positive normal doubles (bit 63 clear, bit 62 set): one v_min_f64
+    // unsigned minimum of two keys that are positive doubles (bit 63 clear; not NaN / infinity: the exponent field is never all ones): one v_min_f64
     __device__ __forceinline__ uint64_t min64(uint64_t a, uint64_t b) const
     {
         uint64_t r;

@@ -1246,9 +1246,9 @@ NTK_HD void lane_tile_sv2_fwd(Sink &sink, XL &xl, MP &mp, uint32_t code)
 // src/sequence.rs:139-152, applied to every window of W+K-1 good bases).  The window ending at byte e holds the W k-mers
 // ending at e-W+1 .. e; its minimizer is the smallest of their canonical values, the LEFTMOST one on ties, reported with
 // that k-mer's strand flag.  Nothing is written to HBM: the canonical values live in registers as 64-bit KEYS
-//     key = (value << 6) | (index << 1) | strand bit,   bit 62 set
-// so that one unsigned 64-bit minimum does everything at once - on the device v_min_f64: with bit 62 set and bit 63 clear
-// a key is a positive NORMAL double, and positive doubles order like their bit patterns:
+//     key = (value << 6) | (index << 1) | strand bit      (< 2^52: as a double, positive with a zero exponent field - a denormal)
+// so that one unsigned 64-bit minimum does everything at once - on the device v_min_f64: positive doubles, denormal ones included, order
+// like their bit patterns (rounds 2 - 4 set bit 62 to make the keys normal doubles; not needed, see key_hi below):
 //   * strand choice: min(forward key, reverse-complement key); the strand bit is arranged so that the tie goes where the
 //     reference's iterator sends it (TIE_RC: rc carries 0, reference src/kmer.rs:124-128; else forward carries 0, bitkmer.rs:138-142);
 //   * window minimum with the leftmost tie rule: the index (own position j -> 16 + j; a key imported from the previous
