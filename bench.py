@@ -510,7 +510,7 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     # (profiles/r05c/pipeline_sweep.txt; the parser threads are the bound, the copies hide behind them)
     th = min(24, os.cpu_count() or 1)
     best = None
-    for _ in range(4):
+    for _ in range(6):
         t0 = time.perf_counter()
         st = nt.scan_file_parallel(ctx, None, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=th, batch_bytes=8 << 20, data=text)
         dt = time.perf_counter() - t0
