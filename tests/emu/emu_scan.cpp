@@ -525,6 +525,22 @@ int emu_window_masks(const uint64_t *g16, uint32_t k, uint64_t *ok16, uint64_t *
     return -1;
 }
 
+// window_masks_ab_any<KM> for the windows of 33 .. 48 bytes of the fused-minimizer builds with three halo lanes (Sv2Geom): ab16[j] = A[j] & B[j]
+int emu_window_masks_wide(const uint64_t *g16, uint32_t km, uint64_t *ab16)
+{
+    uint64_t G[16], A[16], B[16];
+    memcpy(G, g16, sizeof(G));
+    switch (km) {
+#define EMU_WMW(KF) case KF: window_masks_ab_any<KF>(G, A, B); break;
+    EMU_WMW(33) EMU_WMW(34) EMU_WMW(35) EMU_WMW(36) EMU_WMW(37) EMU_WMW(38) EMU_WMW(39) EMU_WMW(40)
+    EMU_WMW(41) EMU_WMW(42) EMU_WMW(43) EMU_WMW(44) EMU_WMW(45) EMU_WMW(46) EMU_WMW(47) EMU_WMW(48)
+#undef EMU_WMW
+    default: return -1;
+    }
+    for (int j = 0; j < 16; j++) ab16[j] = A[j] & B[j];
+    return 0;
+}
+
 // window_masks_runtime: the run-time form of the mask algebra (the generic fused minimizer kernel), any window length L = 1 .. 79
 int emu_window_masks_runtime(const uint64_t *g16, uint32_t L, uint32_t halo_lanes, uint64_t *ok16)
 {

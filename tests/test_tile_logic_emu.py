@@ -114,6 +114,20 @@ def test_window_masks_both_forms_against_the_definition(emu):
                         want[j] |= np.uint64(1 << l)
             assert np.array_equal(ok, want), (trial, k, "finished form")
             assert np.array_equal(ab, want), (trial, k, "A & B form")
+        # windows of 33 .. 48 bytes (fused minimizers such as (23, 11)): three halo lanes, the span form of the algebra at compile time
+        emu.emu_window_masks_wide.restype = C.c_int
+        emu.emu_window_masks_wide.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        if trial < 24:
+            for km in range(33, 49):
+                ab = np.zeros(16, dtype=np.uint64)
+                assert emu.emu_window_masks_wide(G.ctypes.data, km, ab.ctypes.data) == 0
+                want = np.zeros(16, dtype=np.uint64)
+                for l in range(3, 64):
+                    for j in range(16):
+                        e = l * 16 + j
+                        if e - km + 1 >= 0 and flat[e - km + 1: e + 1].all():
+                            want[j] |= np.uint64(1 << l)
+                assert np.array_equal(ab, want), (trial, km, "three halo lanes")
 
 
 @pytest.mark.parametrize("k", list(range(1, 33)))
