@@ -42,5 +42,11 @@ int main() {
     printf("minimizer_batch");
     for (size_t i = 0; i < mins.size(); i++) printf(" %.*s:%llu:%d", (int)mins[i].size(), (const char *)mins[i].data(), (unsigned long long)mpos[i], (int)mrc[i]);
     printf("\n");
+    // Sequence::bit_kmers(k, canonical) for the same three records as planes + dense values (BitKmersPlanes), walked per record
+    BitKmersPlanes bp(buf, offs, 3, true);
+    printf("bit_planes %llu", (unsigned long long)bp.total());
+    for (size_t i = 0; i < 3; i++)
+        bp.for_each(i, [&](size_t pos, uint64_t value, uint8_t k, bool was_rc) { printf(" %zu:%zu:%llu:%d:%d", i, pos, (unsigned long long)value, (int)k, (int)was_rc); });
+    printf("\n");
     return 0;
 }

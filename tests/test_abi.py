@@ -147,6 +147,13 @@ def test_cpp_mirror_quality_and_minimizers_on_gpu():
         assert best[0] == O.minimizer(rec, 3)
         exp.append(f"{best[0].decode()}:{best[1]}:{best[2]}")
     assert got == exp and got[0].startswith("AAA:")
+    # BitKmersPlanes: Sequence::bit_kmers(3, true) for the three records, every item as the reference iterator yields it
+    at += 4
+    wantb = []
+    for i, rec in enumerate(recs):
+        wantb += [f"{i}:{p}:{v}:{k}:{int(f)}" for p, (v, k), f in O.bit_kmers(rec, 3, True)]
+    assert lines[at] == "bit_planes" and int(lines[at + 1]) == len(wantb)
+    assert lines[at + 2: at + 2 + len(wantb)] == wantb
 
 
 def _c_smoke():
