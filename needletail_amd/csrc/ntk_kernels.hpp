@@ -19,8 +19,9 @@
 // the per-wave clock census (NTK_V_CLOCKS) exist for tools/kbench.hip alone, which is built with -DNTK_KBENCH: they produce WRONG results
 // by design and measure what a class of the tile loop costs (profiles/r03c/ablation.txt, r04i/ablation.txt).  No product object may see one.
 #if !defined(NTK_KBENCH) && (defined(NTK_ABL_LOADSONLY) || defined(NTK_ABL_FLOOR) || defined(NTK_ABL_NOLDS) || defined(NTK_ABL_NODIGEST) || \
-                             defined(NTK_ABL_NOEXEC) || defined(NTK_ABL_NOSDWA) || defined(NTK_ABL_NOMASKALG) || defined(NTK_V_CLOCKS))
-#error "NTK_ABL_* / NTK_V_CLOCKS are kernel-bench switches: build with -DNTK_KBENCH (tools/build_kbench.sh), never into the library"
+                             defined(NTK_ABL_NOEXEC) || defined(NTK_ABL_NOSDWA) || defined(NTK_ABL_NOMASKALG) || defined(NTK_V_CLOCKS) || \
+                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_ABL_HALFIMPORTS))
+#error "NTK_ABL_* / NTK_X_* / NTK_V_CLOCKS are kernel-bench switches: build with -DNTK_KBENCH (tools/build_kbench.sh), never into the library"
 #endif
 
 namespace ntk {
@@ -378,6 +379,10 @@ struct DevMasks2 {
     uint32_t one = 1;
     uint32_t nf_s = 0;            // forward-strand count of the WAVE (scalar: s_bcnt1 of the compare mask, no LDS op, no VALU op)
     uint32_t nf_bits = 0;         // fused minimizers: per-lane sum of the chosen keys' strand bits
+#ifdef NTK_X_MFMASUM
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 macc = {0, 0, 0, 0}, msel = {0, 0, 0, 0};   // kbench experiment: byte sums on the matrix pipe (see emit_canon)
+#endif
 
     template <int KM, class Enc>   // KM: good bases a window needs (K, or K + W - 1 for windowed minimizers)
     __device__ __forceinline__ void compute(const Enc &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
@@ -501,8 +506,62 @@ struct DevMasks2 {
           [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)                                                                             \
         : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one)                                                            \
         : "memory", "vcc", "scc"
+#if defined(NTK_X_CMPFIRST)
+        // round-6 experiment (a), profiles/r06a: the four strand compares leave the region - under the full exec mask, each into its own
+        // SGPR pair, scheduled by the compiler among the window words - and the region keeps exec, select, digests, atomic, count
+        uint64_t F[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) F[i] = __builtin_amdgcn_ballot_w64(TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i]);
+#define NTK_X_POS(i, CNT)                                                   \
+        NTK_R_EXEC(i)                                                       \
+        "s_and_b64 vcc, exec, %[F" #i "]\n"                                 \
+        "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n"          \
+        NTK_R_SUM_##i("%[t" #i "]")                                         \
+        NTK_R_XOR("%[t" #i "]")                                             \
+        NTK_R_HIST(i)                                                       \
+        CNT
+#define NTK_X_IN(i) [o##i] "v"(off[i]), [fl##i] "v"(fl[i]), [rl##i] "v"(rl[i]), [F##i] "s"(F[i]), NTK_R_MASKS(i)
+        asm volatile(NTK_X_POS(0, NTK_R_CNT_FIRST) NTK_X_POS(1, NTK_R_CNT) NTK_X_POS(2, NTK_R_CNT) NTK_X_POS(3, NTK_R_CNT) "s_mov_b64 exec, -1\n"
+                     : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+                       [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn)
+                     : NTK_X_IN(0), NTK_X_IN(1), NTK_X_IN(2), NTK_X_IN(3), [one] "v"(one)
+                     : "memory", "vcc", "scc");
+#undef NTK_X_IN
+#undef NTK_X_POS
+#elif defined(NTK_X_TWOPHASE)
+        // round-6 experiment (a'), profiles/r06a: the chain cut in two - first exec / compare / select / count of all four positions, then
+        // exec / digests / atomic of all four: the select's result is not needed for ~10 instructions, at the price of four more exec writes
+#define NTK_X_P1(i, CMP, CNT) NTK_R_EXEC(i) CMP " vcc, %[ft" #i "], %[rt" #i "]\n" "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n" CNT
+#define NTK_X_P2(i) NTK_R_EXEC(i) NTK_R_SUM_##i("%[t" #i "]") NTK_R_XOR("%[t" #i "]") NTK_R_HIST(i)
+#define NTK_X_BODY(CMP) NTK_X_P1(0, CMP, NTK_R_CNT_FIRST) NTK_X_P1(1, CMP, NTK_R_CNT) NTK_X_P1(2, CMP, NTK_R_CNT) NTK_X_P1(3, CMP, NTK_R_CNT) \
+                        NTK_X_P2(0) NTK_X_P2(1) NTK_X_P2(2) NTK_X_P2(3) "s_mov_b64 exec, -1\n"
+        if constexpr (TIE_RC_) asm volatile(NTK_X_BODY("v_cmp_lt_u32") NTK_R_OPS);
+        else asm volatile(NTK_X_BODY("v_cmp_le_u32") NTK_R_OPS);
+#undef NTK_X_BODY
+#undef NTK_X_P2
+#undef NTK_X_P1
+#elif defined(NTK_X_MFMASUM)
+        // round-6 experiment (b), profiles/r06a: the sum of the lo words leaves the VALU - the chosen words are zero outside the window's
+        // lanes (four full-rate moves before the region) and ONE v_mfma_i32_16x16x64_i8 adds the sixteen bytes a lane holds, by significance,
+        // against a 0/1 selector.  TIMING PROXY: i8 is signed, so the byte sums are off by 256 x (bytes with the top bit set), which an exact
+        // version would have to count with more VALU work (tools/gen_ubench14.py prices that); n_total / n_fwd / xor / histogram stay exact.
+        t0 = t1 = t2 = t3 = 0;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+#define NTK_X_POS(i, CMP, CNT) NTK_R_EXEC(i) CMP " vcc, %[ft" #i "], %[rt" #i "]\n" "v_cndmask_b32 %[t" #i "], %[rl" #i "], %[fl" #i "], vcc\n" NTK_R_XOR("%[t" #i "]") NTK_R_HIST(i) CNT
+#define NTK_X_BODY(CMP) NTK_X_POS(0, CMP, NTK_R_CNT_FIRST) NTK_X_POS(1, CMP, NTK_R_CNT) NTK_X_POS(2, CMP, NTK_R_CNT) NTK_X_POS(3, CMP, NTK_R_CNT) "s_mov_b64 exec, -1\n"
+#define NTK_X_OPS : [xlo] "+v"(xlo), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [nf] "=&s"(nf_grp), [cn] "=&s"(cn) \
+                  : NTK_R_IN(0), NTK_R_IN(1), NTK_R_IN(2), NTK_R_IN(3), [one] "v"(one) : "memory", "vcc", "scc"
+        if constexpr (TIE_RC_) asm volatile(NTK_X_BODY("v_cmp_lt_u32") NTK_X_OPS);
+        else asm volatile(NTK_X_BODY("v_cmp_le_u32") NTK_X_OPS);
+        (void)sd;
+        macc = __builtin_amdgcn_mfma_i32_16x16x64_i8(i32x4{(int)t0, (int)t1, (int)t2, (int)t3}, msel, macc, 0, 0, 0);
+#undef NTK_X_OPS
+#undef NTK_X_BODY
+#undef NTK_X_POS
+#else
         if constexpr (TIE_RC_) asm volatile(NTK_R_BODY("v_cmp_lt_u32") NTK_R_OPS);   // byte path: ties report the reverse complement (src/kmer.rs:124-128)
         else asm volatile(NTK_R_BODY("v_cmp_le_u32") NTK_R_OPS);                     // bit path: ties stay forward (src/bitkmer.rs:136-143)
+#endif
         nf_s += nf_grp;
 #undef NTK_R_OPS
 #undef NTK_R_BODY
@@ -737,6 +796,9 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     DevMasks2<K, HB> mp;
     NoSink sink;
     mp.rep = lane & (uint32_t)(DevMasks2<K, HB>::kWordCopies - 1);
+#ifdef NTK_X_MFMASUM
+    { const int sel = 1 << (8 * (lane & 3)); mp.msel = {sel, sel, sel, sel}; }   // B[k][j] = [k % 4 == j % 4]: column j sums the bytes of significance j % 4
+#endif
 
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
@@ -835,6 +897,9 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
     // sum: the two alternating accumulators of the lo words, plus (K >= 24) the hi words' sum; xor: lo words, and (K >= 24) T words
     uint64_t sum = mp.sum + mp.sum2 + ((uint64_t)mp.sumh << 32);
+#ifdef NTK_X_MFMASUM
+    if ((lane & 15) < 4) sum += (uint64_t)(int64_t)(mp.macc.x + mp.macc.y + mp.macc.z + mp.macc.w) << (8 * (lane & 3));   // columns 0..3, all row groups
+#endif
     uint64_t xr = (WORD || LIGHT) ? (uint64_t)mp.xlo : ((uint64_t)mp.xh << 32) | mp.xlo, nf, nv = 0;
     uint64_t shi = 0, xf = 0;   // LIGHT: high parts of the digests, from the histogram
     uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;

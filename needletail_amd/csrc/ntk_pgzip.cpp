@@ -274,6 +274,9 @@ int inflate_codes(Bits &bits, const Tables &tb, Out<T> &o, size_t floor, uint64_
             base = o.base; cap = o.cap;
         }
         PGZ_REFILL();
+        // past the end of the input the reader hands out zero bits: a truncated stream whose all-zero code is a literal would otherwise emit
+        // literals until max_out (checked on every trip: the literal path below never reaches the match path's exit)
+        if (__builtin_expect(ip > n + 16, 0)) { rc = kCorrupt; break; }
         uint32_t e = lit[bb & lmask];
         if ((e & 0x30) == 0x30) {
             const uint32_t sb = e & 15;
@@ -316,7 +319,6 @@ int inflate_codes(Bits &bits, const Tables &tb, Out<T> &o, size_t floor, uint64_
         if ((size_t)dist > pos - floor) { rc = kCorrupt; break; }
         copy_match(base + pos, dist, len);
         pos += len;
-        if (ip > n + 16) { rc = kCorrupt; break; }   // long past the end of the input: a truncated stream decoding phantom zero bits
     }
 #undef PGZ_DROP
 #undef PGZ_REFILL

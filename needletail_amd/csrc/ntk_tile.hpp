@@ -1147,7 +1147,12 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
     // min-ed, so they are fetched once (DPP move).  Its reverse-complement words are only ever the lo candidate of one
     // position and are fetched where that position is handled.
 #pragma unroll
-    for (int g = 2; g <= D; g++) fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+    for (int g = 2; g <= D; g++) {
+#ifdef NTK_ABL_HALFIMPORTS   // kbench what-if (WRONG results): every other cross-lane word taken from the lane's own register - the most a longer lane pitch could save
+        if (g & 1) { fw[D - g] = fw[D + 16 - g]; continue; }
+#endif
+        fw[D - g] = xl.prev(kSlotFw + 16 - g, fw[D + 16 - g]);
+    }
     // Positions are taken in groups {jp, jp+1, jp+8, jp+9}: the T words of positions j and j+8 sit in ONE register on
     // either strand - fw[j-D] = (top half of T_fwd(j) : top half of T_fwd(j+8)), rw[j+8] = (top half of T_rc(j+8) : top half
     // of T_rc(j)) - so in the LIGHT build one packed 16-bit min with crossed halves yields both histogram prefixes
@@ -1162,6 +1167,9 @@ NTK_HD void lane_tile_sv2(Sink &sink, XL &xl, MP &mp, uint32_t code, uint32_t rc
             const int j = pos[i];
             ft[i] = fw[j]; rt[i] = rw[D + j];                   // T words: fw[(j - D) + D], rw[j + D]
             fl[i] = fw[D + j];                                  // lo words: forward = the word ending at base j,
+#ifdef NTK_ABL_HALFIMPORTS
+            if (j - D < -1 && (j & 1)) { rl[i] = rw[16 + j]; continue; }
+#endif
             rl[i] = j - D >= -1 ? rw[j] : xl.prev(kSlotRw + 16 + j - D, rw[16 + j]);   // reverse complement = rw[(j - D) + D]: own word, r1, or the previous lane's word 16 + (j - D)
         }
         if constexpr (LIGHT)
