@@ -36,7 +36,7 @@ extern "C" {
 /* 3 (round 5): + ntk_ctx_set_option (the library no longer reads A/B switches from the environment), ntk_gunzip / ntk_gunzip_free,
  * ntk_bit_kmers_batch_planes.  2 (round 4): + ntk_canonical_kmers_batch_planes, ntk_ctx_trim, ntk_comm_allreduce_time_ms; round 3 had added
  * ntk_device_count, ntk_pinned_alloc / ntk_pinned_free under version 1.  ntk_abi_version() of the loaded library says what it exports. */
-#define NTK_ABI_VERSION 3
+#define NTK_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -100,6 +100,9 @@ typedef struct ntk_result {
     uint64_t sum;     /* sum of values mod 2^64                                                 */
     uint64_t xr;      /* xor of values                                                          */
     uint64_t hist[NTK_HIST_BINS]; /* bin = value >> 2*(k-p), p = min(k,6): leading p bases       */
+    uint64_t n_undigested; /* of n_total: k-mers of a k > 32 scan (byte path, reduce face; CanonicalKmers takes k: u8,
+                              reference src/kmer.rs:48-82) - counted and binned, but a 2-bit value of more than 64 bits
+                              has no place in sum / xr, which cover the other n_total - n_undigested k-mers (ABI 4)  */
 } ntk_result;
 /* Device-side accumulator layout (u64 words), for callers that reduce across GPUs themselves: */
 #define NTK_ACC_N_TOTAL 0
@@ -107,6 +110,7 @@ typedef struct ntk_result {
 #define NTK_ACC_N_RC 2
 #define NTK_ACC_SUM 3
 #define NTK_ACC_XOR 4   /* NOT summable: combine with xor (or use the bit counters below) */
+#define NTK_ACC_UNDIGESTED 5 /* ntk_result.n_undigested */
 #define NTK_ACC_HIST 8  /* 4096 words follow */
 #define NTK_ACC_XOR_BITS (8 + NTK_HIST_BINS) /* 64 words: how many folded partial xors had bit i set; summable
                                                 across GPUs with one ncclSum all-reduce, xor bit i = parity */
@@ -132,7 +136,9 @@ int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
  *   NTK_OPT_MINIMIZER_ROUTE        NTK_ROUTE_NO_* bits: routes of ntk_minimizers_reduce_device switched OFF - the register-fused
  *                                  builds, the generic fused kernel (both off = materialise + window-min), the v_min_f64 keys of the
  *                                  generic kernel (k <= 25 then runs the general keys) - so that each route can be checked against
- *                                  the others on the same input
+ *                                  the others on the same input; NTK_ROUTE_NO_SPECULATION: un-normalised byte-path input
+ *                                  (NTK_PATH_BYTES_CANONICAL, pre < NORMALIZE) goes straight to the raw-byte kernel instead of the
+ *                                  packed-value scan that watches for lower case and is redone by that kernel only if it saw any
  *   NTK_OPT_COMPAT_PACK_THREADS    host threads that pack a chunk of the item-array compat faces (default 8)
  *   NTK_OPT_COPY_STREAMS           HIP streams that take the pinned batches' H2D copies in turn (1 or 2; default 2: the next batch's copy is
  *                                  queued while one runs - measured +14 % on the H2D-inclusive FASTQ pipeline with 4 MiB batches) */
@@ -141,6 +147,7 @@ enum { NTK_OPT_COMPAT_CHUNK_BYTES = 1, NTK_OPT_MINIMIZER_CHUNK_BYTES = 2, NTK_OP
 #define NTK_ROUTE_NO_REGFUSED 1u
 #define NTK_ROUTE_NO_GENERIC 2u
 #define NTK_ROUTE_NO_F64 4u
+#define NTK_ROUTE_NO_SPECULATION 8u
 int ntk_ctx_set_option(ntk_ctx *ctx, int option, uint64_t value);
 /* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */

@@ -18,7 +18,7 @@ ACC_N_TOTAL, ACC_N_FWD, ACC_N_RC, ACC_SUM, ACC_XOR, ACC_HIST = 0, 1, 2, 3, 4, 8
 ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 # ntk_ctx_set_option (test / A-B support)
 OPT_COMPAT_CHUNK_BYTES, OPT_MINIMIZER_CHUNK_BYTES, OPT_MINIMIZER_ROUTE, OPT_COMPAT_PACK_THREADS, OPT_COPY_STREAMS = 1, 2, 3, 4, 5
-ROUTE_NO_REGFUSED, ROUTE_NO_GENERIC, ROUTE_NO_F64 = 1, 2, 4
+ROUTE_NO_REGFUSED, ROUTE_NO_GENERIC, ROUTE_NO_F64, ROUTE_NO_SPECULATION = 1, 2, 4, 8
 ROUTE_TWO_PASS = ROUTE_NO_REGFUSED | ROUTE_NO_GENERIC
 
 # every symbol include/needletail_amd.h declares (tests/test_abi.py checks header <-> library <-> this list)
@@ -56,7 +56,7 @@ def flags(w: int = 0, quality_cutoff: int = 0, reset: bool = False) -> int:
 
 class Result(C.Structure):
     _fields_ = [("n_total", C.c_uint64), ("n_fwd", C.c_uint64), ("n_rc", C.c_uint64), ("sum", C.c_uint64),
-                ("xr", C.c_uint64), ("hist", C.c_uint64 * HIST_BINS)]
+                ("xr", C.c_uint64), ("hist", C.c_uint64 * HIST_BINS), ("n_undigested", C.c_uint64)]
 
 
 class Record(C.Structure):

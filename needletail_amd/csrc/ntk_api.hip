@@ -122,6 +122,8 @@ struct ntk_ctx {
     uint32_t *d_part_hist = nullptr;
     uint32_t *d_work = nullptr;     // kMaxShards work counters, one per 64-B line
     bool work_dirty = true;         // not known to be zero
+    uint32_t *d_lower = nullptr;    // kLowerRing flag words behind the work counters: speculative scans of un-normalised byte-path input (run_scan)
+    uint32_t lower_idx = 0;
     // ntk_ctx_set_option (test / A-B support, per ctx: nothing in the dispatch reads the environment)
     uint64_t minimizer_chunk = (uint64_t)256 << 20;  // NTK_OPT_MINIMIZER_CHUNK_BYTES: bytes of input per two-pass minimizer pass
     uint64_t compat_chunk = (uint64_t)16 << 20;      // NTK_OPT_COMPAT_CHUNK_BYTES: packed bytes per chunk of the batched compat faces
@@ -190,16 +192,18 @@ inline uint32_t quality_cutoff(const ntk_params *p) { return (p->flags >> 8) & 0
 int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 {
     if (!p) return NTK_ERR_BAD_ARG;
-    if (p->k < 1 || p->k > 32) return NTK_ERR_BAD_K;
+    // CanonicalKmers takes k: u8 (reference src/kmer.rs:48-82); 33 <= k <= 255 exists on the byte path's batch face in reduce mode only
+    // (counters + histogram; 2-bit values of more than 64 bits have no sum / xor: ntk_result.n_undigested) - every other face is k <= 32
+    if (p->k < 1 || p->k > (batch_face && p->path == NTK_PATH_BYTES_CANONICAL ? 255u : 32u)) return NTK_ERR_BAD_K;
     if ((p->flags & ~(0xFFFFu | NTK_FLAG_RESET)) != 0 || p->pre > NTK_PRE_NORMALIZE_IUPAC) return NTK_ERR_BAD_ARG;
     m->kw = p->k > 16 ? 2 : 1;
     m->accept_u = p->pre >= NTK_PRE_NORMALIZE;
     switch (p->path) {
     case NTK_PATH_BYTES_CANONICAL:
         // The byte path compares RAW bytes (reference src/kmer.rs:124); that equals the 2-bit order only when
-        // every base has the same case, which normalize guarantees.  Un-normalised byte-path input takes the raw-byte kernels
-        // (reduce mode: canonical_bytes_reduce_kernel; items: ntk_canonical_kmers*); the packed-value scan never approximates it.
-        m->raw_bytes = batch_face && p->pre < NTK_PRE_NORMALIZE;
+        // every base has the same case, which normalize guarantees.  Un-normalised byte-path input is scanned speculatively (the packed-value
+        // scan watches for lower case; canonical_bytes_reduce_kernel redoes the launch if there was any: run_scan); items: ntk_canonical_kmers*.
+        m->raw_bytes = batch_face && (p->pre < NTK_PRE_NORMALIZE || p->k > 32);
         m->canon = true; m->tie_rc = true; break;
     case NTK_PATH_BITS: m->canon = false; m->tie_rc = false; break;
     case NTK_PATH_BITS_CANONICAL: m->canon = true; m->tie_rc = false; break;
@@ -213,6 +217,7 @@ int resolve_mode(const ntk_params *p, bool batch_face, Mode *m)
 // k at run time, plus a k = 21 build for the canonical paths (-5 %); it runs at the rate of a plain read-1-write-8 expansion kernel
 // (2.45 ms per 1.51 GB of input against 2.45-2.50 ms, profiles/r04b/wbw.txt), i.e. it is bound by the 8 bytes it writes per position.
 constexpr int kMaxShards = 256;      // work counters: the pull atomics of > 6000 waves on 8 counters were the bottleneck (profiles/r02)
+constexpr uint32_t kLowerRing = 64;  // "a lower-case byte was seen" flags of consecutive speculative launches (each launch clears its successor's)
 
 template <bool REDUCE, bool QM>
 const void *pick_scan(const Mode &m, uint32_t k)
@@ -260,12 +265,17 @@ int get_event(ntk_ctx *c, hipEvent_t *e)
 }
 
 // CanonicalKmers over raw (un-normalised) bytes into the accumulators: canonical_bytes_reduce_kernel + fold (ntk_kernels.hpp).
-int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, bool zero_first)
+int raw_bytes_blocks(const ntk_ctx *c, uint64_t n)
 {
-    if (zero_first) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
     const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile;
     const uint64_t max_blocks = c->launch_blocks > 0 ? (uint64_t)c->launch_blocks : (uint64_t)c->n_cu * 8;
-    const int blocks = (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
+    return (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
+}
+
+int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, bool zero_first, bool normalized)
+{
+    if (zero_first) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    const int blocks = raw_bytes_blocks(c, n);
     int rc = ensure_partials(c, blocks);
     if (rc) return rc;
     const uint32_t pb = p->k < 6 ? p->k : 6;
@@ -275,12 +285,17 @@ int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk
         rc = get_event(c, &e1); if (rc) { c->ev_free.push_back(e0); return rc; }
         HIPCHK(hipEventRecord(e0, c->stream));
     }
-    hipLaunchKernelGGL(canonical_bytes_reduce_kernel, dim3(blocks), dim3(kPlThreads), 0, c->stream, d_seq, n, (n + 15) & ~(uint64_t)15, p->k,
-                       2u * (p->k - pb), (const uint16_t *)(c->d_lut + 768), c->d_part_hist, c->d_part_scalars);
+    if (p->k > 32)
+        hipLaunchKernelGGL(canonical_bytes_reduce_kernel<true>, dim3(blocks), dim3(kPlThreads), 0, c->stream, d_seq, n, (n + 15) & ~(uint64_t)15, p->k,
+                           2u * (p->k - pb), (const uint16_t *)(c->d_lut + 768), c->d_part_hist, c->d_part_scalars, (const uint32_t *)nullptr, normalized ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(canonical_bytes_reduce_kernel<false>, dim3(blocks), dim3(kPlThreads), 0, c->stream, d_seq, n, (n + 15) & ~(uint64_t)15, p->k,
+                           2u * (p->k - pb), (const uint16_t *)(c->d_lut + 768), c->d_part_hist, c->d_part_scalars, (const uint32_t *)nullptr, 0u);
     HIPCHK(hipGetLastError());
     if (c->timing) { HIPCHK(hipEventRecord(e1, c->stream)); c->ev_used.emplace_back(e0, e1); }
     hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
-                       (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, (uint32_t *)nullptr, 0);
+                       (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, (uint32_t *)nullptr, 0,
+                       (const uint32_t *)nullptr, 0, p->k > 32 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return NTK_OK;
 }
@@ -299,16 +314,26 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     }
     if (!d_seq || ((uintptr_t)d_seq & 15) || ((uintptr_t)d_qual & 15)) return NTK_ERR_BAD_ARG;
     const uint32_t cutoff = d_qual ? quality_cutoff(p) : 0u;  // cutoff 0 masks nothing: the plain build runs
+    const uint64_t kMaxTilesPerLaunch = (uint64_t)8 << 22;
+    bool speculate = false;
     if (m.raw_bytes) {
-        // byte path on input that was not normalised: reduce mode has its raw-byte kernel; dense values, quality masking and windowed
-        // minimizers on such input are not built (normalize first, as the reference's documented chain does)
+        // byte path on input that was not normalised: reduce mode only; dense values, quality masking and windowed minimizers on such
+        // input are not built (normalize first, as the reference's documented chain does), and k > 32 has counters + histogram only
+        if (p->k > 32 && (!reduce || cutoff || fused_min_fn)) return NTK_ERR_BAD_K;
         if (!reduce || cutoff || fused_min_fn) return NTK_ERR_UNSUPPORTED;
-        return run_raw_bytes_reduce(c, d_seq, n, p, zero_first);
+        // k <= 32: the raw-byte order is the 2-bit order unless a base is lower case - the clean read on which Sequence::normalize returns
+        // None (reference src/sequence.rs:57-61).  So the packed-value scan runs (its TIE_RC, !ACCEPT_U build watches every byte it loads for
+        // bit 5), the raw-byte kernel is queued behind it and returns at once unless the flag went up, and the fold takes whichever partials
+        // are valid: no host round trip, 0.45 ms instead of 5.1 per 1.5 GB of upper-case reads.  One launch only (the raw-byte kernel works on
+        // window starts, the scan on window ends: their launch ranges do not line up), the direct route otherwise and under NTK_ROUTE_NO_SPECULATION.
+        const uint64_t tiles_all = ((n + 15) / 16 + tile_slots - 1) / tile_slots;
+        speculate = p->k <= 32 && tiles_all <= kMaxTilesPerLaunch && !(c->route_off & NTK_ROUTE_NO_SPECULATION);
+        if (!speculate) return run_raw_bytes_reduce(c, d_seq, n, p, zero_first, p->k > 32 && m.accept_u);
     }
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
     const void *fn = fused_min_fn ? fused_min_fn
                    : cutoff ? (reduce ? pick_scan<true, true>(m, p->k) : pick_scan<false, true>(m, p->k))
-                            : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));
+                            : (reduce ? pick_scan<true, false>(m, p->k) : pick_scan<false, false>(m, p->k));   // (speculate: tie_rc, !accept_u - the SPEC build)
     if (!fn) return NTK_ERR_BAD_ARG;
     // every reduce-mode scan (any path, any k, with or without a quality stream, fused minimizers) is a scan2 build: 768 threads, two
     // blocks per CU = 6 waves per SIMD, which needs <= 80 VGPRs.  A build above that would get ONE 768-thread block per CU; it runs
@@ -355,7 +380,6 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
     if (cutoff) { const QualityCut qc = quality_cut(cutoff); a.qual = d_qual; a.q_add = qc.add; a.q_sel = qc.sel; }
     // per launch: a shard holds <= 2^22 tiles so that the per-block u32 histogram cells (a block can at most drain its
     // whole shard: 2^22 * 992 windows) and the u32 work counters cannot overflow
-    const uint64_t kMaxTilesPerLaunch = (uint64_t)8 << 22;
     for (uint64_t tb = 0; tb < a.n_tiles; tb += kMaxTilesPerLaunch) {
         const uint64_t te = tb + kMaxTilesPerLaunch < a.n_tiles ? tb + kMaxTilesPerLaunch : a.n_tiles;
         const uint64_t tiles = te - tb;
@@ -378,10 +402,17 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         // (first use, a materialise scan, an error on the way) leaves work_dirty set and costs a memset here
         if (c->work_dirty) HIPCHK(hipMemsetAsync(c->d_work, 0, kMaxShards * 64, c->stream));
         c->work_dirty = true;
+        const int blocks_raw = speculate ? raw_bytes_blocks(c, n) : 0;
         if (reduce) {
-            int rc = ensure_partials(c, blocks);
+            int rc = ensure_partials(c, blocks > blocks_raw ? blocks : blocks_raw);
             if (rc) return rc;
             a.part_hist = c->d_part_hist; a.part_scalars = c->d_part_scalars;
+        }
+        uint32_t *flag = nullptr;
+        if (speculate) {
+            flag = c->d_lower + c->lower_idx;
+            c->lower_idx = (c->lower_idx + 1) % kLowerRing;
+            a.lower_flag = flag; a.lower_flag_next = c->d_lower + c->lower_idx;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->timing) {
@@ -391,13 +422,20 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         }
         void *kargs[] = {(void *)&a};
         HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), kargs, lds, c->stream));
+        if (speculate) {   // (inside the timed span: the pair is this route's scan)
+            const uint32_t pb = p->k < 6 ? p->k : 6;
+            hipLaunchKernelGGL(canonical_bytes_reduce_kernel<false>, dim3(blocks_raw), dim3(kPlThreads), 0, c->stream, d_seq, n, (n + 15) & ~(uint64_t)15, p->k,
+                               2u * (p->k - pb), (const uint16_t *)(c->d_lut + 768), c->d_part_hist, c->d_part_scalars, (const uint32_t *)flag, 0u);
+            HIPCHK(hipGetLastError());
+        }
         if (c->timing) {
             HIPCHK(hipEventRecord(e1, c->stream));
             c->ev_used.emplace_back(e0, e1);
         }
         if (reduce) {
             hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
-                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, c->d_work, (int)a.n_shards);
+                               (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, c->d_work, (int)a.n_shards,
+                               (const uint32_t *)flag, blocks_raw, 0);
             HIPCHK(hipGetLastError());
             c->work_dirty = false;
         }
@@ -535,7 +573,9 @@ int init_ctx(ntk_ctx *c, void *stream, bool borrow)
     HIPCHK(hipMalloc(&c->d_acc_own, NTK_ACC_WORDS * sizeof(uint64_t)));
     c->d_acc = c->d_acc_own;
     HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
-    HIPCHK(hipMalloc(&c->d_work, kMaxShards * 64));
+    HIPCHK(hipMalloc(&c->d_work, kMaxShards * 64 + kLowerRing * sizeof(uint32_t)));
+    c->d_lower = c->d_work + kMaxShards * 16;
+    HIPCHK(hipMemsetAsync(c->d_lower, 0, kLowerRing * sizeof(uint32_t), c->stream));
     HIPCHK(hipMalloc(&c->d_lut, 4 * 256 * sizeof(uint16_t)));
     HIPCHK(hipHostMalloc(&c->h_pinned, 64 * 1024, hipHostMallocDefault));
     uint16_t *h = (uint16_t *)c->h_pinned;
@@ -652,7 +692,7 @@ int ntk_ctx_set_option(ntk_ctx *c, int option, uint64_t value)
         c->minimizer_chunk = value == 0 ? ((uint64_t)256 << 20) : (value & ~(uint64_t)4095);
         return NTK_OK;
     case NTK_OPT_MINIMIZER_ROUTE:
-        if (value & ~(uint64_t)(NTK_ROUTE_NO_REGFUSED | NTK_ROUTE_NO_GENERIC | NTK_ROUTE_NO_F64)) return NTK_ERR_BAD_ARG;
+        if (value & ~(uint64_t)(NTK_ROUTE_NO_REGFUSED | NTK_ROUTE_NO_GENERIC | NTK_ROUTE_NO_F64 | NTK_ROUTE_NO_SPECULATION)) return NTK_ERR_BAD_ARG;
         c->route_off = (uint32_t)value;
         return NTK_OK;
     case NTK_OPT_COPY_STREAMS:            // 0 = default (2); 1 or 2 HIP streams take the pinned batches' H2D copies in turn
@@ -731,6 +771,7 @@ int ntk_accum_read(ntk_ctx *c, ntk_result *out)
     out->n_total = h[NTK_ACC_N_TOTAL]; out->n_fwd = h[NTK_ACC_N_FWD]; out->n_rc = h[NTK_ACC_N_RC];
     out->sum = h[NTK_ACC_SUM]; out->xr = h[NTK_ACC_XOR];
     memcpy(out->hist, h + NTK_ACC_HIST, sizeof(out->hist));
+    out->n_undigested = h[NTK_ACC_UNDIGESTED];
     return NTK_OK;
 }
 
@@ -1587,7 +1628,7 @@ static int minimizers_reduce_impl(ntk_ctx *c, const uint8_t *d_seq, const uint8_
     int rc = resolve_mode(p, true, &m);
     if (rc) return rc;
     if (!m.canon) return NTK_ERR_BAD_ARG;
-    if (m.raw_bytes) return NTK_ERR_UNSUPPORTED;   // windowed minimizers are defined on normalised input (values, not raw bytes)
+    if (m.raw_bytes) return p->k > 32 ? NTK_ERR_BAD_K : NTK_ERR_UNSUPPORTED;   // windowed minimizers are defined on normalised input (values, not raw bytes)
     HIPCHK(hipSetDevice(c->device));
     // fused build (one pass, nothing written to HBM) where one exists - with a quality stream: the quality-masked builds
     if (n) {

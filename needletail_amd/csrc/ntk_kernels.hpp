@@ -792,6 +792,13 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     if (shard_end > launch_tiles) shard_end = launch_tiles;
     uint32_t *ctr = a.work_counters + shard * 16;
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
+    // SPEC: the byte path's tie rule on bytes nobody normalised (NTK_PATH_BYTES_CANONICAL with pre < NORMALIZE).  The reference compares RAW
+    // bytes (src/kmer.rs:121-128), which is the 2-bit order as long as no base is lower case - what Sequence::normalize reports by returning
+    // None on a clean read (src/sequence.rs:57-61).  The build ORs every byte it loads into `lc` (two full-rate ops per tile); a wave that saw
+    // bit 5 anywhere raises a.lower_flag and the host has queued canonical_bytes_reduce_kernel behind this launch, which then redoes it.
+    constexpr bool SPEC = TIE_RC && !ACCEPT_U && !QM && W == 0 && !FWD;
+    uint32_t lc = 0;
+    if (SPEC && a.lower_flag_next && blockIdx.x == 0 && threadIdx.x == 0) *a.lower_flag_next = 0;   // the next launch's flag (a ring, see run_scan)
     DevXL xl;
     DevMasks2<K, HB> mp;
     NoSink sink;
@@ -842,6 +849,7 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r, auto &&after_encode) {
             const bool tail = r >= a.tail_tile_rel;
             Raw16 raw{t.x, t.y, t.z, t.w};
+            if constexpr (SPEC) lc = bitop3<0xFE>(bitop3<0xFE>(lc, t.x, t.y), t.z, t.w);
             if constexpr (QM) raw = quality_break16(raw, Raw16{q.x, q.y, q.z, q.w}, a.q_add, a.q_sel);
 #ifdef NTK_ABL_LOADSONLY
             mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
@@ -893,6 +901,8 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         a.values[w * 4 + 2] = ((clock64() - dbg_c0) & 0xFFFFFFFFFFull) | ((uint64_t)dbg_tiles << 40); a.values[w * 4 + 3] = ((uint64_t)xcc << 32) | hwid;
     }
 #endif
+    if constexpr (SPEC)
+        if (a.lower_flag && __builtin_amdgcn_ballot_w64((lc & 0x20202020u) != 0u) != 0ull && lane == 0) atomicOr(a.lower_flag, 1u);
     // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm blocks' LDS atomics are not tracked by the compiler
     // sum: the two alternating accumulators of the lo words, plus (K >= 24) the hi words' sum; xor: lo words, and (K >= 24) T words
@@ -1195,9 +1205,14 @@ __global__ __launch_bounds__(min_gen_threads(F64), min_gen_waves(F64)) void mini
 // u64 atomic per bin; one extra block reduces the scalar partials.  (A single pass over <= 8 MiB, a few microseconds.)
 constexpr int kFoldThreads = 256, kFoldBinGroups = kHistBins / kFoldThreads, kFoldRowGroups = 32;
 constexpr int kFoldBlocks = kFoldBinGroups * kFoldRowGroups + 1;
+// select != nullptr (speculative scans of un-normalised byte-path input, scan2_kernel SPEC): a set flag means the raw-byte kernel re-did
+// the launch and left nblocks_alt rows of partials in place of the scan's.  undigested: the partials come from a k > 32 scan - its k-mers
+// are counted in acc[NTK_ACC_UNDIGESTED] as well (they are in the counters and the histogram, not in sum / xor).
 __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part_hist, const uint64_t *part_scalars, int nblocks,
-                                                            uint64_t *acc, uint32_t *work_counters = nullptr, int n_counters = 8)
+                                                            uint64_t *acc, uint32_t *work_counters = nullptr, int n_counters = 8,
+                                                            const uint32_t *select = nullptr, int nblocks_alt = 0, int undigested = 0)
 {
+    if (select && *select) nblocks = nblocks_alt;
     if (blockIdx.x < kFoldBinGroups * kFoldRowGroups) {
         const int bin = (blockIdx.x % kFoldBinGroups) * kFoldThreads + threadIdx.x;
         uint64_t s = 0;
@@ -1224,7 +1239,7 @@ __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part
     if (threadIdx.x < 64) {
         tv = tf = ts = tx = 0;
         for (int w = 0; w < kFoldThreads / 64; w++) { tv += s_red[w][0]; tf += s_red[w][1]; ts += s_red[w][2]; tx ^= s_red[w][3]; }
-        if (threadIdx.x == 0) { acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx; }
+        if (threadIdx.x == 0) { acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx; if (undigested) acc[5] += tv; }
         acc[8 + kHistBins + threadIdx.x] += (tx >> threadIdx.x) & 1;  // summable form of the xor (one bit counter per lane)
     }
 }
@@ -1466,9 +1481,20 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_planes_kernel(cons
 // run).  Same staging as the plane kernels; a thread walks the 8 + k - 1 bytes of its 8 starts once with the run length of bases and the
 // rolling 2-bit values of both strands; where a window is emitted the strand is the byte-wise compare (ties -> rc), the value the chosen
 // strand's.  Per-block partials in the layout fold_kernel sums.  k <= 32 (the digests are defined on 2-bit values).
+// run_if != nullptr: the kernel is the second half of a speculative launch pair and returns at once unless the scan before it found a byte
+// with bit 5 set (lower case: the only input on which the raw-byte order and the 2-bit order differ).
+// k > 32 (any k <= 255, reference src/kmer.rs:48-82: k is a u8): the items' positions and strands are as well defined as for small k, their
+// 2-bit values are not (more than 64 bits) - counters and the histogram of the leading 6 bases are produced, sum / xor stay 0 and fold_kernel
+// counts the k-mers as undigested.  normalized: the batch is to be read as Sequence::normalize would have left it (U / u are T, case
+// folded: src/sequence.rs:24-51), i.e. the strand compare runs on the 2-bit codes; only k > 32 comes here in that form.
+// (WIDE = false: the k <= 32 raw-byte build, whose inner loop carries none of the k > 32 / normalised cases - they cost it 30 %, profiles/r06b.)
+template <bool WIDE>
 __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(const uint8_t *seq, uint64_t n, uint64_t n_readable, uint32_t k, uint32_t bin_shift,
-                                                                            const uint16_t *comp_lut, uint32_t *part_hist, uint64_t *part_scalars)
+                                                                            const uint16_t *comp_lut, uint32_t *part_hist, uint64_t *part_scalars,
+                                                                            const uint32_t *run_if, uint32_t normalized_arg)
 {
+    if (run_if && *run_if == 0u) return;
+    const bool normalized = WIDE && normalized_arg;
     __shared__ __align__(16) uint8_t s_b[kPlTile + 256 + 16];
     __shared__ uint32_t s_hist[kHistBins];
     __shared__ uint8_t s_comp[256];
@@ -1477,9 +1503,11 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
     for (int i = threadIdx.x; i < kHistBins; i += kPlThreads) s_hist[i] = 0;
     const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile;
     const uint32_t need = kPlTile + k - 1;
-    const uint64_t vmask_k = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
-    const uint32_t top = 2 * k - 2;
+    constexpr bool wide = WIDE;
+    const uint64_t vmask_k = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t top = wide ? 0u : 2 * k - 2;
     uint64_t nv = 0, nf = 0, sum = 0, xr = 0;
+    auto code_of = [](uint8_t c) -> uint32_t { const uint32_t x = (c >> 1) & 3u; return x ^ (x >> 1); };   // A0 C1 G2 T3 (U3), either case
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t t0 = tile * kPlTile;
         __syncthreads();   // the previous tile's readers are done (and s_comp / s_hist are set up)
@@ -1496,21 +1524,35 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
         for (uint32_t i = 0; i < kPlPer + k - 1; i++) {
             const uint32_t idx = s + i;
             const uint8_t c = s_b[idx], cu = c & 0xDF;
-            const bool good = t0 + idx < n && (cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T');
-            const uint32_t x = (c >> 1) & 3u, code = x ^ (x >> 1);   // A0 C1 G2 T3, either case
+            const bool good = t0 + idx < n && (cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || (normalized && cu == 'U'));
+            const uint32_t code = code_of(c);
             run = good ? run + 1u : 0u;
             fwd = ((fwd << 2) | code) & vmask_k;
             rc = (rc >> 2) | ((uint64_t)(3u - code) << top);
             if (i + 1 >= k && run >= k) {
                 const uint32_t a0 = idx + 1 - k;
                 bool is_rc = true;   // equal slices -> rc (src/kmer.rs:124-128)
-                for (uint32_t m = 0; m < k; m++) {
-                    const uint8_t a = s_b[a0 + m], b = s_comp[s_b[a0 + k - 1 - m]];
-                    if (a != b) { is_rc = !(a < b); break; }
+                if (normalized) {
+                    for (uint32_t m = 0; m < k; m++) {
+                        const uint32_t a = code_of(s_b[a0 + m]), b = 3u - code_of(s_b[a0 + k - 1 - m]);
+                        if (a != b) { is_rc = !(a < b); break; }
+                    }
+                } else {
+                    for (uint32_t m = 0; m < k; m++) {
+                        const uint8_t a = s_b[a0 + m], b = s_comp[s_b[a0 + k - 1 - m]];
+                        if (a != b) { is_rc = !(a < b); break; }
+                    }
                 }
-                const uint64_t v = is_rc ? rc : fwd;
-                nv++; nf += is_rc ? 0u : 1u; sum += v; xr ^= v;
-                atomicAdd(&s_hist[(uint32_t)(v >> bin_shift)], 1u);
+                nv++; nf += is_rc ? 0u : 1u;
+                if (!wide) {
+                    const uint64_t v = is_rc ? rc : fwd;
+                    sum += v; xr ^= v;
+                    atomicAdd(&s_hist[(uint32_t)(v >> bin_shift)], 1u);
+                } else {   // the leading six bases of the chosen strand
+                    uint32_t bin = 0;
+                    for (uint32_t m = 0; m < 6; m++) bin = (bin << 2) | (is_rc ? 3u - code_of(s_b[a0 + k - 1 - m]) : code_of(s_b[a0 + m]));
+                    atomicAdd(&s_hist[bin], 1u);
+                }
             }
         }
     }

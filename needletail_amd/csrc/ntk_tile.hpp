@@ -46,6 +46,9 @@ struct ScanArgs {
     // kernel that adds this scan's partials into them runs after the scan in stream order
     uint64_t *zero_acc;
     uint32_t zero_words;
+    // speculative scans of un-normalised byte-path input (scan2_kernel SPEC builds): raised when a loaded byte has bit 5 set; the launch also
+    // clears the NEXT launch's flag word (a ring in the ctx), so that no memset sits between launches
+    uint32_t *lower_flag, *lower_flag_next;
     // generic fused windowed minimizers (minimizer_scan_kernel): window of w k-mers; the first min_halo_lanes lanes of a tile emit no
     // window (2 lanes of k-mer halo + ceil((w - 1) / 16) lanes of k-mers that earlier windows need), the tile advances by
     // (64 - min_halo_lanes) * 16 bytes; min_smear = doubling shifts that OR a "k-mer invalid" bit over the w window ends it is part of

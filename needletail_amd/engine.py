@@ -19,7 +19,7 @@ def _ptr(x) -> int:
 
 def result_to_dict(r: L.Result) -> dict:
     return {"n_total": int(r.n_total), "n_fwd": int(r.n_fwd), "n_rc": int(r.n_rc), "sum": int(r.sum),
-            "xor": int(r.xr), "hist": np.ctypeslib.as_array(r.hist).copy()}
+            "xor": int(r.xr), "hist": np.ctypeslib.as_array(r.hist).copy(), "n_undigested": int(r.n_undigested)}
 
 
 class Context:

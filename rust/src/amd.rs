@@ -28,7 +28,7 @@ pub struct NtkParams { pub k: u32, pub path: u32, pub pre: u32, pub flags: u32 }
 /// flags = w | (quality_cutoff << 8): w > 0 folds windowed minimizers, a cutoff masks low-quality FASTQ bases first
 pub const fn ntk_flags(window_w: u32, quality_cutoff: u32) -> u32 { (window_w & 0xFF) | ((quality_cutoff & 0xFF) << 8) }
 #[repr(C)]
-pub struct NtkResult { pub n_total: u64, pub n_fwd: u64, pub n_rc: u64, pub sum: u64, pub xr: u64, pub hist: [u64; NTK_HIST_BINS] }
+pub struct NtkResult { pub n_total: u64, pub n_fwd: u64, pub n_rc: u64, pub sum: u64, pub xr: u64, pub hist: [u64; NTK_HIST_BINS], pub n_undigested: u64 }
 #[repr(C)]
 pub struct NtkRecord {
     pub id: *const u8, pub id_len: u64, pub seq: *const u8, pub seq_len: u64, pub qual: *const u8, pub qual_len: u64,

@@ -11,7 +11,7 @@
 
 _Static_assert(sizeof(ntk_params) == 16, "ntk_params is four u32");
 _Static_assert(offsetof(ntk_result, hist) == 40, "five u64 scalars precede the histogram");
-_Static_assert(sizeof(ntk_result) == 40 + 8 * NTK_HIST_BINS, "ntk_result layout");
+_Static_assert(sizeof(ntk_result) == 48 + 8 * NTK_HIST_BINS, "ntk_result layout");   /* ABI 4: + n_undigested */
 _Static_assert(NTK_ACC_WORDS == 8 + NTK_HIST_BINS + 64, "accumulator layout");
 _Static_assert(NTK_COMM_ID_BYTES == 128, "ncclUniqueId");
 

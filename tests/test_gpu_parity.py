@@ -300,6 +300,132 @@ def test_reduce_on_bytes_that_were_not_normalised(ctx):
         ctx.set_launch(0, 0)
 
 
+def test_speculative_scan_of_bytes_that_were_not_normalised(ctx):
+    """Round 6: un-normalised byte-path input is scanned by the packed-value build that watches for lower case; the raw-byte kernel queued
+    behind it redoes the launch only if a byte with bit 5 was seen (reference src/sequence.rs:57-61: normalize returns None on a clean read;
+    src/kmer.rs:121-128: the compare is on raw bytes).  Both routes (speculation on / off) against the oracle's literal chain, on launches
+    that alternate between clean and soft-masked batches - each launch has its own flag word in a ring that later launches re-arm."""
+    rng = np.random.default_rng(606)
+    def reads(n_rec, p_lower, extra=b""):
+        out = []
+        for _ in range(n_rec):
+            a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 150)].copy()
+            a[rng.random(150) < 1 / 256] = ord("N")
+            a[rng.random(150) < p_lower] |= 0x20
+            out.append(a.tobytes())
+        return out + ([extra] if extra else [])
+    clean, soft = reads(700, 0.0), reads(700, 0.02)
+    one_low = [r for r in clean]; one_low[-1] = one_low[-1][:-1] + one_low[-1][-1:].lower()       # ONE lower-case base, in the last tile
+    first_low = [clean[0][:1].lower() + clean[0][1:]] + clean[1:]                                  # ... in the first
+    false_pos = reads(300, 0.0, b"ACGT-ACGT.ACGT*9 nACGTACGTACGTACGTACGTACGTACGT")                 # bit 5 on bytes that are no bases: the slow route, same result
+    sets = {"clean": clean, "soft": soft, "one_low": one_low, "first_low": first_low, "false_pos": false_pos}
+    bufs = {name: (b"\n".join(r) + b"\n") for name, r in sets.items()}
+    devs = {name: to_dev(b) for name, b in bufs.items()}
+    order = ["clean", "soft", "clean", "clean", "one_low", "first_low", "clean", "false_pos", "soft", "soft", "clean"]
+    try:
+        for k in (4, 16, 21, 31, 32):
+            want = {name: O.reduce_records(r, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE) for name, r in sets.items()}
+            for route in (0, NL.ROUTE_NO_SPECULATION):
+                ctx.set_option(NL.OPT_MINIMIZER_ROUTE, route)
+                for geometry in ((0, 0), (2, 0)):
+                    ctx.set_launch(*geometry)
+                    for name in order:
+                        ctx.reduce_device(devs[name], len(bufs[name]), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, reset=True)
+                        assert_stats_equal(ctx.accum_read(), want[name], ("speculative scan", k, route, geometry, name))
+        ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 0); ctx.set_launch(0, 0)
+        # more launches than the ring has flag words, accumulating (no reset): every third one soft-masked
+        k = 21
+        ctx.accum_reset()
+        tot = {key: 0 for key in ("n_total", "n_fwd", "n_rc", "sum", "xor")}; hist = np.zeros(4096, dtype=np.uint64)
+        wc, ws = (O.reduce_records(sets[x], k, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE) for x in ("clean", "soft"))
+        for i in range(150):
+            name, w = ("soft", ws) if i % 3 == 1 else ("clean", wc)
+            ctx.reduce_device(devs[name], len(bufs[name]), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+            for key in ("n_total", "n_fwd", "n_rc"): tot[key] += w[key]
+            tot["sum"] = (tot["sum"] + w["sum"]) & (2**64 - 1); tot["xor"] ^= w["xor"]; hist += w["hist"]
+        tot["hist"] = hist
+        assert_stats_equal(ctx.accum_read(), tot, "150 launches on one ring")
+        # the pinned-batch face: clean and soft-masked records in separate batches and mixed
+        for name, recs in (("clean", clean), ("soft", soft), ("mixed", clean[:300] + soft[:300] + clean[300:])):
+            st = _run_records(ctx, recs, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_STRIP_RETURNS, batch_bytes=1 << 15)
+            assert_stats_equal(st, O.reduce_records(recs, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_STRIP_RETURNS), ("batch face", name))
+    finally:
+        ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 0); ctx.set_launch(0, 0)
+
+
+def _wide_reference(recs, k, normalized):
+    """CanonicalKmers with 33 <= k <= 255 per record through the oracle's literal iterator: counters + the histogram of the leading six
+    bases of every emitted slice (the 2-bit value itself has more than 64 bits: no sum / xor)."""
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"): code[ch] = i; code[ch | 0x20] = i
+    st = {"n_total": 0, "n_fwd": 0, "n_rc": 0, "sum": 0, "xor": 0, "hist": np.zeros(4096, dtype=np.uint64)}
+    for r in recs:
+        if normalized:
+            r = O.normalize(r)[0]
+        rc = O.reverse_complement(r)
+        pos, flg = O.canonical_kmers_arrays(r, rc, k)
+        for p, f in zip(pos.tolist(), flg.tolist()):
+            sl = rc[len(rc) - p - k: len(rc) - p] if f else r[p: p + k]
+            b = 0
+            for ch in sl[:6]: b = b * 4 + int(code[ch])
+            st["hist"][b] += 1
+        st["n_total"] += len(pos); st["n_rc"] += int(flg.sum()); st["n_fwd"] += len(pos) - int(flg.sum())
+    return st
+
+
+def test_k_above_32_on_the_reduce_face(ctx, golden_dir):
+    """Round 6: CanonicalKmers takes k: u8 (reference src/kmer.rs:48-82, src/sequence.rs:237-239); for 33 <= k <= 255 the device-resident
+    reduce face counts the items, splits them by strand and bins them by their leading six bases; sum / xor are not defined on values of
+    more than 64 bits (ntk_result.n_undigested says how many k-mers they do not cover)."""
+    rng = np.random.default_rng(3355)
+    recs28 = fasta_raw_seqs(open(os.path.join(golden_dir, "28S.fasta"), "rb").read())
+    rnd = []
+    for _ in range(60):
+        n = int(rng.integers(0, 900))
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+        m = rng.random(n)
+        a[m < 0.2] |= 0x20
+        a[m > 0.997] = np.frombuffer(b"NnUu-", dtype=np.uint8)[rng.integers(0, 5, int((m > 0.997).sum()))]
+        rnd.append(a.tobytes())
+    pal = [b"ACGT" * 80, b"acgt" * 80, b"AT" * 40 + b"at" * 40, b"A" * 300 + b"T" * 300]   # reverse-complement palindromes: ties -> rc
+    try:
+        for name, recs in (("28S", recs28), ("random", rnd), ("palindromes", pal)):
+            buf = b"\n".join(r.replace(b"\n", b"").replace(b"\r", b"") for r in recs) + b"\n"
+            flat = [r.replace(b"\n", b"").replace(b"\r", b"") for r in recs]
+            t = to_dev(buf)
+            for k in (33, 64, 255):
+                for pre, normalized in ((nt.PRE_NONE, False), (nt.PRE_NORMALIZE, True)):
+                    want = _wide_reference(flat, k, normalized)
+                    for geometry in ((0, 0), (3, 0)):
+                        ctx.set_launch(*geometry)
+                        ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, pre, reset=True)
+                        got = ctx.accum_read()
+                        assert_stats_equal(got, want, ("k > 32", name, k, pre, geometry))
+                        assert got["n_undigested"] == got["n_total"]
+        ctx.set_launch(0, 0)
+        # a k <= 32 scan after it: digests again, nothing undigested
+        buf = b"\n".join(rnd) + b"\n"
+        ctx.reduce_device(to_dev(buf), len(buf), 31, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, reset=True)
+        got = ctx.accum_read()
+        assert_stats_equal(got, O.reduce_records(rnd, 31, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE), "k = 31 after k > 32")
+        assert got["n_undigested"] == 0
+        # the pinned-batch face at k = 64
+        st = _run_records(ctx, rnd, 64, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 14)
+        assert_stats_equal(st, _wide_reference(rnd, 64, True), "batch face, k = 64")
+        # everything else stays k <= 32
+        t = to_dev(b"ACGT" * 100)
+        vals = torch.zeros(512, dtype=torch.int64, device="cuda"); v16 = torch.zeros(64, dtype=torch.int16, device="cuda"); r16 = torch.zeros_like(v16)
+        for call in (lambda: ctx.reduce_device(t, 400, 256, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE),
+                     lambda: ctx.reduce_device(t, 400, 33, nt.PATH_BITS_CANONICAL, nt.PRE_NONE),
+                     lambda: ctx.reduce_device(t, 400, 33, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, w=5),
+                     lambda: ctx.materialize_device(t, 400, 33, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, vals, v16, r16)):
+            with pytest.raises(nt.NtkError) as e:
+                call()
+            assert e.value.status == 1
+    finally:
+        ctx.set_launch(0, 0)
+
+
 def test_unsupported_and_bad_args_are_errors(ctx):
     t = to_dev(b"ACGT" * 100)
     # un-normalised byte-path input: reduce mode has its raw-byte kernel (test_reduce_on_bytes_that_were_not_normalised); dense values and

@@ -1,5 +1,6 @@
-"""The raw-byte reduce kernel (ntk_reduce_device, byte path, pre = NONE: input that was not normalised) on the config-2 batch with a third of
-the bases in lower case, next to the packed-value scan on the same batch normalised.  python tools/raw_bytes_bench.py"""
+"""Un-normalised byte-path input on the reduce face (ntk_reduce_device, pre = NONE) on the config-2 batch: a third of the bases in lower case,
+one lower-case base, none (the clean FASTQ case: the speculative packed-value scan stands) - next to the packed-value scan on the same
+batch normalised.  Times are the hipEvent spans around the scan (+ the raw-byte kernel where it is queued).  python tools/raw_bytes_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,7 +22,11 @@ want = O.reduce_records(host.split(b"\n")[:pre_reads], 21, nt.PATH_BYTES_CANONIC
 ctx.accum_reset(); ctx.reduce_device(mixed, pre_reads * (L + 1), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
 got = ctx.accum_read()
 assert all(int(got[k]) == int(want[k]) for k in ("n_total", "n_fwd", "n_rc", "sum", "xor")), "prefix differs from the oracle"
-for name, buf, pre in (("raw bytes, mixed case, pre = NONE", mixed, nt.PRE_NONE), ("packed-value scan, upper case, pre = NORMALIZE", seq, nt.PRE_NORMALIZE)):
+one = seq.clone(); one[n - 3] |= 0x20   # ONE lower-case base at the end of the batch: the whole launch is redone
+for name, buf, pre in (("raw bytes, mixed case, pre = NONE (speculation fails: scan + raw-byte kernel)", mixed, nt.PRE_NONE),
+                       ("upper case with one lower-case base, pre = NONE (speculation fails)", one, nt.PRE_NONE),
+                       ("upper case, pre = NONE (speculative packed-value scan; the raw-byte kernel returns at once)", seq, nt.PRE_NONE),
+                       ("packed-value scan, upper case, pre = NORMALIZE", seq, nt.PRE_NORMALIZE)):
     for _ in range(3): ctx.reduce_device(buf, n, 21, nt.PATH_BYTES_CANONICAL, pre, reset=True)
     torch.cuda.synchronize(); ctx.scan_time_ms(); ctx.enable_timing(True)
     for _ in range(5): ctx.reduce_device(buf, n, 21, nt.PATH_BYTES_CANONICAL, pre, reset=True)
