@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): + ntk_ctx_set_option (the library no longer reads A/B switches from the environment), ntk_gunzip / ntk_gunzip_free,
+/* 4 (round 6): ntk_result.n_undigested (k = 33..255 on the byte path's reduce face), ntk_gunzip_info grew (streamed runs), + ntk_ctx_get_option,
+ * ntk_scan_file_info; the environment variables of earlier rounds are ntk_ctx_set_option options.
+ * 3 (round 5): + ntk_ctx_set_option (the library no longer reads A/B switches from the environment), ntk_gunzip / ntk_gunzip_free,
  * ntk_bit_kmers_batch_planes.  2 (round 4): + ntk_canonical_kmers_batch_planes, ntk_ctx_trim, ntk_comm_allreduce_time_ms; round 3 had added
  * ntk_device_count, ntk_pinned_alloc / ntk_pinned_free under version 1.  ntk_abi_version() of the loaded library says what it exports. */
 #define NTK_ABI_VERSION 4
@@ -141,14 +143,26 @@ int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
  *                                  packed-value scan that watches for lower case and is redone by that kernel only if it saw any
  *   NTK_OPT_COMPAT_PACK_THREADS    host threads that pack a chunk of the item-array compat faces (default 8)
  *   NTK_OPT_COPY_STREAMS           HIP streams that take the pinned batches' H2D copies in turn (1 or 2; default 2: the next batch's copy is
- *                                  queued while one runs - measured +14 % on the H2D-inclusive FASTQ pipeline with 4 MiB batches) */
+ *                                  queued while one runs - measured +14 % on the H2D-inclusive FASTQ pipeline with 4 MiB batches)
+ *   NTK_OPT_BATCH_WAIT_POLL_US     ntk_batch_wait polls the batch's event every that many microseconds (default 50; NTK_POLL_BLOCK = block
+ *                                  in hipEventSynchronize instead; values are clamped to 10 s)
+ *   NTK_OPT_GZ_INMEM_LIMIT_BYTES   largest inflated size ntk_scan_file_parallel accepts for a gzip file: with n_threads = 1 the text is held in
+ *                                  memory (default 16 GiB); with more threads it is the address range reserved for the text, which is consumed
+ *                                  while it is inflated and never resident as a whole (default 4 TiB)
+ *   NTK_OPT_GZ_STREAM_WINDOW_BYTES how far the inflater of ntk_scan_file_parallel may run ahead of the parsers (default 512 MiB, at least 8 MiB):
+ *                                  the bound on the inflated text resident at any time
+ *   NTK_OPT_PIPE_STATS             != 0: the parser threads of the parallel producer print their phase times on stderr
+ * ntk_ctx_get_option reads an option back (0 = the default is in force). */
 enum { NTK_OPT_COMPAT_CHUNK_BYTES = 1, NTK_OPT_MINIMIZER_CHUNK_BYTES = 2, NTK_OPT_MINIMIZER_ROUTE = 3, NTK_OPT_COMPAT_PACK_THREADS = 4,
-       NTK_OPT_COPY_STREAMS = 5 };
+       NTK_OPT_COPY_STREAMS = 5, NTK_OPT_BATCH_WAIT_POLL_US = 6, NTK_OPT_GZ_INMEM_LIMIT_BYTES = 7, NTK_OPT_GZ_STREAM_WINDOW_BYTES = 8,
+       NTK_OPT_PIPE_STATS = 9 };
+#define NTK_POLL_BLOCK 0xFFFFFFFFu
 #define NTK_ROUTE_NO_REGFUSED 1u
 #define NTK_ROUTE_NO_GENERIC 2u
 #define NTK_ROUTE_NO_F64 4u
 #define NTK_ROUTE_NO_SPECULATION 8u
 int ntk_ctx_set_option(ntk_ctx *ctx, int option, uint64_t value);
+int ntk_ctx_get_option(ntk_ctx *ctx, int option, uint64_t *value);
 /* Record hipEvents around every scan-kernel launch; ntk_ctx_scan_time_ms returns the sum of the
  * scan kernels' durations since the last call and how many launches that covers (synchronises). */
 int ntk_ctx_enable_timing(ntk_ctx *ctx, int on);
@@ -235,8 +249,8 @@ int ntk_batch_append_quality(ntk_batch *b, const uint8_t *seq, const uint8_t *qu
                              uint32_t cutoff);
 int ntk_batch_buffers(ntk_batch *b, uint8_t **seq, uint64_t **offsets, uint64_t *n_bytes, uint64_t *n_records);
 int ntk_batch_submit(ntk_ctx *ctx, ntk_batch *b, const ntk_params *p);  /* async: H2D + reduce */
-/* Waits by polling the batch's event every NTK_BATCH_WAIT_POLL_US microseconds (environment, read once per process;
- * default 50, clamped to 10 s; 0 = block in hipEventSynchronize; not a number = default). */
+/* Waits by polling the batch's event every 50 microseconds (ntk_ctx_set_option NTK_OPT_BATCH_WAIT_POLL_US; NTK_POLL_BLOCK = block in
+ * hipEventSynchronize). */
 int ntk_batch_wait(ntk_ctx *ctx, ntk_batch *b);
 void ntk_batch_release(ntk_ctx *ctx, ntk_batch *b);
 
@@ -280,8 +294,13 @@ int ntk_scan_reader(ntk_ctx *ctx, ntk_reader *r, const ntk_params *p, uint64_t b
 /* Parallel producer for PLAIN (uncompressed) input: the byte range is cut at record starts into about eight pieces per
  * thread, handed out on demand to n_threads parser threads (at most 64 are used; 32 reach the PCIe rate), each filling
  * its own pinned batches (record order is not preserved; the reduced result does not depend on it).  A gzip stream is sequential: ntk_scan_buffer_parallel refuses it (NTK_ERR_UNSUPPORTED, use
- * ntk_scan_reader; the same for bzip2 / xz / zstd); ntk_scan_file_parallel inflates the whole file into memory first (ntk_gunzip below: all members,
- * all threads) when the output stays under 16 GiB (NTK_GZ_INMEM_LIMIT_BYTES), and is NTK_ERR_UNSUPPORTED otherwise.
+ * ntk_scan_reader; the same for bzip2 / xz / zstd).  ntk_scan_file_parallel takes a gzip file of any size: with n_threads >= 2 the file is
+ * inflated by n_threads threads (every member, CRC-32 and ISIZE checked; ordinary one-member streams in parallel too, see ntk_gunzip below)
+ * WHILE max(2, n_threads / 4) parser threads take the text as it becomes final, fill pinned batches and hand the pages back: the H2D copies
+ * and the scans run inside the inflate's span and the resident text is bounded by NTK_OPT_GZ_STREAM_WINDOW_BYTES (BASELINE.json configs[4];
+ * ntk_scan_file_info says what the run did).  Truncated or corrupt data is NTK_ERR_PARSE when the decoder reaches it - batches scanned before
+ * that have been accumulated, as a caller of the reference's reader has seen the records before the Io error.  With n_threads = 1 the file
+ * is inflated into memory first (at most NTK_OPT_GZ_INMEM_LIMIT_BYTES, else NTK_ERR_UNSUPPORTED).
  * Parse errors return NTK_ERR_PARSE without position detail. */
 /* The cut points the parallel producer uses: cuts[0] = 0 <= cuts[1] <= ... <= cuts[n_pieces] = n, every cut a record start. */
 int ntk_fastx_split_points(const uint8_t *data, uint64_t n, uint32_t n_pieces, uint64_t *cuts);
@@ -300,12 +319,19 @@ int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, 
  * ntk_scan_buffer_parallel takes.  info may be NULL. */
 typedef struct ntk_gunzip_info {
     uint32_t route, threads, chunks, chunks_dropped;   /* chunks_dropped: chunk starts that turned out not to be block boundaries */
-    uint32_t members, reserved;
-    double search_s, decode_s, decode_busy_s, crc_s;   /* wall seconds of the boundary search / of the decode + resolve pipeline; CPU seconds inside the chunk decoders; CRC combination */
+    uint32_t members, streamed;                        /* streamed: the text was consumed while it was inflated (ntk_scan_file_parallel) */
+    double search_s, decode_s, decode_busy_s, crc_s;   /* boundary search (CPU seconds / threads); wall seconds of the decode + resolve pipeline; CPU seconds inside the chunk decoders; CRC combination */
     uint64_t marker_symbols;                           /* symbols that went through the 16-bit "unknown window" form */
+    /* ABI 4 */
+    uint32_t chunks_deferred, parse_threads;           /* chunks that outgrew the speculative cap and were decoded again at the chain's head; parser threads of a streamed run */
+    uint64_t peak_backlog_bytes, text_bytes;           /* streamed runs: the most inflated text that was placed and not yet handed to a parser; the text's size */
+    double first_batch_s, total_s;                     /* streamed runs: seconds from the call to the first batch submitted / to the return */
+    double resolve_busy_s;                             /* CPU seconds inside the marker replacement + copy + CRC of the resolved chunks */
 } ntk_gunzip_info;
 int ntk_gunzip(const uint8_t *gz, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info);
 void ntk_gunzip_free(uint8_t *out, uint64_t out_n);
+/* What the gzip front-end did in the calling thread's last ntk_scan_file_parallel (route 0: the file was not gzip). */
+int ntk_scan_file_info(ntk_gunzip_info *info);
 
 /* ---- compat face: the reference's per-sequence functions, eager ---------------------------------
  * Caller-allocated outputs; *_len out-params; outputs need capacity n unless stated. */

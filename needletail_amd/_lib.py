@@ -18,6 +18,8 @@ ACC_N_TOTAL, ACC_N_FWD, ACC_N_RC, ACC_SUM, ACC_XOR, ACC_HIST = 0, 1, 2, 3, 4, 8
 ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 # ntk_ctx_set_option (test / A-B support)
 OPT_COMPAT_CHUNK_BYTES, OPT_MINIMIZER_CHUNK_BYTES, OPT_MINIMIZER_ROUTE, OPT_COMPAT_PACK_THREADS, OPT_COPY_STREAMS = 1, 2, 3, 4, 5
+OPT_BATCH_WAIT_POLL_US, OPT_GZ_INMEM_LIMIT_BYTES, OPT_GZ_STREAM_WINDOW_BYTES, OPT_PIPE_STATS = 6, 7, 8, 9
+POLL_BLOCK = 0xFFFFFFFF
 ROUTE_NO_REGFUSED, ROUTE_NO_GENERIC, ROUTE_NO_F64, ROUTE_NO_SPECULATION = 1, 2, 4, 8
 ROUTE_TWO_PASS = ROUTE_NO_REGFUSED | ROUTE_NO_GENERIC
 
@@ -26,7 +28,7 @@ SYMBOLS = [
     "ntk_strerror", "ntk_last_hip_error", "ntk_last_rccl_error", "ntk_abi_version", "ntk_device_count",
     "ntk_comm_init_all", "ntk_comm_unique_id", "ntk_comm_init_rank", "ntk_comm_size", "ntk_allreduce_accumulators", "ntk_comm_allreduce_time_ms", "ntk_comm_destroy",
     "ntk_ctx_create", "ntk_ctx_create_on_stream", "ntk_ctx_destroy", "ntk_ctx_synchronize",
-    "ntk_ctx_set_launch", "ntk_ctx_set_option", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
+    "ntk_ctx_set_launch", "ntk_ctx_set_option", "ntk_ctx_get_option", "ntk_ctx_enable_timing", "ntk_ctx_scan_time_ms",
     "ntk_accum_reset", "ntk_reduce_device", "ntk_reduce_device_quality", "ntk_accum_read", "ntk_accum_device_ptr", "ntk_accum_bind_device",
     "ntk_materialize_device", "ntk_materialize_device_quality",
     "ntk_batch_acquire", "ntk_batch_append", "ntk_batch_append_quality", "ntk_batch_buffers", "ntk_batch_submit", "ntk_batch_wait",
@@ -35,7 +37,7 @@ SYMBOLS = [
     "ntk_canonical_kmers_batch_planes", "ntk_bit_kmers_batch_planes", "ntk_ctx_trim", "ntk_minimizer_batch",
     "ntk_synth_reads_device", "ntk_reverse_complement_records_device",
     "ntk_reader_open_file", "ntk_reader_open_memory", "ntk_reader_next", "ntk_reader_error", "ntk_reader_position", "ntk_reader_close",
-    "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points", "ntk_gunzip", "ntk_gunzip_free",
+    "ntk_scan_reader", "ntk_scan_buffer_parallel", "ntk_scan_file_parallel", "ntk_fastx_split_points", "ntk_gunzip", "ntk_gunzip_free", "ntk_scan_file_info",
     "ntk_minimizers_reduce_device", "ntk_minimizer", "ntk_canonical", "ntk_bit_minimizers", "ntk_quality_mask", "ntk_bit_canonical",
 ]
 
@@ -67,8 +69,13 @@ class Record(C.Structure):
 
 class GunzipInfo(C.Structure):
     _fields_ = [("route", C.c_uint32), ("threads", C.c_uint32), ("chunks", C.c_uint32), ("chunks_dropped", C.c_uint32),
-                ("members", C.c_uint32), ("reserved", C.c_uint32), ("search_s", C.c_double), ("decode_s", C.c_double),
-                ("decode_busy_s", C.c_double), ("crc_s", C.c_double), ("marker_symbols", C.c_uint64)]
+                ("members", C.c_uint32), ("streamed", C.c_uint32), ("search_s", C.c_double), ("decode_s", C.c_double),
+                ("decode_busy_s", C.c_double), ("crc_s", C.c_double), ("marker_symbols", C.c_uint64),
+                ("chunks_deferred", C.c_uint32), ("parse_threads", C.c_uint32), ("peak_backlog_bytes", C.c_uint64), ("text_bytes", C.c_uint64),
+                ("first_batch_s", C.c_double), ("total_s", C.c_double), ("resolve_busy_s", C.c_double)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 class NtkError(RuntimeError):
@@ -157,6 +164,8 @@ def lib() -> C.CDLL:
     L.ntk_scan_buffer_parallel.argtypes = [vp, C.c_char_p, u64, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]
     L.ntk_scan_file_parallel.argtypes = [vp, C.c_char_p, C.POINTER(Params), u64, u32, C.POINTER(u64), C.POINTER(u64)]
     L.ntk_gunzip.argtypes = [C.c_char_p, u64, u32, pp, C.POINTER(u64), C.POINTER(GunzipInfo)]
+    L.ntk_scan_file_info.argtypes = [C.POINTER(GunzipInfo)]
+    L.ntk_ctx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
     L.ntk_gunzip_free.restype = None
     L.ntk_gunzip_free.argtypes = [vp, u64]
     L.ntk_minimizers_reduce_device.argtypes = [vp, vp, u64, C.POINTER(Params), u32]

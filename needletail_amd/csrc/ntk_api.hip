@@ -129,6 +129,8 @@ struct ntk_ctx {
     uint64_t compat_chunk = (uint64_t)16 << 20;      // NTK_OPT_COMPAT_CHUNK_BYTES: packed bytes per chunk of the batched compat faces
     uint32_t route_off = 0;                          // NTK_OPT_MINIMIZER_ROUTE: NTK_ROUTE_NO_* bits
     uint32_t pack_threads = 8;                       // NTK_OPT_COMPAT_PACK_THREADS
+    uint64_t wait_poll_us = 50;                      // NTK_OPT_BATCH_WAIT_POLL_US (0: block in hipEventSynchronize)
+    uint64_t gz_limit = 0, gz_window = 0, pipe_stats = 0;   // NTK_OPT_GZ_INMEM_LIMIT_BYTES / _STREAM_WINDOW_BYTES / NTK_OPT_PIPE_STATS: read by the producer (ntk_fastx_api.cpp) through ntk_ctx_get_option; 0 = its default
     uint64_t *d_part_scalars = nullptr;
     int part_blocks = 0;
     uint16_t *d_lut = nullptr;  // [0]=normalize(false) [1]=normalize(true) [2]=strip [3]=complement, 256 each
@@ -680,6 +682,23 @@ int ntk_ctx_set_launch(ntk_ctx *c, int blocks, int threads)
     return NTK_OK;
 }
 
+int ntk_ctx_get_option(ntk_ctx *c, int option, uint64_t *value)
+{
+    if (!c || !value) return NTK_ERR_BAD_ARG;
+    switch (option) {
+    case NTK_OPT_COMPAT_CHUNK_BYTES: *value = c->compat_chunk; return NTK_OK;
+    case NTK_OPT_MINIMIZER_CHUNK_BYTES: *value = c->minimizer_chunk; return NTK_OK;
+    case NTK_OPT_MINIMIZER_ROUTE: *value = c->route_off; return NTK_OK;
+    case NTK_OPT_COMPAT_PACK_THREADS: *value = c->pack_threads; return NTK_OK;
+    case NTK_OPT_COPY_STREAMS: *value = c->copy_streams; return NTK_OK;
+    case NTK_OPT_BATCH_WAIT_POLL_US: *value = c->wait_poll_us ? c->wait_poll_us : NTK_POLL_BLOCK; return NTK_OK;
+    case NTK_OPT_GZ_INMEM_LIMIT_BYTES: *value = c->gz_limit; return NTK_OK;
+    case NTK_OPT_GZ_STREAM_WINDOW_BYTES: *value = c->gz_window; return NTK_OK;
+    case NTK_OPT_PIPE_STATS: *value = c->pipe_stats; return NTK_OK;
+    default: return NTK_ERR_BAD_ARG;
+    }
+}
+
 int ntk_ctx_set_option(ntk_ctx *c, int option, uint64_t value)
 {
     if (!c) return NTK_ERR_BAD_ARG;
@@ -695,6 +714,12 @@ int ntk_ctx_set_option(ntk_ctx *c, int option, uint64_t value)
         if (value & ~(uint64_t)(NTK_ROUTE_NO_REGFUSED | NTK_ROUTE_NO_GENERIC | NTK_ROUTE_NO_F64 | NTK_ROUTE_NO_SPECULATION)) return NTK_ERR_BAD_ARG;
         c->route_off = (uint32_t)value;
         return NTK_OK;
+    case NTK_OPT_BATCH_WAIT_POLL_US:      // 0 = default (50); NTK_POLL_BLOCK = block in hipEventSynchronize
+        c->wait_poll_us = value == 0 ? 50 : (value == NTK_POLL_BLOCK ? 0 : (value > 10000000 ? 10000000 : value));
+        return NTK_OK;
+    case NTK_OPT_GZ_INMEM_LIMIT_BYTES: c->gz_limit = value; return NTK_OK;
+    case NTK_OPT_GZ_STREAM_WINDOW_BYTES: c->gz_window = value; return NTK_OK;
+    case NTK_OPT_PIPE_STATS: c->pipe_stats = value; return NTK_OK;
     case NTK_OPT_COPY_STREAMS:            // 0 = default (2); 1 or 2 HIP streams take the pinned batches' H2D copies in turn
         if (value > 2) return NTK_ERR_BAD_ARG;
         c->copy_streams = value ? (uint32_t)value : 2u;
@@ -982,16 +1007,8 @@ int ntk_batch_wait(ntk_ctx *c, ntk_batch *b)
     if (b->in_flight) {
         // query + sleep rather than hipEventSynchronize: with dozens of parser threads blocked inside the runtime at once, the
         // submitting thread's enqueue calls slowed down 2 - 3 x (48+ threads: 16 instead of 39 Gbases/s, profiles/r02e/pipeline.txt).
-        // NTK_BATCH_WAIT_POLL_US = 0 restores the blocking wait.
-        // The variable is read once per process; a value that is not a number keeps the default 50, values are clamped to 10 s.
-        static const long poll_us = [] {
-            const char *e = getenv("NTK_BATCH_WAIT_POLL_US");
-            if (!e) return 50L;
-            char *end = nullptr;
-            const long v = strtol(e, &end, 10);
-            if (end == e) return 50L;
-            return v < 0 ? 0L : (v > 10000000L ? 10000000L : v);
-        }();
+        // NTK_OPT_BATCH_WAIT_POLL_US = NTK_POLL_BLOCK restores the blocking wait (values are clamped to 10 s).
+        const long poll_us = (long)c->wait_poll_us;
         if (poll_us > 0) {
             for (;;) {
                 const hipError_t q = hipEventQuery(b->ev_done);

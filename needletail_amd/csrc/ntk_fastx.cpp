@@ -390,7 +390,7 @@ static inline void count_nl_cr(const uint8_t *p, size_t n, uint64_t *nl, uint64_
 #else
     static void (*const fn)(const uint8_t *, size_t, uint64_t *, uint64_t *) = [] {
         __builtin_cpu_init();
-        return (__builtin_cpu_supports("avx2") && !getenv("NTK_NO_AVX2")) ? count_nl_cr_avx2 : count_nl_cr_plain;
+        return __builtin_cpu_supports("avx2") ? count_nl_cr_avx2 : count_nl_cr_plain;
     }();
     fn(p, n, nl, cr);
 #endif
@@ -496,7 +496,7 @@ static inline int find_newlines(const uint8_t *p, size_t n, size_t *out, int wan
 #else
     static int (*const fn)(const uint8_t *, size_t, size_t *, int) = [] {
         __builtin_cpu_init();
-        return (__builtin_cpu_supports("avx2") && !getenv("NTK_NO_AVX2")) ? find_newlines_avx2 : find_newlines_memchr;
+        return __builtin_cpu_supports("avx2") ? find_newlines_avx2 : find_newlines_memchr;
     }();
     return fn(p, n, out, want);
 #endif

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <chrono>
 #include <thread>
@@ -197,20 +198,94 @@ uint64_t next_record_start(const uint8_t *d, uint64_t n, uint64_t from, int form
     return n;
 }
 
+// Where the range workers get their pieces of plain text from: a buffer cut in advance (ntk_scan_buffer_parallel), or the growing output of
+// a gzip inflater that is still running (ntk_scan_file_parallel on a .gz file: StreamPieces below).
+struct PieceSource {
+    virtual ~PieceSource() {}
+    virtual bool next(const uint8_t **p, uint64_t *len) = 0;   // false: no more pieces (or an error: see rc())
+    virtual void parsed(const uint8_t *, uint64_t) {}          // every record of the piece has been copied into a pinned batch
+    virtual int rc() { return NTK_OK; }
+};
+
+void release_pages(const uint8_t *p, uint64_t len)
+{
+    const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = (uintptr_t)(p + len) & ~(uintptr_t)4095;
+    if (e > a) (void)madvise((void *)a, e - a, MADV_DONTNEED);
+}
+
+// the input is cut into several pieces per thread, handed out on demand: host threads do not run at one speed (SMT siblings,
+// the far socket), and with one static range per thread the slowest one set the time (profiles/r02e/pipeline.txt)
+struct StaticPieces : PieceSource {
+    const uint8_t *data = nullptr;
+    const uint64_t *cut = nullptr;
+    uint32_t n_pieces = 0;
+    std::atomic<uint32_t> next_piece{0};
+    bool next(const uint8_t **p, uint64_t *len) override
+    {
+        for (;;) {
+            const uint32_t i = next_piece.fetch_add(1);
+            if (i >= n_pieces) return false;
+            if (cut[i + 1] <= cut[i]) continue;
+            *p = data + cut[i]; *len = cut[i + 1] - cut[i];
+            return true;
+        }
+    }
+};
+
+uint64_t next_record_start(const uint8_t *d, uint64_t n, uint64_t from, int format);
+
+// Pieces of the text a gzip inflater is still producing (ntk::PgzStream: [0, ready) is final and grows).  A piece is cut at a record start
+// about `target` bytes after the previous one as soon as that much text (+ the few lines the cut looks ahead) is ready; what has been handed
+// out counts as consumed - the inflater stays within its window of that point - and a worker gives the pages of a piece back to the kernel
+// when it has parsed it, so that the text of a file of any size passes through a bounded amount of memory.
+struct StreamPieces : PieceSource {
+    ntk::PgzStream *s = nullptr;
+    uint64_t cursor = 0, target = (uint64_t)4 << 20;
+    int format = -2;   // -2: not looked at yet
+    int err = NTK_OK;
+    bool next(const uint8_t **p, uint64_t *len) override
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        for (;;) {
+            if (err != NTK_OK || s->cancel) return false;
+            if (s->finished && s->rc != 0) return false;   // (the caller maps the inflater's status)
+            const uint64_t ready = s->ready, have = ready - cursor;
+            if (format == -2 && (ready >= 2 || s->finished)) {
+                if (ready < 2) { err = NTK_ERR_PARSE; s->cv.notify_all(); return false; }   // EmptyFile (reference src/parser/mod.rs:88-91)
+                format = s->base[0] == '>' ? ntk::kFasta : (s->base[0] == '@' ? ntk::kFastq : -1);
+                if (format < 0) { err = NTK_ERR_PARSE; s->cv.notify_all(); return false; }
+            }
+            if (s->finished && have == 0) return false;
+            if (format >= 0 && (s->finished || have >= target + (64 << 10))) {
+                uint64_t cut = ready;
+                if (have > target + (64 << 10) || !s->finished) {
+                    cut = next_record_start(s->base, ready, cursor + target, format);
+                    if (cut >= ready && !s->finished) cut = 0;   // no record start in what is ready (a very long record): wait for more
+                }
+                if (cut > cursor) {
+                    *p = s->base + cursor; *len = cut - cursor;
+                    cursor = cut;
+                    s->consumed = cursor;
+                    s->cv.notify_all();   // the inflater may place more
+                    return true;
+                }
+                if (have > s->window / 2 && s->window < ((uint64_t)1 << 40)) { s->window *= 2; s->cv.notify_all(); }   // one record longer than the window: let it grow
+            }
+            s->cv.wait(lk);
+        }
+    }
+    void parsed(const uint8_t *p, uint64_t len) override { release_pages(p, len); }
+    int rc() override { return err; }
+};
+
 struct Shared {
     ntk_ctx *ctx; const ntk_params *p; uint64_t batch_bytes;
     std::mutex mu;                       // the ctx is not thread-safe: submit / wait / acquire are serialised
     std::atomic<int> rc{NTK_OK};
     std::atomic<uint64_t> nrec{0}, nbases{0};
-    // the input is cut into several pieces per thread, handed out on demand: host threads do not run at one speed (SMT siblings,
-    // the far socket), and with one static range per thread the slowest one set the time (profiles/r02e/pipeline.txt)
-    const uint8_t *data = nullptr;
-    const uint64_t *cut = nullptr;
-    uint32_t n_pieces = 0;
-    std::atomic<uint32_t> next_piece{0};
-    // the input is the library's own scratch (a gzip file inflated into an anonymous mapping): a worker hands the pages of a piece back to
-    // the kernel as soon as it has parsed it - unmapping 3 GB in one go at the end took a third of the whole call (profiles/r05g)
-    bool release_input = false;
+    PieceSource *src = nullptr;
+    bool stats = false;                  // NTK_OPT_PIPE_STATS: per-thread phase times on stderr
+    std::atomic<int64_t> first_submit_ns{-1};   // steady-clock time of the first batch submitted
 };
 
 void range_worker(Shared *sh)
@@ -223,9 +298,9 @@ void range_worker(Shared *sh)
     for (int i = 0; i < 2 && rc == NTK_OK; i++) rc = ntk_batch_acquire(sh->ctx, sh->batch_bytes, max_records, &b[i]);
     uint64_t nrec = 0, nbases = 0;
     int cur = 0;
-    uint32_t piece = 0;
+    const uint8_t *piece = nullptr; uint64_t piece_len = 0;
     ntk_record rec;
-    static const bool stats = getenv("NTK_PIPE_STATS") != nullptr;
+    const bool stats = sh->stats;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t_begin = now();
@@ -243,6 +318,8 @@ void range_worker(Shared *sh)
             r = ntk_batch_submit(sh->ctx, b[cur], sh->p);
             const auto t2 = now();
             t_lock += secs(t0, t1); t_submit += secs(t1, t2); n_sub++;
+            int64_t none = -1;
+            sh->first_submit_ns.compare_exchange_strong(none, (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t2.time_since_epoch()).count());
         }
         if (r != NTK_OK) return r;
         cur ^= 1;
@@ -255,19 +332,13 @@ void range_worker(Shared *sh)
     };
     while (rc == NTK_OK && sh->rc.load() == NTK_OK) {
         if (!rd) {   // next piece of the input (a batch in the making carries over: pieces are not flushed)
-            const uint32_t i = sh->next_piece.fetch_add(1);
-            if (i >= sh->n_pieces) break;
-            if (sh->cut[i + 1] <= sh->cut[i]) continue;
-            piece = i;
-            if ((rc = ntk_reader_open_memory(sh->data + sh->cut[i], sh->cut[i + 1] - sh->cut[i], &rd)) != NTK_OK) break;
+            if (!sh->src->next(&piece, &piece_len)) { rc = sh->src->rc(); break; }
+            if ((rc = ntk_reader_open_memory(piece, piece_len, &rd)) != NTK_OK) break;
         }
         const int s = ntk_reader_next(rd, &rec);
         if (s == NTK_EOF) {
             ntk_reader_close(rd); rd = nullptr;
-            if (sh->release_input) {   // every record of the piece has been copied into a pinned batch
-                const uintptr_t a = ((uintptr_t)(sh->data + sh->cut[piece]) + 4095) & ~(uintptr_t)4095, e = (uintptr_t)(sh->data + sh->cut[piece + 1]) & ~(uintptr_t)4095;
-                if (e > a) (void)madvise((void *)a, e - a, MADV_DONTNEED);
-            }
+            sh->src->parsed(piece, piece_len);
             continue;
         }
         if (s != NTK_OK) { rc = s; break; }
@@ -324,6 +395,37 @@ int ntk_scan_buffer_parallel(ntk_ctx *ctx, const uint8_t *data, uint64_t n, cons
     return scan_buffer_parallel_impl(ctx, data, n, p, batch_bytes, n_threads, n_records, n_bases, false);
 }
 
+namespace {
+uint64_t ctx_option(ntk_ctx *ctx, int option, uint64_t fallback)
+{
+    uint64_t v = 0;
+    return ntk_ctx_get_option(ctx, option, &v) == NTK_OK && v ? v : fallback;
+}
+
+// The range workers over a piece source: n_threads parser threads, each with its two pinned batches.
+int run_workers(ntk_ctx *ctx, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads, PieceSource *src, uint64_t *n_records, uint64_t *n_bases,
+                int64_t *first_submit_ns = nullptr)
+{
+    Shared sh;
+    sh.ctx = ctx; sh.p = p; sh.batch_bytes = batch_bytes; sh.src = src;
+    sh.stats = ctx_option(ctx, NTK_OPT_PIPE_STATS, 0) != 0;
+    std::vector<std::thread> th;
+    try { for (uint32_t i = 1; i < n_threads; i++) th.emplace_back(range_worker, &sh); } catch (...) {}   // fewer threads than asked for: the pieces are pulled
+    range_worker(&sh);
+    for (auto &t : th) t.join();
+    if (n_records) *n_records = sh.nrec.load();
+    if (n_bases) *n_bases = sh.nbases.load();
+    if (first_submit_ns) *first_submit_ns = sh.first_submit_ns.load();
+    return sh.rc.load();
+}
+
+struct BufferPieces : StaticPieces {
+    bool release = false;   // the buffer is the library's own scratch (a gzip file inflated into an anonymous mapping): a worker hands the pages of
+                            // a piece back as soon as it has parsed it - unmapping 3 GB in one go at the end took a third of the call (profiles/r05g)
+    void parsed(const uint8_t *p, uint64_t len) override { if (release) release_pages(p, len); }
+};
+}  // namespace
+
 // release_input: `data` is an anonymous private mapping owned by the caller inside this library (the inflated text of a gzip file)
 static int scan_buffer_parallel_impl(ntk_ctx *ctx, const uint8_t *data, uint64_t n, const ntk_params *p, uint64_t batch_bytes,
                                      uint32_t n_threads, uint64_t *n_records, uint64_t *n_bases, bool release_input)
@@ -349,28 +451,21 @@ static int scan_buffer_parallel_impl(ntk_ctx *ctx, const uint8_t *data, uint64_t
     const uint32_t n_pieces = (uint32_t)want_pieces;
     std::vector<uint64_t> cut(n_pieces + 1, n);
     if (ntk_fastx_split_points(data, n, n_pieces, cut.data()) != NTK_OK) return NTK_ERR_PARSE;
-    Shared sh;
-    sh.ctx = ctx; sh.p = p; sh.batch_bytes = batch_bytes;
-    sh.data = data; sh.cut = cut.data(); sh.n_pieces = n_pieces; sh.release_input = release_input;
+    BufferPieces src;
+    src.data = data; src.cut = cut.data(); src.n_pieces = n_pieces; src.release = release_input;
     // one worker per non-empty piece at most (on small or odd inputs many cuts collapse onto the end of the buffer, and a
     // worker without a piece would still acquire its two pinned batches)
     uint32_t live_pieces = 0;
     for (uint32_t i = 0; i < n_pieces; i++) live_pieces += cut[i + 1] > cut[i];
     if (n_threads > live_pieces) n_threads = live_pieces ? live_pieces : 1;
-    std::vector<std::thread> th;
-    for (uint32_t i = 0; i < n_threads; i++) th.emplace_back(range_worker, &sh);
-    for (auto &t : th) t.join();
-    if (n_records) *n_records = sh.nrec.load();
-    if (n_bases) *n_bases = sh.nbases.load();
-    return sh.rc.load();
+    return run_workers(ctx, p, batch_bytes, n_threads, &src, n_records, n_bases);
 }
 
 namespace {
-// Whole-file gzip for the parallel producer: the file is inflated into memory by all threads (inflate_whole below) and the plain
-// text is then parsed in parallel.  libdeflate (a whole-buffer decoder; its runtime .so ships with the image, its headers do not; the
+// gzip for the parallel producer.  libdeflate (a whole-buffer decoder; its runtime .so ships with the image, its headers do not; the
 // three entry points below are its stable v1 ABI) inflates the members of BLOCK gzip files; ordinary gzip streams go through this
-// library's own speculative parallel inflater (ntk_pgzip.cpp).  Outputs beyond the in-memory limit are NTK_ERR_UNSUPPORTED here: the
-// streaming ntk_scan_reader (zlib, one thread - what the reference does) is the way for those.
+// library's own speculative parallel inflater (ntk_pgzip.cpp).  ntk_gunzip hands the whole text over in one buffer (up to the in-memory
+// limit); ntk_scan_file_parallel consumes it WHILE it is inflated (scan_gzip_streamed below): bounded memory, no limit on the file's size.
 struct Deflate {
     void *(*alloc)() = nullptr;
     int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
@@ -386,6 +481,7 @@ struct Deflate {
         ok = alloc && gzip_ex && free_;
     }
 };
+const Deflate *deflate_lib() { static const Deflate lib; return &lib; }
 
 // BGZF (block gzip: bgzip / htslib): every member is <= 64 KiB and carries its own compressed size in a 'BC' extra
 // subfield and its plain size in the trailer, so the members can be located without inflating anything and inflated
@@ -394,25 +490,86 @@ struct BgzfBlock { uint64_t in_off, in_len, out_off, out_len; };
 bool bgzf_index(const uint8_t *in, uint64_t n, std::vector<BgzfBlock> *blocks, uint64_t *total_out)
 {
     uint64_t ip = 0, op = 0;
-    while (ip < n) {
-        if (n - ip < 28 || in[ip] != 0x1F || in[ip + 1] != 0x8B || in[ip + 2] != 8 || !(in[ip + 3] & 4)) return false;
-        const uint32_t xlen = in[ip + 10] | (in[ip + 11] << 8);
-        if (n - ip < 12 + (uint64_t)xlen + 8) return false;
-        uint64_t bsize = 0;
-        for (uint32_t x = 0; x + 4 <= xlen;) {
-            const uint8_t *sf = in + ip + 12 + x;
-            const uint32_t slen = sf[2] | (sf[3] << 8);
-            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint64_t)(sf[4] | (sf[5] << 8)) + 1;
-            x += 4 + slen;
+    try {
+        while (ip < n) {
+            if (n - ip < 28 || in[ip] != 0x1F || in[ip + 1] != 0x8B || in[ip + 2] != 8 || !(in[ip + 3] & 4)) return false;
+            const uint32_t xlen = in[ip + 10] | (in[ip + 11] << 8);
+            if (n - ip < 12 + (uint64_t)xlen + 8) return false;
+            uint64_t bsize = 0;
+            for (uint32_t x = 0; x + 4 <= xlen;) {
+                const uint8_t *sf = in + ip + 12 + x;
+                const uint32_t slen = sf[2] | (sf[3] << 8);
+                if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint64_t)(sf[4] | (sf[5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + (uint64_t)xlen + 8 || bsize > n - ip) return false;
+            const uint8_t *tr = in + ip + bsize - 4;
+            const uint64_t isize = (uint64_t)tr[0] | ((uint64_t)tr[1] << 8) | ((uint64_t)tr[2] << 16) | ((uint64_t)tr[3] << 24);
+            blocks->push_back(BgzfBlock{ip, bsize, op, isize});
+            ip += bsize; op += isize;
         }
-        if (bsize < 12 + (uint64_t)xlen + 8 || bsize > n - ip) return false;
-        const uint8_t *tr = in + ip + bsize - 4;
-        const uint64_t isize = (uint64_t)tr[0] | ((uint64_t)tr[1] << 8) | ((uint64_t)tr[2] << 16) | ((uint64_t)tr[3] << 24);
-        blocks->push_back(BgzfBlock{ip, bsize, op, isize});
-        ip += bsize; op += isize;
-    }
+    } catch (...) { return false; }
     *total_out = op;
     return !blocks->empty();
+}
+
+constexpr size_t kBgzfGroup = 16;   // blocks (<= 1 MiB of text) per grab
+
+// Inflates the members of a BGZF file into buf (their final offsets are known from the index).  stream != nullptr: progressive - groups
+// are taken in file order, none is started further than the stream's window beyond what the consumer has taken, and [0, ready) is the
+// prefix of finished groups.  Returns 0, or 1 for corrupt data.
+int bgzf_inflate(const uint8_t *in, const std::vector<BgzfBlock> &blocks, uint64_t total, uint8_t *buf, uint32_t nt, ntk::PgzStream *stream)
+{
+    const Deflate &lib = *deflate_lib();
+    std::atomic<int> bad{0};
+    std::atomic<size_t> next{0};
+    const size_t n_groups = (blocks.size() + kBgzfGroup - 1) / kBgzfGroup;
+    std::vector<uint8_t> done;
+    size_t ready_group = 0;
+    if (stream) { try { done.assign(n_groups, 0); } catch (...) { return 3; } }
+    auto work = [&]() {
+        void *d = lib.alloc();
+        if (!d) { bad = 3; if (stream) { std::lock_guard<std::mutex> g(stream->mu); stream->cv.notify_all(); } return; }
+        for (size_t g; !bad && (g = next.fetch_add(1)) < n_groups;) {
+            const size_t i = g * kBgzfGroup;
+            if (stream) {   // stay within the window of the consumer
+                std::unique_lock<std::mutex> lk(stream->mu);
+                while (!bad && !stream->cancel && blocks[i].out_off > stream->consumed + stream->window) stream->cv.wait(lk);
+                if (stream->cancel) { bad = 4; break; }
+                const uint64_t backlog = blocks[i].out_off > stream->consumed ? blocks[i].out_off - stream->consumed : 0;
+                if (backlog > stream->peak_backlog) stream->peak_backlog = backlog;
+            }
+            for (size_t j = i; j < i + kBgzfGroup && j < blocks.size(); j++) {
+                const BgzfBlock &b = blocks[j];
+                size_t used = 0, made = 0;
+                if (lib.gzip_ex(d, in + b.in_off, b.in_len, buf + b.out_off, b.out_len, &used, &made) != 0 || made != b.out_len) { bad = 1; break; }
+            }
+            if (stream) {
+                std::lock_guard<std::mutex> lk(stream->mu);
+                done[g] = 1;
+                while (ready_group < n_groups && done[ready_group]) ready_group++;
+                stream->ready = ready_group < n_groups ? blocks[ready_group * kBgzfGroup].out_off : total;
+                stream->cv.notify_all();
+            }
+        }
+        lib.free_(d);
+        if (bad && stream) { std::lock_guard<std::mutex> g(stream->mu); stream->cv.notify_all(); }
+    };
+    std::vector<std::thread> th;
+    try { for (uint32_t t = 1; t < nt; t++) th.emplace_back(work); } catch (...) {}
+    work();
+    for (auto &t : th) t.join();
+    return bad.load();
+}
+
+int map_pgz_status(int r) { return r == 0 ? NTK_OK : (r == 2 ? NTK_ERR_UNSUPPORTED : (r == 3 ? NTK_ERR_NOMEM : NTK_ERR_PARSE)); }
+
+void fill_info(ntk_gunzip_info *info, uint32_t route, uint32_t nt, const ntk::PgzStats &st)
+{
+    if (!info) return;
+    info->route = route; info->threads = nt; info->chunks = st.chunks; info->chunks_dropped = st.chunks_dropped; info->members = st.members;
+    info->search_s = st.search_s; info->decode_s = st.decode_s; info->decode_busy_s = st.decode_busy_s; info->crc_s = st.crc_s;
+    info->marker_symbols = st.marker_symbols; info->chunks_deferred = st.chunks_deferred; info->resolve_busy_s = st.resolve_busy_s;
 }
 
 // The whole gzip file inflated into one buffer (every member, CRC-32 and ISIZE checked; reference: MultiGzDecoder,
@@ -423,39 +580,19 @@ bool bgzf_index(const uint8_t *in, uint64_t n, std::vector<BgzfBlock> *blocks, u
 //   2  an ordinary gzip stream, n_threads > 1: speculative parallel inflate (ntk_pgzip.cpp: chunks enter the stream at block
 //      boundaries with the 32 KiB before them as unknowns, resolved afterwards)
 //   3  the same decoder on one thread
-int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info)
+int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limit, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info)
 {
-    static const Deflate lib;
-    uint64_t limit = (uint64_t)16 << 30;
-    if (const char *e = getenv("NTK_GZ_INMEM_LIMIT_BYTES")) limit = strtoull(e, nullptr, 10);
     const uint32_t nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
     if (info) { memset(info, 0, sizeof(*info)); info->threads = nt; }
-    if (lib.ok) {   // BGZF: members inflate in parallel straight to their final offsets
+    if (deflate_lib()->ok) {   // BGZF: members inflate in parallel straight to their final offsets
         std::vector<BgzfBlock> blocks;
         uint64_t total = 0;
         if (bgzf_index(in, n, &blocks, &total)) {
             if (total > limit) return NTK_ERR_UNSUPPORTED;
             uint8_t *buf = ntk::pgz_alloc(total);
             if (!buf) return NTK_ERR_NOMEM;
-            std::atomic<int> bad{0};
-            std::atomic<size_t> next{0};
-            auto work = [&]() {
-                void *d = lib.alloc();
-                if (!d) { bad = 1; return; }
-                for (size_t i; !bad && (i = next.fetch_add(16)) < blocks.size();)   // 16 blocks (<= 1 MiB) per grab
-                    for (size_t j = i; j < i + 16 && j < blocks.size(); j++) {
-                        const BgzfBlock &b = blocks[j];
-                        size_t used = 0, made = 0;
-                        if (lib.gzip_ex(d, in + b.in_off, b.in_len, buf + b.out_off, b.out_len, &used, &made) != 0 ||
-                            made != b.out_len) { bad = 1; break; }
-                    }
-                lib.free_(d);
-            };
-            std::vector<std::thread> th;
-            try { for (uint32_t t = 1; t < nt; t++) th.emplace_back(work); } catch (...) {}
-            work();
-            for (auto &t : th) t.join();
-            if (bad) { ntk::pgz_free(buf, total); return NTK_ERR_PARSE; }
+            const int bad = bgzf_inflate(in, blocks, total, buf, nt, nullptr);
+            if (bad) { ntk::pgz_free(buf, total); return bad == 3 ? NTK_ERR_NOMEM : NTK_ERR_PARSE; }
             *out = buf; *out_n = total;
             if (info) { info->route = 1; info->chunks = (uint32_t)blocks.size(); info->members = (uint32_t)blocks.size(); }
             return NTK_OK;
@@ -463,19 +600,99 @@ int inflate_whole(const uint8_t *in, uint64_t n, uint32_t n_threads, uint8_t **o
     }
     ntk::PgzStats st;
     const int r = ntk::pgz_inflate(in, n, nt, limit, out, out_n, &st);
-    if (info) {
-        info->route = nt > 1 ? 2 : 3; info->chunks = st.chunks; info->chunks_dropped = st.chunks_dropped; info->members = st.members;
-        info->search_s = st.search_s; info->decode_s = st.decode_s; info->decode_busy_s = st.decode_busy_s; info->crc_s = st.crc_s;
-        info->marker_symbols = st.marker_symbols;
+    fill_info(info, nt > 1 ? 2 : 3, nt, st);
+    return map_pgz_status(r);
+}
+
+thread_local ntk_gunzip_info t_last_info;   // ntk_scan_file_info
+
+// A gzip file through the parallel producer WITHOUT holding its text: the inflater (route 1 or 2 above, on n_threads threads) runs beside
+// the parser threads, which take pieces of the text as it becomes final, copy the records into pinned batches (H2D copies and scans overlap
+// on the GPU's side as for any batch) and give the pages back.  BASELINE.json configs[4]: "CPU decompress overlapped with GPU k-mer via pinned
+// async copies"; the reference's arrangement is one zlib thread feeding the parser (src/parser/mod.rs:95-108).  Same errors as the reader:
+// every member is read and checked; truncated / corrupt data is NTK_ERR_PARSE (reported when the decoder gets there: batches scanned before
+// that have been added to the accumulators, as a caller of the reference's reader has processed the records before the Io error).
+int scan_gzip_streamed(ntk_ctx *ctx, const uint8_t *gz, uint64_t n, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads,
+                       uint64_t *n_records, uint64_t *n_bases)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    if (n_records) *n_records = 0;
+    if (n_bases) *n_bases = 0;
+    const uint32_t nt = n_threads > 64 ? 64 : n_threads;
+    ntk_params p_local = *p;   // NTK_FLAG_RESET: once for the whole scan, not per batch
+    if (p_local.flags & NTK_FLAG_RESET) { const int r = ntk_accum_reset(ctx); if (r != NTK_OK) return r; p_local.flags &= ~NTK_FLAG_RESET; }
+    ntk::PgzStream S;
+    S.window = ctx_option(ctx, NTK_OPT_GZ_STREAM_WINDOW_BYTES, (uint64_t)512 << 20);
+    if (S.window < ((uint64_t)8 << 20)) S.window = (uint64_t)8 << 20;
+    ntk_gunzip_info info;
+    memset(&info, 0, sizeof(info));
+    info.threads = nt; info.streamed = 1;
+    // the parsers are a fraction of the inflater's work (10 M reads: 0.75 core-seconds of parsing and packing against 4.8 of inflating,
+    // profiles/r05g); they sleep while no text is ready, so they are threads on top of the inflater's, not taken from them
+    uint32_t n_parse = nt / 4;
+    if (n_parse < 2) n_parse = 2;
+    if (n_parse > 8) n_parse = 8;
+    info.parse_threads = n_parse;
+    std::vector<BgzfBlock> blocks;
+    uint64_t total = 0;
+    const bool bgzf = deflate_lib()->ok && bgzf_index(gz, n, &blocks, &total);
+    int rc_inflate = 0;
+    ntk::PgzStats st;
+    std::thread producer;
+    uint8_t *bgzf_buf = nullptr;
+    if (bgzf) {
+        bgzf_buf = ntk::pgz_alloc(total);
+        if (!bgzf_buf) return NTK_ERR_NOMEM;
+        S.base = bgzf_buf;
+        info.route = 1; info.chunks = (uint32_t)blocks.size(); info.members = (uint32_t)blocks.size();
     }
-    return r == 0 ? NTK_OK : (r == 2 ? NTK_ERR_UNSUPPORTED : (r == 3 ? NTK_ERR_NOMEM : NTK_ERR_PARSE));
+    try {
+        producer = std::thread([&] {
+            if (bgzf) {
+                rc_inflate = bgzf_inflate(gz, blocks, total, bgzf_buf, nt, &S);
+                std::lock_guard<std::mutex> g(S.mu);
+                S.rc = rc_inflate == 4 ? 0 : rc_inflate; S.finished = true;
+                S.cv.notify_all();
+            } else {
+                // the address range reserved for the text: 4 TiB unless the option says otherwise (it is touched as it is written and given
+                // back behind the parsers; the inflater halves the reservation until the system grants it)
+                const uint64_t limit = ctx_option(ctx, NTK_OPT_GZ_INMEM_LIMIT_BYTES, (uint64_t)1 << 42);
+                rc_inflate = ntk::pgz_inflate_stream(gz, n, nt, limit, &S, &st);
+            }
+        });
+    } catch (...) { if (bgzf_buf) ntk::pgz_free(bgzf_buf, total); return NTK_ERR_NOMEM; }
+    StreamPieces src;
+    src.s = &S;
+    // pieces: small enough that the first batch leaves early and the parsers share the text evenly, large enough to amortise a reader each
+    src.target = batch_bytes < ((uint64_t)2 << 20) ? ((uint64_t)2 << 20) : (batch_bytes > ((uint64_t)16 << 20) ? ((uint64_t)16 << 20) : batch_bytes);
+    if (src.target > S.window / 4) src.target = S.window / 4;
+    int64_t first_ns = -1;
+    int rc = run_workers(ctx, &p_local, batch_bytes, n_parse, &src, n_records, n_bases, &first_ns);
+    if (rc != NTK_OK) {   // the parsers gave up: the inflater must not run on into memory nobody drains
+        std::lock_guard<std::mutex> g(S.mu);
+        S.cancel = true;
+        S.cv.notify_all();
+    }
+    producer.join();
+    if (!bgzf) fill_info(&info, 2, nt, st);
+    info.streamed = 1; info.parse_threads = n_parse;
+    info.peak_backlog_bytes = S.peak_backlog;
+    info.text_bytes = S.ready;
+    info.total_s = std::chrono::duration<double>(clk::now() - t0).count();
+    info.first_batch_s = first_ns < 0 ? 0.0 : (double)(first_ns - (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count()) * 1e-9;
+    t_last_info = info;
+    if (bgzf) ntk::pgz_free(bgzf_buf, total); else ntk::pgz_stream_release(&S);
+    if (rc_inflate != 0 && rc_inflate != 4) return bgzf ? (rc_inflate == 3 ? NTK_ERR_NOMEM : NTK_ERR_PARSE) : map_pgz_status(rc_inflate);   // (4: cancelled above)
+    return rc;
 }
 }  // namespace
 
 int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, uint64_t batch_bytes, uint32_t n_threads,
                            uint64_t *n_records, uint64_t *n_bases)
 {
-    if (!ctx || !path || !p) return NTK_ERR_BAD_ARG;
+    if (!ctx || !path || !p || batch_bytes < 1024 || n_threads < 1 || n_threads > 1024) return NTK_ERR_BAD_ARG;
+    memset(&t_last_info, 0, sizeof(t_last_info));
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return NTK_ERR_PARSE;
     struct stat st;
@@ -486,11 +703,16 @@ int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, 
     const uint8_t *data = (const uint8_t *)m;
     int rc;
     if (data[0] == 0x1F && data[1] == 0x8B) {
-        uint8_t *plain = nullptr; uint64_t plain_n = 0;
-        rc = inflate_whole(data, (uint64_t)st.st_size, n_threads, &plain, &plain_n, nullptr);
-        if (rc == NTK_OK) {
-            rc = scan_buffer_parallel_impl(ctx, plain, plain_n, p, batch_bytes, n_threads, n_records, n_bases, true);
-            ntk::pgz_free(plain, plain_n);
+        if (n_threads >= 2 && st.st_size >= 18) {
+            (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            rc = scan_gzip_streamed(ctx, data, (uint64_t)st.st_size, p, batch_bytes, n_threads, n_records, n_bases);
+        } else {   // one thread: inflate, then parse (nothing to overlap with)
+            uint8_t *plain = nullptr; uint64_t plain_n = 0;
+            rc = inflate_whole(data, (uint64_t)st.st_size, n_threads, ctx_option(ctx, NTK_OPT_GZ_INMEM_LIMIT_BYTES, (uint64_t)16 << 30), &plain, &plain_n, &t_last_info);
+            if (rc == NTK_OK) {
+                rc = scan_buffer_parallel_impl(ctx, plain, plain_n, p, batch_bytes, n_threads, n_records, n_bases, true);
+                ntk::pgz_free(plain, plain_n);
+            }
         }
     } else {
         rc = ntk_scan_buffer_parallel(ctx, data, (uint64_t)st.st_size, p, batch_bytes, n_threads, n_records, n_bases);
@@ -499,12 +721,19 @@ int ntk_scan_file_parallel(ntk_ctx *ctx, const char *path, const ntk_params *p, 
     return rc;
 }
 
+int ntk_scan_file_info(ntk_gunzip_info *info)
+{
+    if (!info) return NTK_ERR_BAD_ARG;
+    *info = t_last_info;
+    return NTK_OK;
+}
+
 int ntk_gunzip(const uint8_t *gz, uint64_t n, uint32_t n_threads, uint8_t **out, uint64_t *out_n, ntk_gunzip_info *info)
 {
     if (!gz || !out || !out_n) return NTK_ERR_BAD_ARG;
     *out = nullptr; *out_n = 0;
     if (n < 18 || gz[0] != 0x1F || gz[1] != 0x8B) return NTK_ERR_PARSE;
-    return inflate_whole(gz, n, n_threads, out, out_n, info);
+    return inflate_whole(gz, n, n_threads, (uint64_t)16 << 30, out, out_n, info);
 }
 
 void ntk_gunzip_free(uint8_t *out, uint64_t out_n) { ntk::pgz_free(out, out_n); }

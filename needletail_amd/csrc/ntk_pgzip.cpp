@@ -10,6 +10,9 @@
 #include <zlib.h>   // crc32_z / crc32_combine only
 
 #include <sys/mman.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -27,6 +30,8 @@ constexpr int kLitBits = 11, kDistBits = 9;        // primary table index bits
 constexpr uint32_t kWin = 32768;                   // deflate's window
 constexpr uint32_t kInvalid = 0x30;                // kind = sub-table link, 0 index bits: no such code
 constexpr uint64_t kNone = ~0ull;
+constexpr uint64_t kPending = ~0ull - 1;           // a chunk whose block-boundary search has not finished yet
+constexpr uint64_t kSpecCap = (uint64_t)96 << 20;  // output symbols a chunk may produce while it is not at the head of the chain (ordinary text: <= 4 MiB x ~6)
 enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3 };
 // table entry: bits 3:0 code bits to consume (link: index bits of the sub-table), 5:4 kind, 9:6 extra bits, 31:10 value (literal,
 // base length, base distance, or the sub-table's offset)
@@ -161,6 +166,7 @@ struct Block { uint8_t *p = nullptr; size_t cap = 0; };
 constexpr size_t kHuge = (size_t)2 << 20;
 bool block_alloc(Block &b, size_t bytes, bool reserve_only = false)
 {
+    if (bytes == 0 || bytes > ((size_t)1 << 46)) return false;   // (a limit of 2^64 - 1 must not wrap to a zero-byte mapping that "succeeds")
     bytes = (bytes + kHuge - 1) & ~(kHuge - 1);
     void *m = mmap(nullptr, bytes + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | (reserve_only ? MAP_NORESERVE : 0), -1, 0);
     if (m == MAP_FAILED) return false;
@@ -224,7 +230,7 @@ struct Out {
     void drop() { if (blk.p) pool->give(blk); base = nullptr; cap = 0; }
 };
 
-enum { kOk = 0, kCorrupt = 1, kTooLarge = 2, kNoMem = 3 };
+enum { kOk = 0, kCorrupt = 1, kTooLarge = 2, kNoMem = 3, kCancelled = 4 };
 
 template <class T>
 inline void copy_match(T *dst, uint32_t dist, uint32_t len)
@@ -408,6 +414,7 @@ struct Chunk {
     // results
     int status = kOk;
     bool done = false, dropped = false;
+    bool deferred = false, in_flight = false;   // deferred: it outgrew the cap of a chunk that is not at the chain's head and waits to be decoded there
     bool at_end = false;                // the chunk decoded to the end of the file
     uint32_t end_chunk = 0;             // else: index of the chunk whose start_bit it stopped at
     Out<uint16_t> o16;                  // marker-mode symbols (o16.base[0, kWin) = the marker prefix)
@@ -446,6 +453,8 @@ void decode_chunk(const uint8_t *in, uint64_t n, std::vector<Chunk> &chunks, uin
     Out<uint16_t> &o16 = c.o16;
     Out<uint8_t> &o8 = c.o8;
     o16.pool = pool; o8.pool = pool;
+    o16.pos = kWin; o8.pos = kWin;
+    c.members.clear(); c.member_starts.clear(); c.at_end = false; c.end_chunk = 0; c.min_marker = kWin; c.nsym = c.nbyt = 0;   // (a deferred chunk is decoded twice)
     bool byte_mode = c.trusted_start;
     size_t floor8 = kWin;                 // byte mode: first position a match may read (kWin = no history)
     size_t scanned = kWin, lastm = 0;     // marker mode: symbols scanned for markers so far, last marker seen (0 = none: positions start at kWin)
@@ -463,9 +472,18 @@ void decode_chunk(const uint8_t *in, uint64_t n, std::vector<Chunk> &chunks, uin
     while (status == kOk) {
         // block boundary: is this where a later chunk starts?
         if (!speculative_blocks && blocks > 0) {
+            // (the later chunks' starts are found while this chunk decodes: a start that is not known yet cannot stop it - if this decoder passes
+            // the place before the search reports it, it simply runs on to the next known start and that chunk's work is dropped)
             const uint64_t here = b.bit_pos();
-            while (next_chunk < chunks.size() && (chunks[next_chunk].start_bit == kNone || chunks[next_chunk].start_bit < here)) next_chunk++;
-            if (next_chunk < chunks.size() && chunks[next_chunk].start_bit == here) { c.end_chunk = next_chunk; break; }
+            uint32_t stop = 0;
+            for (uint32_t j = next_chunk; j < chunks.size(); j++) {
+                const uint64_t sb = __atomic_load_n(&chunks[j].start_bit, __ATOMIC_ACQUIRE);
+                if (sb == kPending) { if (chunks[j].byte_begin * 8 > here) break; continue; }
+                if (sb == kNone || sb < here) { if (j == next_chunk) next_chunk++; continue; }
+                if (sb == here) stop = j;
+                break;
+            }
+            if (stop) { c.end_chunk = stop; break; }
         }
         if (speculative_blocks && blocks >= speculative_blocks) break;
         b.refill();
@@ -578,7 +596,7 @@ uint64_t find_block(const uint8_t *in, uint64_t n, uint64_t from_byte, uint64_t 
     return found;
 }
 
-struct Crc {
+struct Crc {   // (one per process: crc_lib() below - the handle is never closed, so it is taken once)
     uint32_t (*fast)(uint32_t, const void *, size_t) = nullptr;
     Crc()
     {
@@ -592,6 +610,8 @@ struct Crc {
         return c;
     }
 };
+
+const Crc &crc_lib() { static const Crc c; return c; }
 
 template <class F>
 void run_parallel(uint32_t threads, F &&f)
@@ -625,43 +645,39 @@ void pgz_free(uint8_t *p, uint64_t n)
     if (p) munmap(p, (size_t)(((n ? n : 1) + 4095) & ~(uint64_t)4095));
 }
 
-int pgz_inflate(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limit, uint8_t **out, uint64_t *out_n, PgzStats *stats)
+namespace {
+
+// The decoder behind pgz_inflate (stream == nullptr: the whole output in one buffer, handed over at the end) and pgz_inflate_stream (the
+// output becomes readable as the chain advances; see ntk_pgzip.hpp).
+int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limit, uint8_t **out, uint64_t *out_n, PgzStats *stats, PgzStream *stream)
 {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    *out = nullptr; *out_n = 0;
+    if (out) { *out = nullptr; *out_n = 0; }
     PgzStats st;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     st.threads = n_threads;
+    if (limit > ((uint64_t)1 << 46)) limit = (uint64_t)1 << 46;   // ("no limit" spelled as 2^64 - 1 must not wrap the mapping's size)
     uint64_t off = 0;
     if (!skip_gzip_header(in, n, &off)) return kCorrupt;
     Pool pool;
-    // chunks of the compressed bytes: about sixteen per thread, 512 KiB .. 4 MiB each
+    // chunks of the compressed bytes: about sixteen per thread, 512 KiB .. 4 MiB each (thirty-two per thread, <= 2 MiB: 25 % less resident
+    // memory - a chunk in flight holds its text as 16-bit symbols - and 4 % slower, profiles/r06c/config5_phases3.txt)
     uint64_t chunk_bytes = n / ((uint64_t)n_threads * 16) + 1;
     if (chunk_bytes < (512u << 10)) chunk_bytes = 512u << 10;
     if (chunk_bytes > (4u << 20)) chunk_bytes = 4u << 20;
     const uint64_t n_chunks64 = n_threads == 1 ? 1 : (n - off + chunk_bytes - 1) / chunk_bytes;
+    if (n_chunks64 > 0x7FFFFFFFull) return kTooLarge;
     const uint32_t n_chunks = (uint32_t)(n_chunks64 < 1 ? 1 : n_chunks64);
-    std::vector<Chunk> chunks(n_chunks);
+    std::vector<Chunk> chunks;
+    try { chunks.resize(n_chunks); } catch (...) { return kNoMem; }
     chunks[0].byte_begin = off; chunks[0].start_bit = off * 8; chunks[0].trusted_start = true;
-    for (uint32_t i = 1; i < n_chunks; i++) chunks[i].byte_begin = off + (uint64_t)i * chunk_bytes;
-    // phase A: every later chunk looks for a block boundary in the first MiB of its own range (a stream without dynamic blocks - stored
-    // data, Z_FIXED - has none to find: its chunks fall to the one before them)
-    const auto tA = clk::now();
-    {
-        std::atomic<uint32_t> next{1};
-        run_parallel(n_threads < n_chunks ? n_threads : n_chunks, [&] {
-            for (uint32_t i; (i = next.fetch_add(1)) < n_chunks;) {
-                uint64_t end = i + 1 < n_chunks ? chunks[i + 1].byte_begin : n;
-                if (end > chunks[i].byte_begin + (1u << 20)) end = chunks[i].byte_begin + (1u << 20);
-                chunks[i].start_bit = find_block(in, n, chunks[i].byte_begin, end, &pool);
-            }
-        });
-    }
-    const auto tB = clk::now();
-    st.search_s = secs(tA, tB);
-    st.chunks = n_chunks;
+    for (uint32_t i = 1; i < n_chunks; i++) { chunks[i].byte_begin = off + (uint64_t)i * chunk_bytes; chunks[i].start_bit = kPending; }
+    // The boundary search (every later chunk looks for a block boundary in the first MiB of its own range; a stream without dynamic blocks -
+    // stored data, Z_FIXED - has none to find: its chunks fall to the one before them) is part of the pipeline below: a worker that takes
+    // chunk i for decoding searches its start first.  (Round 5 ran the search as a phase of its own before any decoding; with the progressive
+    // form that would delay the first ready byte by the search of the WHOLE file.)
     // the output: address space for the whole limit, touched as it is written (no growing, no copying); smaller if the system refuses
     Block fin;
     uint64_t fin_limit = limit;
@@ -673,25 +689,36 @@ int pgz_inflate(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limi
         }
         if (fin.cap < fin_limit) fin_limit = fin.cap;
     }
-    // phase B: one pipeline.  Workers decode chunks in index order (at most max_ahead chunks beyond the chain's head are in flight);
-    // whenever the chunk at the chain's head is done, its window is fixed (sequentially: <= 32 KiB of work), its place in the output is
-    // known and a resolve task for it is queued; resolve tasks go first.
-    const Crc crc;
-    std::mutex mu;
-    std::condition_variable cv;
+    // One pipeline.  Workers take chunks in index order (at most max_ahead chunks beyond the chain's head are in flight): boundary search, then
+    // decode; whenever the chunk at the chain's head is done, its window is fixed (sequentially: <= 32 KiB of work), its place in the output is
+    // known and a resolve task for it is queued; resolve tasks go first.  Progressive form: the head is not placed while more than
+    // stream->window bytes are placed and not consumed; [0, ready) = the resolved prefix.
+    const Crc &crc = crc_lib();
+    std::mutex own_mu;
+    std::condition_variable own_cv;
+    std::mutex &mu = stream ? stream->mu : own_mu;
+    std::condition_variable &cv = stream ? stream->cv : own_cv;
     std::deque<ResolveTask> rq;
     std::vector<CrcPiece> pieces;
     std::vector<std::pair<uint64_t, MemberEnd>> ends;   // absolute output offsets of the member ends
+    std::deque<std::pair<uint64_t, bool>> placed;       // (end offset, resolved) of the placed chunks beyond `ready`, in stream order
+    uint64_t ready = 0;
     uint32_t next_decode = 0, chain_cur = 0, resolving = 0;
-    const uint32_t max_ahead = n_threads * 2 + 2;
+    const uint32_t max_ahead = n_threads + n_threads / 2 + 2;   // (2 T + 2 until round 6: the symbol buffers of the chunks in flight are the run's largest resident item)
     uint64_t total = 0, avail = 0;
     std::vector<uint8_t> tail(kWin, 0);   // the kWin bytes before `total` (valid: the last `avail`)
     bool chain_done = false;
     int rc = kOk;
+    if (stream) { std::lock_guard<std::mutex> g(mu); stream->base = fin.p; stream->map = fin.p; stream->map_bytes = fin.cap; }
     auto advance_chain = [&]() {   // under mu
         while (rc == kOk && !chain_done && chain_cur < n_chunks && chunks[chain_cur].done) {
             Chunk &c = chunks[chain_cur];
             if (c.status != kOk) { rc = c.status; break; }
+            if (stream) {
+                const uint64_t backlog = total - stream->consumed;
+                if (backlog > stream->peak_backlog) stream->peak_backlog = backlog;
+                if (backlog > stream->window) break;   // the consumer's next cv.notify_all() brings a worker back here
+            }
             const uint64_t tot = c.nsym + c.nbyt;
             if (c.nsym && c.min_marker < kWin - avail) { rc = kCorrupt; break; }   // a match reaches back before the member's first byte
             if (total + tot > fin_limit) { rc = kTooLarge; break; }
@@ -716,11 +743,12 @@ int pgz_inflate(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limi
             avail = a < kWin ? a : kWin;
             total += tot;
             rq.push_back(t);
+            placed.push_back({total, false});
             st.decode_busy_s += c.busy_s; st.marker_symbols += c.nsym;
             if (c.at_end) { chain_done = true; break; }
             // chunks between this one and the one it stopped at were no boundaries (or had none): dropped
             for (uint32_t i = chain_cur + 1; i < c.end_chunk; i++) {
-                if (chunks[i].start_bit != kNone) st.chunks_dropped++;
+                if (chunks[i].start_bit != kNone && chunks[i].start_bit != kPending) st.chunks_dropped++;
                 chunks[i].dropped = true;
                 if (chunks[i].done) chunks[i].release();
             }
@@ -728,67 +756,147 @@ int pgz_inflate(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limi
         }
         if (rc == kOk && !chain_done && chain_cur >= n_chunks) rc = kCorrupt;
     };
-    auto resolve = [&](const ResolveTask &t) {
+    std::atomic<uint64_t> resolve_ns{0};
+    auto resolve = [&](const ResolveTask &t) -> int {   // kOk / kNoMem
+        const auto r0 = clk::now();
+        struct Timer { std::atomic<uint64_t> &acc; clk::time_point t0; ~Timer() { acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count(); } } timer{resolve_ns, r0};
         Chunk &c = chunks[t.chunk];
         uint8_t *dst = fin.p + t.out_off;
-        if (c.nsym) {
-            // one table look-up per symbol: 0..255 -> the byte, 32768 + w -> window byte w
-            std::vector<uint8_t> lut(2 * kWin);
-            for (uint32_t i = 0; i < 256; i++) lut[i] = (uint8_t)i;
-            memcpy(lut.data() + kWin, t.win, kWin);
-            const uint16_t *s = c.o16.base + kWin;
-            const uint8_t *L = lut.data();
-            for (size_t i = 0; i < c.nsym; i++) dst[i] = L[s[i]];
-        }
-        if (c.nbyt) memcpy(dst + c.nsym, c.o8.base + kWin, c.nbyt);
-        free(t.win);
-        // CRC-32 of what was just written (still in the cache), cut at the member ends inside the chunk
-        const uint64_t tot = c.nsym + c.nbyt;
         std::vector<CrcPiece> mine;
-        uint64_t at = 0;
-        for (size_t m = 0; m <= c.members.size(); m++) {
-            const uint64_t to = m < c.members.size() ? c.members[m].out_off : tot;
-            if (to > at) mine.push_back({t.out_off + at, to - at, crc.run(dst + at, (size_t)(to - at))});
-            at = to;
-        }
+        try {
+            if (c.nsym) {
+                // 0..255 -> the byte, 32768 + w -> window byte w.  Sixteen symbols at a time: a group without a marker is packed to bytes
+                // (SSE2, part of the x86-64 baseline), one with markers goes symbol by symbol through a table.  (FASTQ text keeps markers alive
+                // for the whole chunk - every header and every quality run copies from the record before it, back to the unknown window - so
+                // both paths matter: the table loop alone was a third of the inflater's CPU time, profiles/r06c.)
+                std::vector<uint8_t> lut(2 * kWin);
+                for (uint32_t i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+                memcpy(lut.data() + kWin, t.win, kWin);
+                const uint16_t *s = c.o16.base + kWin;
+                const uint8_t *L = lut.data();
+                size_t i = 0;
+#if defined(__SSE2__)
+                const __m128i hi = _mm_set1_epi16((short)0xFF00);
+                for (; i + 16 <= c.nsym; i += 16) {
+                    const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
+                    const __m128i any = _mm_and_si128(_mm_or_si128(a, b), hi);
+                    if (_mm_movemask_epi8(_mm_cmpeq_epi8(any, _mm_setzero_si128())) == 0xFFFF) {
+                        _mm_storeu_si128((__m128i *)(dst + i), _mm_packus_epi16(a, b));
+                    } else {
+                        for (int j = 0; j < 16; j++) dst[i + j] = L[s[i + j]];
+                    }
+                }
+#endif
+                for (; i < c.nsym; i++) dst[i] = L[s[i]];
+            }
+            if (c.nbyt) memcpy(dst + c.nsym, c.o8.base + kWin, c.nbyt);
+            // CRC-32 of what was just written (still in the cache), cut at the member ends inside the chunk
+            const uint64_t tot = c.nsym + c.nbyt;
+            uint64_t at = 0;
+            for (size_t m = 0; m <= c.members.size(); m++) {
+                const uint64_t to = m < c.members.size() ? c.members[m].out_off : tot;
+                if (to > at) mine.push_back({t.out_off + at, to - at, crc.run(dst + at, (size_t)(to - at))});
+                at = to;
+            }
+        } catch (...) { free(t.win); c.release(); return kNoMem; }
+        free(t.win);
+        const uint64_t end_off = t.out_off + c.nsym + c.nbyt;
         c.release();
         std::lock_guard<std::mutex> g(mu);
-        for (const CrcPiece &p : mine) pieces.push_back(p);
+        try { for (const CrcPiece &p : mine) pieces.push_back(p); } catch (...) { return kNoMem; }
+        for (auto &pl : placed) if (pl.first == end_off && !pl.second) { pl.second = true; break; }
+        while (!placed.empty() && placed.front().second) { ready = placed.front().first; placed.pop_front(); }
+        if (stream) stream->ready = ready;
+        return kOk;
     };
     const auto tC = clk::now();
+    std::atomic<uint64_t> search_ns{0};
     run_parallel(n_threads, [&] {
         std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            if (rc != kOk) break;
-            if (!rq.empty()) {
-                const ResolveTask t = rq.front();
-                rq.pop_front();
-                resolving++;
-                lk.unlock();
-                resolve(t);
-                lk.lock();
-                resolving--;
-                cv.notify_all();
-                continue;
+        try {
+            for (;;) {
+                if (stream && stream->cancel && rc == kOk) rc = kCancelled;
+                if (rc != kOk) break;
+                if (!rq.empty()) {
+                    const ResolveTask t = rq.front();
+                    rq.pop_front();
+                    resolving++;
+                    lk.unlock();
+                    const int r = resolve(t);
+                    lk.lock();
+                    resolving--;
+                    if (r != kOk && rc == kOk) rc = r;
+                    cv.notify_all();
+                    continue;
+                }
+                if (chain_done) { if (resolving == 0) break; cv.wait(lk); continue; }
+                if (stream && chain_cur < n_chunks && chunks[chain_cur].done) {   // a head that waited for the consumer
+                    advance_chain();
+                    if (rc != kOk || !rq.empty() || chain_done) { cv.notify_all(); continue; }
+                }
+                if (chain_cur < n_chunks && chunks[chain_cur].deferred && !chunks[chain_cur].in_flight) {
+                    // the head outgrew its cap as a speculative chunk: now that it is the head it decodes against the whole limit (nothing
+                    // else can be placed before it anyway)
+                    Chunk &c = chunks[chain_cur];
+                    const uint32_t i = chain_cur;
+                    c.deferred = false; c.in_flight = true;
+                    lk.unlock();
+                    decode_chunk(in, n, chunks, i, fin_limit, 0, &pool);
+                    lk.lock();
+                    c.in_flight = false; c.done = true;
+                    st.chunks_deferred++;
+                    advance_chain();
+                    cv.notify_all();
+                    continue;
+                }
+                if (next_decode < n_chunks && next_decode < chain_cur + max_ahead) {
+                    const uint32_t i = next_decode++;
+                    Chunk &c = chunks[i];
+                    if (c.dropped) { c.done = true; continue; }
+                    c.in_flight = true;
+                    const bool is_head = i == chain_cur;
+                    lk.unlock();
+                    if (i > 0) {
+                        const auto s0 = clk::now();
+                        uint64_t end = i + 1 < n_chunks ? chunks[i + 1].byte_begin : n;
+                        if (end > c.byte_begin + (1u << 20)) end = c.byte_begin + (1u << 20);
+                        const uint64_t sb = find_block(in, n, c.byte_begin, end, &pool);
+                        search_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - s0).count();
+                        lk.lock();
+                        __atomic_store_n(&c.start_bit, sb, __ATOMIC_RELEASE);   // (read by the decoders of earlier chunks at their block boundaries)
+                        const bool skip = sb == kNone || c.dropped;
+                        if (skip) { c.done = true; c.dropped = true; c.in_flight = false; continue; }
+                        lk.unlock();
+                    }
+                    // A chunk that is not at the head of the chain decodes against a cap: high-ratio data (or a false block start decoding
+                    // garbage) would otherwise let every one of the 2 T + 2 chunks in flight grow towards the global limit.  One that
+                    // outgrows the cap gives its buffers back and is decoded again when it is the head.
+                    const uint64_t cap = (is_head || fin_limit < kSpecCap) ? fin_limit : kSpecCap;
+                    decode_chunk(in, n, chunks, i, cap, 0, &pool);
+                    lk.lock();
+                    c.in_flight = false;
+                    if (c.status == kTooLarge && cap < fin_limit && !c.dropped) {
+                        c.status = kOk; c.deferred = true;
+                        cv.notify_all();
+                        continue;
+                    }
+                    c.done = true;
+                    if (c.dropped) c.release();
+                    advance_chain();
+                    cv.notify_all();
+                    continue;
+                }
+                cv.wait(lk);
             }
-            if (chain_done) { if (resolving == 0) break; cv.wait(lk); continue; }
-            if (next_decode < n_chunks && next_decode < chain_cur + max_ahead) {
-                const uint32_t i = next_decode++;
-                Chunk &c = chunks[i];
-                if (c.start_bit == kNone || c.dropped) { c.done = true; c.dropped = true; continue; }
-                lk.unlock();
-                decode_chunk(in, n, chunks, i, fin_limit, 0, &pool);
-                lk.lock();
-                c.done = true;
-                if (c.dropped) c.release();
-                advance_chain();
-                cv.notify_all();
-                continue;
-            }
-            cv.wait(lk);
+        } catch (...) {   // bad_alloc in a container: an error of the run, not of the process
+            if (!lk.owns_lock()) lk.lock();
+            if (rc == kOk) rc = kNoMem;
         }
         cv.notify_all();
     });
+    st.search_s = (double)search_ns.load() * 1e-9 / (double)n_threads;   // (summed over the workers; as wall seconds of n_threads)
+    st.chunks = n_chunks;
+    st.resolve_busy_s = (double)resolve_ns.load() * 1e-9;
     st.decode_s = secs(tC, clk::now());
     for (ResolveTask &t : rq) free(t.win);
     for (Chunk &c : chunks) c.release();
@@ -810,13 +918,43 @@ int pgz_inflate(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limi
         if (rc == kOk && (pi != pieces.size() || mstart != total)) rc = kCorrupt;   // output after the last member's trailer: cannot be
     }
     st.crc_s = secs(tD, clk::now());
+    if (stats) *stats = st;
+    if (stream) {   // the mapping stays (the consumer may still be reading): pgz_stream_release
+        std::lock_guard<std::mutex> g(mu);
+        stream->rc = rc; stream->finished = true;
+        cv.notify_all();
+        return rc;
+    }
     if (rc != kOk) { block_free(fin); return rc; }
     // give back the address space that was not needed
     const size_t keep = (size_t)(((total ? total : 1) + 4095) & ~(uint64_t)4095);
     if (keep < fin.cap) munmap(fin.p + keep, fin.cap - keep);
     *out = fin.p; *out_n = total;
-    if (stats) *stats = st;
     return kOk;
+}
+
+}  // namespace
+
+int pgz_inflate(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limit, uint8_t **out, uint64_t *out_n, PgzStats *stats)
+{
+    return inflate_impl(in, n, n_threads, limit, out, out_n, stats, nullptr);
+}
+
+int pgz_inflate_stream(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limit, PgzStream *s, PgzStats *stats)
+{
+    if (!s) return kCorrupt;
+    const int rc = inflate_impl(in, n, n_threads, limit, nullptr, nullptr, stats, s);
+    if (!s->finished) {   // an early return (bad header, no memory for the mapping): the consumer must hear of it too
+        std::lock_guard<std::mutex> g(s->mu);
+        s->rc = rc; s->finished = true;
+        s->cv.notify_all();
+    }
+    return rc;
+}
+
+void pgz_stream_release(PgzStream *s)
+{
+    if (s && s->map) { munmap(s->map, (size_t)s->map_bytes); s->map = nullptr; s->base = nullptr; s->map_bytes = 0; }
 }
 
 }  // namespace ntk

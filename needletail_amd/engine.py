@@ -59,6 +59,11 @@ class Context:
         """ntk_ctx_set_option: test / A-B support (chunk sizes, minimizer routes switched off); value 0 = the default."""
         L.check(L.lib().ntk_ctx_set_option(self._h, option, value), "ntk_ctx_set_option")
 
+    def get_option(self, option: int) -> int:
+        v = C.c_uint64(0)
+        L.check(L.lib().ntk_ctx_get_option(self._h, option, C.byref(v)), "ntk_ctx_get_option")
+        return int(v.value)
+
     def enable_timing(self, on: bool = True):
         L.check(L.lib().ntk_ctx_enable_timing(self._h, int(on)), "ntk_ctx_enable_timing")
 

@@ -215,9 +215,9 @@ def parse_fastx_string(content) -> FastxReader:
 
 def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int = 0, batch_bytes: int = 16 << 20, w: int = 0,
                        data: bytes = None, quality_cutoff: int = 0, streaming_fallback: bool = True) -> dict:
-    """scan_file with one parser thread per file range.  Plain FASTA/FASTQ directly; a gzip file is inflated into memory first
-    (libdeflate; block gzip by all threads) and falls back to the streaming scan_file when that is not possible.
-    `data` scans an in-memory plain-text buffer instead of a path."""
+    """scan_file with parser threads that take pieces of the text on demand.  Plain FASTA/FASTQ directly; a gzip file is inflated by all
+    threads WHILE the parsers consume the text (bounded memory, any size; out["gzip"] = what the front-end did: route, peak backlog, time of
+    the first batch).  `data` scans an in-memory plain-text buffer instead of a path."""
     import os
     from .engine import result_to_dict  # noqa: F401
     threads = threads or min(os.cpu_count() or 1, 32)  # measured best 16-32 on a 256-thread host (tools/pipeline_bench.py)
@@ -234,6 +234,10 @@ def scan_file_parallel(ctx, path, k: int, path_kind: int, pre: int, threads: int
     L.check(rc, "ntk_scan_file_parallel")
     out = ctx.accum_read()
     out["n_records"], out["n_bases"] = int(nrec.value), int(nb.value)
+    if data is None:
+        info = L.GunzipInfo()
+        L.lib().ntk_scan_file_info(C.byref(info))
+        out["gzip"] = info.as_dict()
     return out
 
 

@@ -606,6 +606,124 @@ def test_bit_reverse_complement_and_canonical_kats(ctx):
             assert (int(can[i]), bool(flg[i])) == O.bit_canonical(int(v[i]), k)
 
 
+def _fastq_text(host: np.ndarray, n_reads: int, L: int, seed: int) -> bytes:
+    """FASTQ text of synthetic reads (host = the packed batch layout: L bases + a break byte per read) with random qualities, so that a
+    zlib-6 stream of it is made of many dynamic blocks and is not tiny."""
+    rng = np.random.default_rng(seed)
+    seqs = host.reshape(n_reads, L + 1)[:, :L]
+    hdr = np.frombuffer(b"@r%08d\n" % 0, dtype=np.uint8)
+    rec = np.empty((n_reads, len(hdr) + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, : len(hdr)] = hdr
+    idx = np.arange(n_reads)
+    for d in range(8):
+        rec[:, 2 + 7 - d] = 48 + (idx // 10**d) % 10
+    o = len(hdr)
+    rec[:, o: o + L] = seqs
+    rec[:, o + L: o + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, o + L + 3: o + 2 * L + 3] = rng.integers(33, 74, (n_reads, L), dtype=np.uint8)
+    rec[:, -1] = 10
+    return rec.tobytes()
+
+
+def test_gzip_file_streamed_through_the_parallel_producer(ctx, tmp_path):
+    """BASELINE.json configs[4] on its fast route: a >= 64 MB ONE-member zlib-6 FASTQ through ntk_scan_file_parallel -
+    speculative parallel inflate (route 2) consumed WHILE it runs by the parser threads -> pinned batches -> H2D -> fused (21, 11)
+    minimizers / the k = 21 scan, against the oracle on the plain text.  Also: a small window (the inflater waits for the parsers all the
+    time), several members, block gzip, a truncated and a corrupt stream (reference src/parser/mod.rs:95-108: MultiGzDecoder reads every
+    member, truncation is an error), and a record longer than the window."""
+    import zlib
+    from needletail_amd import _lib as NL2
+    def gzip_member(data: bytes, level: int) -> bytes:
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+    n_reads, L = 410_000, 150
+    host = O.synth_reads(0x5EED0002, 0, n_reads, L, 2)
+    text = _fastq_text(host, n_reads, L, 64)
+    z = gzip_member(text, 6)
+    assert len(z) >= 64 << 20, len(z)
+    gz = tmp_path / "c2_prefix.fq.gz"
+    gz.write_bytes(z)
+    def minimizers_oracle(buf: np.ndarray, parts: int = 8) -> dict:   # read-aligned parts on threads (the C oracle runs outside the GIL): windows never span reads
+        from concurrent.futures import ThreadPoolExecutor
+        per = (n_reads + parts - 1) // parts * (L + 1)
+        with ThreadPoolExecutor(parts) as ex:
+            rs = list(ex.map(lambda i: O.minimizers_reduce(buf[i * per: (i + 1) * per].tobytes(), 21, 11, True, True), range(parts)))
+        tot = {key: sum(r[key] for r in rs) for key in ("n_total", "n_fwd", "n_rc")}
+        tot["sum"] = sum(r["sum"] for r in rs) & (2**64 - 1)
+        tot["xor"] = 0
+        for r in rs: tot["xor"] ^= r["xor"]
+        tot["hist"] = sum(r["hist"] for r in rs)
+        return tot
+    want_min = minimizers_oracle(host)
+    want_k = O.reduce_fused(host, 21, True, True, True)
+    try:
+        for window in (0, 8 << 20):
+            ctx.set_option(NL2.OPT_GZ_STREAM_WINDOW_BYTES, window)
+            st = nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=16, batch_bytes=4 << 20, w=11)
+            g = st["gzip"]
+            assert (g["route"], g["streamed"], g["members"]) == (2, 1, 1) and g["chunks"] >= 16 and g["text_bytes"] == len(text), g
+            assert g["peak_backlog_bytes"] <= (window or (512 << 20)) + (128 << 20), g      # the window + one chunk's text
+            assert st["n_records"] == n_reads and st["n_bases"] == n_reads * L
+            assert_stats_equal(st, want_min, ("streamed gzip, (21, 11) minimizers", window))
+            assert 0 < g["first_batch_s"] < g["total_s"]
+        ctx.set_option(NL2.OPT_GZ_STREAM_WINDOW_BYTES, 0)
+        st = nt.scan_file_parallel(ctx, str(gz), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=5, batch_bytes=1 << 20)
+        assert st["gzip"]["route"] == 2 and st["gzip"]["streamed"] == 1
+        assert_stats_equal(st, want_k, "streamed gzip, k = 21")
+        # one thread: inflate, then parse (route 3, not streamed)
+        small_reads = 30_000
+        small_text = _fastq_text(host[: small_reads * (L + 1)], small_reads, L, 65)
+        small_want = O.reduce_fused(host[: small_reads * (L + 1)], 21, True, True, True)
+        one = tmp_path / "small.fq.gz"
+        one.write_bytes(gzip_member(small_text, 6))
+        st = nt.scan_file_parallel(ctx, str(one), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=1, batch_bytes=1 << 18)
+        assert (st["gzip"]["route"], st["gzip"]["streamed"]) == (3, 0)
+        assert_stats_equal(st, small_want, "one thread")
+        # several members (cut at record boundaries and in the middle of a record), and block gzip
+        rec_len = len(small_text) // small_reads
+        cuts = [0, 7000 * rec_len, 7000 * rec_len + 40, 19_000 * rec_len + 200, len(small_text)]
+        multi = tmp_path / "multi.fq.gz"
+        multi.write_bytes(b"".join(gzip_member(small_text[a:b], lvl) for (a, b), lvl in zip(zip(cuts, cuts[1:]), (6, 1, 9, 4))))
+        st = nt.scan_file_parallel(ctx, str(multi), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=6, batch_bytes=1 << 18)
+        assert (st["gzip"]["route"], st["gzip"]["streamed"], st["gzip"]["members"]) == (2, 1, 4)
+        assert_stats_equal(st, small_want, "four members")
+        try:
+            import ctypes
+            ctypes.CDLL("libdeflate.so.0")
+            bg = tmp_path / "blocks.fq.gz"
+            bg.write_bytes(bgzf_compress(small_text, block=60000))
+            ctx.set_option(NL2.OPT_GZ_STREAM_WINDOW_BYTES, 8 << 20)
+            st = nt.scan_file_parallel(ctx, str(bg), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=6, batch_bytes=1 << 18)
+            assert (st["gzip"]["route"], st["gzip"]["streamed"]) == (1, 1) and st["gzip"]["text_bytes"] == len(small_text)
+            assert_stats_equal(st, small_want, "block gzip, streamed")
+        except OSError:
+            pass
+        ctx.set_option(NL2.OPT_GZ_STREAM_WINDOW_BYTES, 0)
+        # truncated / corrupt: NTK_ERR_PARSE, whatever the decoder had delivered before it got there
+        zs = one.read_bytes()
+        for name, bad in (("cut in the middle", z[: len(z) // 2]), ("trailer cut", z[:-5]), ("small, cut", zs[: len(zs) * 2 // 3]),
+                          ("bit flip", z[: len(z) // 3] + bytes([z[len(z) // 3] ^ 0x10]) + z[len(z) // 3 + 1:]),
+                          ("last member cut", multi.read_bytes()[:-9])):
+            badf = tmp_path / "bad.fq.gz"
+            badf.write_bytes(bad)
+            with pytest.raises(nt.NtkError) as e:
+                nt.scan_file_parallel(ctx, str(badf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=8, batch_bytes=1 << 20, streaming_fallback=False)
+            assert e.value.status == 8, name
+        # a record longer than the window (a 20 MB contig against an 8 MiB window): the window grows instead of the run stalling
+        rng = np.random.default_rng(9)
+        contig = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20 << 20)].tobytes()
+        fa_text = b">short\nACGTACGTACGTACGTACGTACGTACGT\n>long\n" + contig + b"\n>tail\nTTTTTTTTTTTTTTTTTTTTTTTTTGGGG\n"
+        fa = tmp_path / "contig.fa.gz"
+        fa.write_bytes(gzip_member(fa_text, 1))
+        ctx.set_option(NL2.OPT_GZ_STREAM_WINDOW_BYTES, 8 << 20)
+        st = nt.scan_file_parallel(ctx, str(fa), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=4, batch_bytes=1 << 20)
+        recs = [b"ACGTACGTACGTACGTACGTACGTACGT", contig, b"TTTTTTTTTTTTTTTTTTTTTTTTTGGGG"]
+        assert st["n_records"] == 3
+        assert_stats_equal(st, O.reduce_records(recs, 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE), "a record longer than the window")
+    finally:
+        ctx.set_option(NL2.OPT_GZ_STREAM_WINDOW_BYTES, 0)
+
+
 @pytest.mark.parametrize("k,w", [(21, 11), (5, 3), (31, 1), (16, 20)])
 def test_windowed_minimizers_reduce(ctx, k, w):
     buf = O.synth_reads(0x5EED0005, 3, 300, 150, 6).tobytes()

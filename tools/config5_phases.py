@@ -53,9 +53,24 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     open(path, "wb").write(gz)
     tpath = os.path.join(d, "c5.fastq")
     open(tpath, "wb").write(text)
-    for bb in (4 << 20, 8 << 20):
-        t, ts = best(lambda: nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=bb, w=w, streaming_fallback=False))
-        print(f"gz file   -> scan_file_parallel, batch {bb >> 20} MiB: {t:.3f} s = {reads * RL / t / 1e9:.2f} Gbases/s  {['%.3f' % x for x in ts]}", flush=True)
+    def rss_mb():
+        return int(next(l for l in open("/proc/self/status") if l.startswith("VmRSS")).split()[1]) / 1024
+    def hwm_mb():
+        return int(next(l for l in open("/proc/self/status") if l.startswith("VmHWM")).split()[1]) / 1024
+    last = {}
+    def run_gz(bb, threads):
+        try: open("/proc/self/clear_refs", "w").write("5")   # reset the resident-set high-water mark
+        except OSError: pass
+        r0 = rss_mb()
+        st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=threads, batch_bytes=bb, w=w, streaming_fallback=False)
+        last.update(st["gzip"]); last["rss_peak_above_start_MB"] = round(hwm_mb() - r0, 1)
+    for threads in sorted({cpus, cpus + 4, 2 * cpus}):
+        for bb in (4 << 20, 8 << 20):
+            t, ts = best(lambda: run_gz(bb, threads))
+            print(f"gz file   -> scan_file_parallel (streamed), {threads} inflate threads + {last['parse_threads']} parsers, batch {bb >> 20} MiB: {t:.3f} s = {reads * RL / t / 1e9:.2f} Gbases/s  "
+                  f"{['%.3f' % x for x in ts]}  route {last['route']} streamed {last['streamed']} first batch after {last['first_batch_s']:.3f} s, peak backlog {last['peak_backlog_bytes'] / 2**20:.0f} MiB, "
+                  f"peak RSS above start {last['rss_peak_above_start_MB']:.0f} MB, chunks {last['chunks']} dropped {last['chunks_dropped']} deferred {last['chunks_deferred']}, "
+                  f"decode cpu {last['decode_busy_s']:.2f} s, resolve cpu {last['resolve_busy_s']:.2f} s, search {last['search_s']:.3f} s", flush=True)
     t, ts = best(lambda: nt.scan_file_parallel(ctx, tpath, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=4 << 20, w=w))
     print(f"text file -> scan_file_parallel (mmap of the page cache): {t:.3f} s = {reads * RL / t / 1e9:.2f} Gbases/s  {['%.3f' % x for x in ts]}", flush=True)
     t, ts = best(lambda: nt.scan_file_parallel(ctx, None, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=4 << 20, w=w, data=text))

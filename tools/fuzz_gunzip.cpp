@@ -4,6 +4,7 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined tools/fuzz_gunzip.cpp -lz -ldl -lpthread [iterations]
 #include "../needletail_amd/csrc/ntk_pgzip.cpp"
 #include <random>
+#include <thread>
 #include <string>
 
 static std::string deflate_gz(const std::string &t, int level, int strategy, size_t flush_every, std::mt19937_64 &rng)
@@ -69,8 +70,47 @@ int main(int argc, char **argv)
         if (only >= 0 && it != only) continue;
         if (dump) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(z.data(), 1, z.size(), f); fclose(f); } fprintf(stderr, "it %d: %zu bytes of gzip, %zu of text, mutation %d, %d member(s), %u threads\n", it, z.size(), whole.size(), mut, members, threads); }
         uint8_t *out = nullptr; uint64_t out_n = 0; ntk::PgzStats st;
-        const int rc = ntk::pgz_inflate((const uint8_t *)z.data(), z.size(), threads, (uint64_t)64 << 20, &out, &out_n, &st);
+        int rc;
+        const bool streamed = rng() % 3 == 0;   // every third stream through the progressive form, read by a consumer thread as it grows
+        ntk::PgzStream S;
+        std::string taken;
+        if (streamed) {
+            S.window = (uint64_t)(1 + rng() % 6) << 18;   // 256 KiB .. 1.5 MiB: the decoder waits for the consumer all the time
+            const uint64_t step = 1 + rng() % 300000;
+            const bool give_up = mut > 1 && rng() % 8 == 0;   // sometimes the consumer walks away in the middle
+            std::thread consumer([&] {
+                std::unique_lock<std::mutex> lk(S.mu);
+                uint64_t cur = 0;
+                for (;;) {
+                    if (S.ready > cur) {
+                        const uint64_t to = std::min(S.ready, cur + step);
+                        taken.append((const char *)S.base + cur, (size_t)(to - cur));
+                        if (to >= 4096) madvise((void *)S.base, (size_t)((to - 4096) & ~(uint64_t)4095), MADV_DONTNEED);   // what was read may vanish
+                        cur = to; S.consumed = cur;
+                        if (give_up && cur > step) { S.cancel = true; S.cv.notify_all(); return; }
+                        S.cv.notify_all();
+                        continue;
+                    }
+                    if (S.finished) return;
+                    S.cv.wait(lk);
+                }
+            });
+            rc = ntk::pgz_inflate_stream((const uint8_t *)z.data(), z.size(), threads, (uint64_t)64 << 20, &S, &st);
+            consumer.join();
+            if (rc == 4) rc = 1;   // cancelled by the consumer: counts as rejected
+            if (rc == 0) {   // hand the text over in the other form's shape
+                out_n = taken.size();
+                out = ntk::pgz_alloc(out_n);
+                if (out_n) memcpy(out, taken.data(), out_n);
+                if (S.ready != out_n) { fprintf(stderr, "stream: ready %llu, taken %llu (it %d)\n", (unsigned long long)S.ready, (unsigned long long)out_n, it); return 1; }
+            }
+            ntk::pgz_stream_release(&S);
+        } else
+            rc = ntk::pgz_inflate((const uint8_t *)z.data(), z.size(), threads, (uint64_t)64 << 20, &out, &out_n, &st);
         bytes += z.size();
+        if (rc == 2 && whole.size() <= ((uint64_t)64 << 20) && mut == 2) {   // a truncated stream is an error of the data, never "too large"
+            fprintf(stderr, "truncated stream reported as too large: it %d threads %u\n", it, threads); return 1;
+        }
         if (rc == 0) {
             const bool same = out_n == whole.size() && (out_n == 0 || memcmp(out, whole.data(), out_n) == 0);
             if (mut <= 1 && !same) { fprintf(stderr, "MISMATCH it %d threads %u (valid stream)\n", it, threads); return 1; }
