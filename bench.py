@@ -580,9 +580,10 @@ def bgzf_members(text, threads, block=60000):
 
 def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
     """BASELINE.json configs[4] end to end: the first 10 M reads of C2 as FASTQ text, ONE gzip member at zlib level 6,
-    as a file -> inflate on the host's cores -> parallel record parser -> pinned batches -> overlapped H2D + fused (21, 11) minimizers;
-    the result must equal the accumulators of the resident minimizer run over the same reads.  Routes: (a) the ordinary .gz through
-    ntk_scan_file_parallel (speculative parallel inflate of the one deflate stream, all granted CPUs), (b) the same file through the
+    as a file -> inflate on the host's cores, the parser threads taking the text while it is inflated -> pinned batches -> overlapped H2D +
+    fused (21, 11) minimizers; the result must equal the accumulators of the resident minimizer run over the same reads.  Routes: (a) the
+    ordinary .gz through ntk_scan_file_parallel (speculative parallel inflate of the one deflate stream, all granted CPUs, streamed: bounded
+    memory), (b) the same file through the
     streaming reader (zlib on one thread: what the reference does, src/parser/mod.rs:95-108; a 1 M-read sample), (c) block gzip
     (bgzip-style members).  Plus ntk_gunzip alone per thread count."""
     import ctypes as C
@@ -615,17 +616,34 @@ def config5_gzip_minimizers(ctx, nt, text, k21_seq, reads, read_len):
         path = os.path.join(d, "c5.fastq.gz")
         with open(path, "wb") as f:
             f.write(gz)
-        best = None
-        for _ in range(2):
+        best, ginfo, rss_peak, all_s = None, None, None, []
+
+        def status_mb(key):
+            return int(next(l for l in open("/proc/self/status") if l.startswith(key)).split()[1]) / 1024
+        for _ in range(3):
+            try:
+                open("/proc/self/clear_refs", "w").write("5")   # reset VmHWM: the resident-set peak of THIS call
+            except OSError:
+                pass
+            rss0 = status_mb("VmRSS")
             t0 = time.perf_counter()
             st = nt.scan_file_parallel(ctx, path, k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=cpus, batch_bytes=8 << 20, w=w, streaming_fallback=False)
             dt = time.perf_counter() - t0
             if not (stats_equal(st, want) and st["n_records"] == reads):
                 raise SystemExit("secondary: config 5 (gzip + minimizers) differs from the resident minimizer run")
-            best = dt if best is None else min(best, dt)
-        line["plain_gz_parallel_inflate"] = {"call": "ntk_scan_file_parallel", "inflate_threads": cpus, "parser_threads": cpus, "seconds": round(best, 3),
+            all_s.append(round(dt, 3))
+            if best is None or dt < best:
+                best, ginfo, rss_peak = dt, st["gzip"], status_mb("VmHWM") - rss0
+        line["plain_gz_parallel_inflate"] = {"call": "ntk_scan_file_parallel (the text is consumed WHILE it is inflated)", "inflate_threads": cpus,
+                                             "parser_threads": ginfo["parse_threads"], "seconds": round(best, 3), "seconds_of_three_calls_back_to_back": all_s,
                                              "Gbases_s": round(reads * read_len / best / 1e9, 3), "text_GB_s": round(len(text) / best / 1e9, 2),
-                                             "equal_to_resident_run": True}
+                                             "equal_to_resident_run": True, "route": ginfo["route"], "streamed": ginfo["streamed"],
+                                             "first_batch_submitted_after_s": round(ginfo["first_batch_s"], 4),
+                                             "peak_text_waiting_for_a_parser_MB": round(ginfo["peak_backlog_bytes"] / 1e6, 1),
+                                             "peak_rss_above_call_start_MB": round(rss_peak, 1),
+                                             "peak_rss_note": "includes the pages of the mmap-ed .gz file the call touched (its size: gzip_bytes)",
+                                             "chunks": ginfo["chunks"], "chunks_dropped": ginfo["chunks_dropped"], "chunks_deferred": ginfo["chunks_deferred"],
+                                             "decode_cpu_s": round(ginfo["decode_busy_s"], 3), "resolve_cpu_s": round(ginfo["resolve_busy_s"], 3)}
         # the inflate alone, per thread count (the whole file for 1 and all granted CPUs, a 2 M-read member for the ones between)
         table = []
         dt, n_out, info = gunzip(gz, cpus)

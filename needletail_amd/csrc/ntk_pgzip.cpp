@@ -191,6 +191,23 @@ bool block_grow(Block &b, size_t bytes)
 }
 void block_free(Block &b) { if (b.p) munmap(b.p, b.cap); b.p = nullptr; b.cap = 0; }
 
+// Unmapping what a run touched is not free - the symbol buffers of the chunks (~1 GB resident at 16 threads) and the page tables of the text's
+// range took 60 - 70 ms of a 370 ms configs[4] call when they were unmapped before the call returned (profiles/r06d).  The results are complete
+// by then; the mappings go on a detached thread.
+void release_async(std::vector<Block> &&blocks)
+{
+    if (blocks.empty()) return;
+    try {
+        // MADV_DONTNEED first: giving the pages back is the expensive part and only needs the address space's lock shared; the unmap that
+        // follows holds it exclusively (every page fault of a run that has started meanwhile waits for it) but finds nothing left to free
+        std::thread([b = std::move(blocks)]() mutable {
+            for (Block &x : b) { if (x.p) (void)madvise(x.p, x.cap, MADV_DONTNEED); block_free(x); }
+        }).detach();
+    } catch (...) {
+        for (Block &x : blocks) block_free(x);
+    }
+}
+
 struct Pool {
     std::mutex mu;
     std::vector<Block> free_;
@@ -208,7 +225,7 @@ struct Pool {
         return b;
     }
     void give(Block &b) { if (!b.p) return; std::lock_guard<std::mutex> g(mu); free_.push_back(b); b = Block(); }
-    ~Pool() { for (Block &b : free_) block_free(b); }
+    ~Pool() { release_async(std::move(free_)); }
 };
 
 // growable output of symbols of type T with a 32 KiB prefix in front (the window: markers, or the bytes carried over)
@@ -647,6 +664,9 @@ void pgz_free(uint8_t *p, uint64_t n)
 
 namespace {
 
+std::mutex g_text_mu;
+Block g_text;                 // the text range of the last streamed run, kept for the next one (pgz_stream_release)
+
 // The decoder behind pgz_inflate (stream == nullptr: the whole output in one buffer, handed over at the end) and pgz_inflate_stream (the
 // output becomes readable as the chain advances; see ntk_pgzip.hpp).
 int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t limit, uint8_t **out, uint64_t *out_n, PgzStats *stats, PgzStream *stream)
@@ -681,7 +701,12 @@ int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t lim
     // the output: address space for the whole limit, touched as it is written (no growing, no copying); smaller if the system refuses
     Block fin;
     uint64_t fin_limit = limit;
-    {
+    if (stream) {   // the range a previous streamed run left behind, if it is large enough (every byte is written before it is read: what
+                    // the earlier run left in it - the pages at its pieces' edges - is simply overwritten)
+        std::lock_guard<std::mutex> g(g_text_mu);
+        if (g_text.p && g_text.cap >= limit) { fin = g_text; g_text = Block(); }
+    }
+    if (!fin.p) {
         uint64_t want = limit < ((uint64_t)1 << 20) ? ((uint64_t)1 << 20) : limit;
         while (!block_alloc(fin, (size_t)want, true)) {
             if (want <= ((uint64_t)256 << 20)) return kNoMem;
@@ -954,7 +979,18 @@ int pgz_inflate_stream(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64
 
 void pgz_stream_release(PgzStream *s)
 {
-    if (s && s->map) { munmap(s->map, (size_t)s->map_bytes); s->map = nullptr; s->base = nullptr; s->map_bytes = 0; }
+    if (!s || !s->map) return;
+    Block b;
+    b.p = s->map; b.cap = (size_t)s->map_bytes;
+    s->map = nullptr; s->base = nullptr; s->map_bytes = 0;
+    // The range is address space (its pages went back behind the parsers); unmapping it means walking the page tables of everything the run
+    // touched with the address space locked.  One range is kept for the next streamed run of the process instead.
+    {
+        std::lock_guard<std::mutex> g(g_text_mu);
+        if (!g_text.p) { g_text = b; return; }
+    }
+    std::vector<Block> one(1, b);
+    release_async(std::move(one));
 }
 
 }  // namespace ntk

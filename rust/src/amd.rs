@@ -37,8 +37,11 @@ pub struct NtkRecord {
 /// ntk_gunzip: which route inflated the file (1 block gzip, 2 speculative parallel inflate of an ordinary stream, 3 sequential) and its timings
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct NtkGunzipInfo {
-    pub route: u32, pub threads: u32, pub chunks: u32, pub chunks_dropped: u32, pub members: u32, pub reserved: u32,
+    pub route: u32, pub threads: u32, pub chunks: u32, pub chunks_dropped: u32, pub members: u32, pub streamed: u32,
     pub search_s: f64, pub decode_s: f64, pub decode_busy_s: f64, pub crc_s: f64, pub marker_symbols: u64,
+    // ABI 4: streamed runs of ntk_scan_file_parallel (ntk_scan_file_info)
+    pub chunks_deferred: u32, pub parse_threads: u32, pub peak_backlog_bytes: u64, pub text_bytes: u64,
+    pub first_batch_s: f64, pub total_s: f64, pub resolve_busy_s: f64,
 }
 pub enum NtkCtx {}
 pub enum NtkBatch {}
@@ -57,6 +60,7 @@ extern "C" {
     pub fn ntk_ctx_synchronize(ctx: *mut NtkCtx) -> c_int;
     pub fn ntk_ctx_set_launch(ctx: *mut NtkCtx, blocks: c_int, threads_per_block: c_int) -> c_int;
     pub fn ntk_ctx_set_option(ctx: *mut NtkCtx, option: c_int, value: u64) -> c_int;
+    pub fn ntk_ctx_get_option(ctx: *mut NtkCtx, option: c_int, value: *mut u64) -> c_int;
     pub fn ntk_ctx_enable_timing(ctx: *mut NtkCtx, on: c_int) -> c_int;
     pub fn ntk_ctx_scan_time_ms(ctx: *mut NtkCtx, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn ntk_comm_init_all(ctxs: *const *mut NtkCtx, n: c_int, out: *mut *mut NtkComm) -> c_int;
@@ -93,6 +97,7 @@ extern "C" {
     pub fn ntk_scan_file_parallel(ctx: *mut NtkCtx, path: *const c_char, p: *const NtkParams, batch_bytes: u64, n_threads: u32, n_records: *mut u64, n_bases: *mut u64) -> c_int;
     pub fn ntk_gunzip(gz: *const u8, n: u64, n_threads: u32, out: *mut *mut u8, out_n: *mut u64, info: *mut NtkGunzipInfo) -> c_int;
     pub fn ntk_gunzip_free(out: *mut u8, out_n: u64);
+    pub fn ntk_scan_file_info(info: *mut NtkGunzipInfo) -> c_int;
     pub fn ntk_normalize(ctx: *mut NtkCtx, seq: *const u8, n: u64, allow_iupac: c_int, out: *mut u8, out_len: *mut u64, changed: *mut c_int) -> c_int;
     pub fn ntk_strip_returns(ctx: *mut NtkCtx, seq: *const u8, n: u64, out: *mut u8, out_len: *mut u64, borrowed: *mut c_int) -> c_int;
     pub fn ntk_reverse_complement(ctx: *mut NtkCtx, seq: *const u8, n: u64, out: *mut u8) -> c_int;

@@ -129,6 +129,25 @@ def test_truncation_and_corruption_are_errors():
     assert L.lib().ntk_gunzip(None, 0, 2, C.byref(out), C.byref(n), None) == 2   # NTK_ERR_BAD_ARG
 
 
+def test_truncated_literal_heavy_streams_end_at_once():
+    """a stream cut inside a block whose all-zero Huffman code is a LITERAL kept the decoder busy on phantom zero bits
+    until the output limit (seconds, gigabytes, NTK_ERR_UNSUPPORTED instead of NTK_ERR_PARSE): the literal path never looked at the input
+    position.  Z_HUFFMAN_ONLY (no matches at all) and incompressible data at level 1 (hardly any) are the cases the match path's check
+    never saw; every cut must be a parse error within a fraction of a second."""
+    import time
+    rng = np.random.default_rng(5)
+    low_match = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3_000_000)])
+    for name, z in (("huffman only, FASTQ", deflate(TEXT, 6, zlib.Z_HUFFMAN_ONLY)), ("huffman only, bases", deflate(low_match, 6, zlib.Z_HUFFMAN_ONLY)),
+                    ("level 1, random bytes", deflate(bytes(rng.integers(0, 256, 2_000_000).astype(np.uint8)), 1)),
+                    ("filtered", deflate(low_match, 6, zlib.Z_FILTERED))):
+        for cut in sorted(set(int(x) for x in rng.integers(20, len(z) - 9, 6)) | {len(z) - 9, len(z) // 2}):
+            for threads in (1, 4):
+                t0 = time.perf_counter()
+                rc = gunzip(z[:cut], threads)[0]
+                dt = time.perf_counter() - t0
+                assert rc == NTK_ERR_PARSE and dt < 2.0, (name, cut, threads, rc, dt)
+
+
 def test_random_structured_inputs():
     """Data with long-range repeats, runs and incompressible stretches; random flush points make blocks of every size."""
     rng = np.random.default_rng(11)
