@@ -625,6 +625,7 @@ int scan_gzip_streamed(ntk_ctx *ctx, const uint8_t *gz, uint64_t n, const ntk_pa
     if (p_local.flags & NTK_FLAG_RESET) { const int r = ntk_accum_reset(ctx); if (r != NTK_OK) return r; p_local.flags &= ~NTK_FLAG_RESET; }
     ntk::PgzStream S;
     S.window = ctx_option(ctx, NTK_OPT_GZ_STREAM_WINDOW_BYTES, (uint64_t)512 << 20);
+    S.input_is_file_mapping = true;   // (ntk_scan_file_parallel's own private mapping of the file)
     if (S.window < ((uint64_t)8 << 20)) S.window = (uint64_t)8 << 20;
     ntk_gunzip_info info;
     memset(&info, 0, sizeof(info));

@@ -733,6 +733,7 @@ int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t lim
     uint64_t total = 0, avail = 0;
     std::vector<uint8_t> tail(kWin, 0);   // the kWin bytes before `total` (valid: the last `avail`)
     bool chain_done = false;
+    uint64_t dropped_in = 0;   // compressed bytes whose pages have been given back (file-mapped input only)
     int rc = kOk;
     if (stream) { std::lock_guard<std::mutex> g(mu); stream->base = fin.p; stream->map = fin.p; stream->map_bytes = fin.cap; }
     auto advance_chain = [&]() {   // under mu
@@ -778,6 +779,11 @@ int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t lim
                 if (chunks[i].done) chunks[i].release();
             }
             chain_cur = c.end_chunk;
+            if (stream && stream->input_is_file_mapping && chain_cur < n_chunks && (chain_cur & 15) == 0) {
+                // everything before the head's first byte has been decoded for good (the 4 KiB page holding that byte may still be read)
+                const uintptr_t a = ((uintptr_t)in + dropped_in + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)in + chunks[chain_cur].byte_begin) & ~(uintptr_t)4095;
+                if (e > a) { (void)madvise((void *)a, e - a, MADV_DONTNEED); dropped_in = (uint64_t)(e - (uintptr_t)in); }
+            }
         }
         if (rc == kOk && !chain_done && chain_cur >= n_chunks) rc = kCorrupt;
     };

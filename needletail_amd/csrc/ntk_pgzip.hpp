@@ -53,6 +53,8 @@ struct PgzStream {
     uint64_t ready = 0;                 // bytes [0, ready) are final
     uint64_t consumed = 0;              // written by the consumer (then cv.notify_all()): it will not read below this offset again
     uint64_t window = (uint64_t)512 << 20;
+    bool input_is_file_mapping = false; // the compressed bytes are a private read-only FILE mapping the caller owns: the decoder drops its pages behind
+                                        // the chain's head (madvise(MADV_DONTNEED): they come back from the page cache if ever touched again)
     bool cancel = false;                // set by the consumer (then cv.notify_all()): the decoder stops at once and returns 4
     bool finished = false;              // the decoder has returned: rc says how (member CRCs and sizes are checked when the last byte is ready)
     int rc = 0;
