@@ -232,12 +232,12 @@ const void *pick_scan(const Mode &m, uint32_t k)
     } else {
 #define NTK_PICK_FIX(KF, T, U)                                                                      \
     if (!QM && m.kw == 2 && m.canon && k == KF && m.tie_rc == T && m.accept_u == U)                  \
-        return (const void *)&scan_kernel<2, true, T, U, false, KF, false>;
+        return (const void *)&scan_kernel<2, true, T, U, false, KF>;
     NTK_PICK_FIX(21, false, false) NTK_PICK_FIX(21, false, true) NTK_PICK_FIX(21, true, false) NTK_PICK_FIX(21, true, true)
 #undef NTK_PICK_FIX
 #define NTK_PICK(KW, C, T, U)                                                                       \
     if (m.kw == KW && m.canon == C && m.tie_rc == T && m.accept_u == U)                             \
-        return (const void *)&scan_kernel<KW, C, T, U, false, 0, false, QM>;
+        return (const void *)&scan_kernel<KW, C, T, U, false, 0, QM>;
     NTK_PICK(1, false, false, false) NTK_PICK(1, false, false, true)
     NTK_PICK(1, true, false, false) NTK_PICK(1, true, false, true)
     NTK_PICK(1, true, true, false) NTK_PICK(1, true, true, true)

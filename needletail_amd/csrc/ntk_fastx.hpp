@@ -24,7 +24,21 @@
 
 struct z_stream_s;
 
-namespace ntk { struct StreamDecoder; }
+namespace ntk {
+// A streaming decoder of a compressed container other than gzip (ntk_fastx_codecs.cpp; nullptr from make_stream_decoder: the codec's
+// run-time library is not installed, or the library was built without that translation unit)
+struct StreamDecoder {
+    virtual ~StreamDecoder() {}
+    // consumes from [in, in+in_n), produces into [out, out+cap); returns false on a stream error.  *end is set when the
+    // compressed stream is complete.
+    virtual bool step(const uint8_t *in, size_t in_n, size_t *used, uint8_t *out, size_t cap, size_t *made, bool *end) = 0;
+    // input that runs out while this is true is a TRUNCATED stream (an error, like the reference's decoders: UnexpectedEof),
+    // not an end of file.  bzip2 / xz: true until the stream end marker has been seen (read_plain stops at the marker).
+    virtual bool mid_stream() const { return true; }
+    virtual const char *name() const = 0;
+};
+StreamDecoder *make_stream_decoder(uint8_t first_magic_byte);   // 0x42 bzip2, 0xFD xz, 0x28 zstd
+}
 
 namespace ntk {
 

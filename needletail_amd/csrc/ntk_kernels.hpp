@@ -133,88 +133,9 @@ struct MaterializeSink {
     }
 };
 
-// ---------------------------------------------------------------------------------------------
-// "sv" reduce path (k-specialised, 17 <= k <= 32): break flags and window validity in scalar registers (ntk_tile.hpp)
-// ---------------------------------------------------------------------------------------------
-template <int K>
-struct ReduceSinkSV {
-    uint64_t sum = 0, xr = 0;
-    uint32_t *hist;
-    uint32_t bin_shift;
-    // byte offset of the bin from T, the value's top 32 bits: (T >> 20) * 4 as one shift + one AND, both full-rate (the
-    // generic `v >> bin_shift` is a 64-bit shift and the * 4 a left shift, both half-rate on gfx950: tools/ubench.hip)
-    __device__ __forceinline__ static uint32_t bin_offset(uint32_t t) { return (t >> 18) & 0x3FFCu; }
-    __device__ __forceinline__ void add(uint32_t hi, uint32_t lo, uint32_t off)
-    {
-        const uint64_t v = ((uint64_t)hi << 32) | lo;
-        sum += v;
-        xr ^= v;
-        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hist) + off), 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-};
-
 // 64-bit lane mask "byte BSEL of a == byte BSEL of b" in one SDWA compare, written straight to an SGPR pair.
 #define NTK_SDWA_EQ(dst, a, b, BSEL) \
     asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:" #BSEL " src1_sel:" #BSEL : "=s"(dst) : "v"(a), "v"(b))
-
-struct DevMasks {
-    uint64_t V[16];  // lane masks: window ending at byte j is emitted
-    uint32_t *fwd_cell = nullptr;  // this thread's own LDS cell: forward-strand count
-
-    template <int K>
-    __device__ __forceinline__ void compute(const EncSV &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
-    {
-        uint64_t B[16];
-        // base i <-> byte (3 - i/4) of word i%4
-        NTK_SDWA_EQ(B[0], en.ex[0], en.uu[0], BYTE_3);  NTK_SDWA_EQ(B[1], en.ex[1], en.uu[1], BYTE_3);
-        NTK_SDWA_EQ(B[2], en.ex[2], en.uu[2], BYTE_3);  NTK_SDWA_EQ(B[3], en.ex[3], en.uu[3], BYTE_3);
-        NTK_SDWA_EQ(B[4], en.ex[0], en.uu[0], BYTE_2);  NTK_SDWA_EQ(B[5], en.ex[1], en.uu[1], BYTE_2);
-        NTK_SDWA_EQ(B[6], en.ex[2], en.uu[2], BYTE_2);  NTK_SDWA_EQ(B[7], en.ex[3], en.uu[3], BYTE_2);
-        NTK_SDWA_EQ(B[8], en.ex[0], en.uu[0], BYTE_1);  NTK_SDWA_EQ(B[9], en.ex[1], en.uu[1], BYTE_1);
-        NTK_SDWA_EQ(B[10], en.ex[2], en.uu[2], BYTE_1); NTK_SDWA_EQ(B[11], en.ex[3], en.uu[3], BYTE_1);
-        NTK_SDWA_EQ(B[12], en.ex[0], en.uu[0], BYTE_0); NTK_SDWA_EQ(B[13], en.ex[1], en.uu[1], BYTE_0);
-        NTK_SDWA_EQ(B[14], en.ex[2], en.uu[2], BYTE_0); NTK_SDWA_EQ(B[15], en.ex[3], en.uu[3], BYTE_0);
-        if (tail_tile) {  // wave-uniform: bytes at or beyond n_bytes are breaks (the last 16-B line may carry padding)
-#pragma unroll
-            for (int i = 0; i < 16; i++) B[i] &= __builtin_amdgcn_ballot_w64(lane_base + i < (int64_t)n_bytes);
-        }
-        if constexpr (K >= 17) window_masks<K>(B, V); else window_masks1<K>(B, V);
-    }
-
-    // k <= 16: a 32-bit value
-    template <int K, class S>
-    __device__ __forceinline__ void emit1(S &sink, int j, bool take_fwd, uint32_t v)
-    {
-        uint32_t hi = 0;
-        // histogram byte offset: (v >> (2K - 12)) * 4 = one shift + one AND for K >= 7, v * 4 below (the value is the bin)
-        uint32_t off = K >= 7 ? ((v >> ((2 * K - 14) & 31)) & 0x3FFCu) : (v << 2);
-        asm volatile("" : "+v"(v), "+v"(off));
-        const uint64_t fwd = __builtin_amdgcn_ballot_w64(take_fwd);
-        if (__builtin_amdgcn_inverse_ballot_w64(V[j])) sink.add(hi, v, off);
-        if (__builtin_amdgcn_inverse_ballot_w64(V[j] & fwd))
-            __hip_atomic_fetch_add(fwd_cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // (t, lo): top and low 32 bits of the chosen value (ntk_tile.hpp lane_tile_sv)
-    template <int K, class S>
-    __device__ __forceinline__ void emit(S &sink, int j, bool take_fwd, uint32_t t, uint32_t lo)
-    {
-        uint32_t hi = K == 32 ? t : t >> ((64 - 2 * K) & 31);
-        // Everything that does not depend on the window being valid - strand select, histogram offset - is computed under
-        // the full exec mask and pinned there (a VALU instruction costs the same with one active lane as with 64; left to
-        // itself the compiler sinks it into the masked region, which then exceeds the length below which it drops the
-        // s_cbranch_execz: one branch and one basic-block boundary per position).  Only the side effects are masked.
-        uint32_t off = S::bin_offset(t);
-        asm volatile("" : "+v"(hi), "+v"(lo), "+v"(off));
-        // The forward-strand count costs NO vector ALU work: exec is narrowed once more by the compare mask and a
-        // non-returning ds_add_u32 bumps the thread's own LDS cell (conflict-free, the LDS pipe has headroom).
-        // (two sibling regions, not nested ones: a region without inner control flow and this short loses its execz branch)
-        const uint64_t fwd = __builtin_amdgcn_ballot_w64(take_fwd);  // the compare's own SGPR pair, no VALU work
-        if (__builtin_amdgcn_inverse_ballot_w64(V[j])) sink.add(hi, lo, off);
-        if (__builtin_amdgcn_inverse_ballot_w64(V[j] & fwd))
-            __hip_atomic_fetch_add(fwd_cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-};
 
 // ---------------------------------------------------------------------------------------------
 // the scan kernel (template flags: see lane_tile in ntk_tile.hpp; ACCEPT_U: U/u is a base coding T because the
@@ -222,15 +143,12 @@ struct DevMasks {
 // bytes each) with the next tile's load in flight while the current one is processed; no byte is fetched from HBM
 // twice (the 32 halo bytes of a tile come back from L2).
 // ---------------------------------------------------------------------------------------------
-template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0, bool SV = false, bool QM = false>
+template <int KW, bool CANON, bool TIE_RC, bool ACCEPT_U, bool REDUCE, int KFIX = 0, bool QM = false>
 __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
 {
-    static_assert(!SV || (REDUCE && ((KW == 2 && KFIX >= 17 && KFIX <= 32) || (KW == 1 && KFIX >= 1 && KFIX <= 16))),
-                  "the scalar-validity path is a k-specialised reduce path");
-    using Sink = typename std::conditional<SV, ReduceSinkSV<(KFIX >= 1 ? KFIX : 17)>, typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type>::type;
+    using Sink = typename std::conditional<REDUCE, ReduceSink<KW>, MaterializeSink<KW>>::type;
     __shared__ uint32_t s_hist[REDUCE ? kHistBins : 1];
     __shared__ uint64_t s_red[REDUCE ? 16 * 4 : 1];
-    __shared__ uint32_t s_nfwd[SV ? 1024 : 1];  // sv builds: per-thread forward-strand counters
     extern __shared__ __attribute__((aligned(16))) uint64_t s_stage[];  // materialise mode: kStageWaveU64 u64 per wave (dynamic)
 
     Sink sink;
@@ -262,8 +180,6 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
     uint32_t *ctr = a.work_counters + shard * 16;
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
     DevXL xl;
-    DevMasks mp;
-    if constexpr (SV) { s_nfwd[threadIdx.x] = 0; mp.fwd_cell = &s_nfwd[threadIdx.x]; }  // own cell: no barrier needed
     const bool halo_lane = lane < (uint32_t)kHaloLanes;
 
     uint32_t next = 0;
@@ -311,15 +227,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
             const bool tail = r >= a.tail_tile_rel;  // this tile reaches the end of the input
             Raw16 raw{cur.x, cur.y, cur.z, cur.w};
             if constexpr (QM) raw = quality_break16(raw, Raw16{curq.x, curq.y, curq.z, curq.w}, a.q_add, a.q_sel);
-            if constexpr (SV) {
-                const EncSV en = encode16_sv<ACCEPT_U>(raw);
-                mp.template compute<KFIX>(en, tail, (int64_t)tile_byte - 32 + lane * 16, a.n_bytes);
-                if constexpr (KW == 2) lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
-                else lane_tile_sv1<CANON, TIE_RC, KFIX>(sink, xl, mp, en);
-            } else {
-                lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, raw,
-                                                             (int64_t)tile_byte - 32 + lane * 16, halo_lane, tail);
-            }
+            lane_tile<KW, CANON, TIE_RC, ACCEPT_U, KFIX>(a, sink, xl, raw, (int64_t)tile_byte - 32 + lane * 16, halo_lane, tail);
             cur = nxt; curq = nxtq; voff += kTileStride; tile_byte += kTileStride;
         }
         next = __builtin_amdgcn_readfirstlane(next);
@@ -329,15 +237,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         // wave -> block -> per-block partials (plain stores; the fold kernel sums them)
         uint64_t sum = sink.sum, xr = sink.xr, nf, nv;
         uint32_t *ph = a.part_hist + (size_t)blockIdx.x * kHistBins;
-        if constexpr (SV) {
-            // the sv path does not count emitted windows one by one: every emit increments exactly one bin, so the
-            // block's n_total is the sum of its histogram, taken while the histogram is copied out
-            nf = s_nfwd[threadIdx.x]; nv = 0;
-            __syncthreads();
-            for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) { const uint32_t h = s_hist[i]; ph[i] = h; nv += h; }
-        } else {
-            nf = sink.n_fwd; nv = sink.n_valid;
-        }
+        nf = sink.n_fwd; nv = sink.n_valid;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sum += __shfl_xor(sum, o, 64);
@@ -347,8 +247,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(ScanArgs a)
         }
         if (lane == 0) { s_red[wave * 4 + 0] = nv; s_red[wave * 4 + 1] = nf; s_red[wave * 4 + 2] = sum; s_red[wave * 4 + 3] = xr; }
         __syncthreads();
-        if constexpr (!SV)
-            for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
+        for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) ph[i] = s_hist[i];
         if (threadIdx.x == 0) {
             uint64_t tv = 0, tf = 0, ts = 0, tx = 0;
             for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {

@@ -746,67 +746,12 @@ inline void scan_args_set_window(ScanArgs &a, uint32_t w)
 // bytes 33+j-k..15 of the lane before.  The mask then gates the emit through exec with no VALU work per position.
 // k is a compile-time constant here.
 // The host emulation computes B from the same per-lane expected/actual bytes and runs the same mask algebra.
+// (Rounds 1 - 2 had a first generation of this scheme - transpose encode, finished masks OK[j], one emit per position: lane_tile_sv /
+// lane_tile_sv1 - which no build of the library used after round 3; removed in round 6, see profiles/history/.)
 // ---------------------------------------------------------------------------------------------
-struct EncSV {
-    uint32_t code, rcode;
-    uint32_t ex[4];  // expected letter per byte: byte (3-u) of word s belongs to base 4u+s
-    uint32_t uu[4];  // the byte as read, case-folded (and with T/U merged when ACCEPT_U)
-};
-
-template <bool ACCEPT_U>
-NTK_HD EncSV encode16_sv(Raw16 d)
-{
-    const uint32_t x0 = perm(d.x, d.y, 0x04000501u), x1 = perm(d.x, d.y, 0x06020703u);
-    const uint32_t y0 = perm(d.z, d.w, 0x04000501u), y1 = perm(d.z, d.w, 0x06020703u);
-    const uint32_t e[4] = {perm(x0, y0, 0x07060302u), perm(x0, y0, 0x05040100u), perm(x1, y1, 0x07060302u), perm(x1, y1, 0x05040100u)};
-    const uint32_t m = bfi(0xC0C0C0C0u, e[0] << 5, bfi(0x30303030u, e[1] << 3, bfi(0x0C0C0C0Cu, e[2] << 1, e[3] >> 1)));
-    EncSV r;
-    r.code = m ^ ((m >> 1) & 0x55555555u);
-    const uint32_t t = brev32(~r.code);
-    r.rcode = bfi(0x55555555u, t >> 1, t << 1);
-    constexpr uint32_t kTable = ACCEPT_U ? 0x47554341u : 0x47544341u;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        uint32_t u = e[s] & 0xDFDFDFDFu;
-        if (ACCEPT_U) u = and_or(u >> 4, 0x01010101u, u);
-        r.uu[s] = u;
-        r.ex[s] = perm(0u, kTable, (e[s] >> 1) & 0x03030303u);
-    }
-    return r;
-}
-
-// break bit of base i of one lane (host side of the SDWA compare): byte (3 - i/4) of word i%4
-NTK_HD bool sv_base_is_break(const EncSV &e, int i)
-{
-    const int s = i & 3, sh = 8 * (3 - (i >> 2));
-    return ((e.ex[s] >> sh) & 0xFFu) != ((e.uu[s] >> sh) & 0xFFu);
-}
-
-// OK[j] (window ending at byte j is emitted) from G[i] (byte i is a base), as lane masks; K >= 17.  Positive logic so
-// that the result feeds s_and_saveexec directly; a lane shift fills lane 0 with "not a base", and lanes 0 and 1 (halo
-// lanes) are cleared: all their windows are invalid.
-template <int K>
-NTK_HD void window_masks(const uint64_t (&G)[16], uint64_t (&OK)[16])
-{
-    static_assert(K >= 17 && K <= 32, "sv path is built for 17 <= k <= 32");
-    uint64_t P[16], S[16];
-    P[0] = G[0] & ~3ull;  // halo lanes 0/1: cleared once here, inherited by every prefix
-#pragma unroll
-    for (int j = 1; j < 16; j++) P[j] = P[j - 1] & G[j];
-    S[15] = G[15];
-#pragma unroll
-    for (int i = 14; i >= 0; i--) S[i] = S[i + 1] & G[i];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int c = 17 + j - K, a_ = c > 0 ? c : 0;
-        uint64_t v = P[j] & (S[a_] << 1);
-        if (c < 0) v &= S[(33 + j - K) & 15] << 2;
-        OK[j] = v;
-    }
-}
-
-// The same masks with their last AND left open: OK[j] = A[j] & B[j] (A = the lane's own prefix, B = what the previous lanes
-// contribute).  The masked region forms exec with that AND itself (s_and_b64 exec, A, B): one scalar op instead of AND + move.
+// OK[j] (window ending at byte j is emitted) = A[j] & B[j] with the last AND left open (A = the lane's own prefix, B = what the previous
+// lanes contribute): the masked region forms exec with that AND itself (s_and_b64 exec, A, B) - one scalar op instead of AND + move.
+// Positive logic; a lane shift fills lane 0 with "not a base", and lanes 0 and 1 (halo lanes) are cleared: all their windows are invalid.
 template <int K>
 NTK_HD void window_masks_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16])
 {
@@ -827,105 +772,15 @@ NTK_HD void window_masks_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t
     for (int j = 1; j < 16; j++) A[j] = A[j - 1] & G[j];
 }
 
-template <bool CANON, bool TIE_RC, int KFIX, class Sink, class XL, class MP>
-NTK_HD void lane_tile_sv(Sink &sink, XL &xl, MP &mp, const EncSV &en)
-{
-    constexpr int D = KFIX - 16, S = 64 - 2 * KFIX;
-    const uint32_t c1 = xl.prev(kSlotCode, en.code);
-    const uint32_t r1 = xl.prev(kSlotRcode, en.rcode);
-    uint32_t Q[3];
-    Q[0] = S ? en.rcode >> S : en.rcode;
-    Q[1] = alignbit(en.rcode, r1, S);
-    Q[2] = xl.prev(kSlotQ1, Q[1]);
-    uint32_t W2[3] = {xl.prev(kSlotCode1, c1), c1, en.code};
-    uint32_t fls[16], rls[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        fls[j] = j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j);
-        rls[j] = win32(Q, 32 + 2 * (15 - j));
-    }
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        // A value is handled as (T, lo): lo = its low 32 bits, T = its TOP 32 bits (the first 16 bases) - they overlap in
-        // 64-2K bits.  (T:lo) pairs order exactly like the values (T decides unless equal, and then the overlap is equal too),
-        // so the strand compare needs no hi words; T is the lo word of the window ending K-16 bases earlier (already in a
-        // register for most j), the hi word of the CHOSEN value is one shift of the chosen T, and the histogram offset is a
-        // shift + AND of T whatever K is.
-        const uint32_t fl = fls[j], rl = rls[j];
-        const uint32_t ft = j >= D ? fls[j >= D ? j - D : 0] : win32(W2, 34 + 2 * (j - D));
-        const uint32_t rt = j + D <= 15 ? rls[j + D <= 15 ? j + D : 0] : win32(Q, 2 * (15 - j) + S);
-        bool take_fwd = true;
-        if (CANON) {
-            const uint64_t f = ((uint64_t)ft << 32) | fl, r = ((uint64_t)rt << 32) | rl;
-            take_fwd = TIE_RC ? (f < r) : (f <= r);
-        }
-        mp.template emit<KFIX>(sink, j, take_fwd, take_fwd ? ft : rt, take_fwd ? fl : rl);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// "sv" variant for k <= 16 (32-bit values).  The window ending at byte j covers bytes j-K+1 .. j: inside the lane when
-// j >= K-1, else reaching into the previous lane (never further: K <= 16).  With E = [previous lane's 16 masks shifted
-// one lane up, own 16 masks] the validity masks are a sliding AND of width K over E, built by doubling (widths 1, 2, 4,
-// 8) and one overlap step; only the entries a later level reads are generated (everything is unrolled).
+// The same for k <= 16 (32-bit values).  The window ending at byte j covers bytes j-K+1 .. j: inside the lane when j >= K-1, else
+// reaching into the previous lane (never further: K <= 16).  9 <= K <= 16: prefix / suffix ANDs (about 70 scalar ops: the scalar unit
+// is shared by the CU's four SIMDs and these kernels keep it busy) - a window that reaches into the previous lane is (own prefix [0..j])
+// AND (the previous lane's suffix from byte 17+j-K, one lane shift); one inside the lane straddles the middle of the 16, so it is
+// (suffix of the first half from its start) AND (prefix of the second half up to j), or a whole prefix / suffix when it touches byte
+// 0 / 15.  K <= 8: with E = [previous lane's 16 masks shifted one lane up, own 16 masks] a sliding AND of width K over E, built by
+// doubling (widths 1, 2, 4, 8) and one overlap step.  OK[j] = A[j] & B[j] as in window_masks_ab.
 // ---------------------------------------------------------------------------------------------
-template <int K>
-NTK_HD void window_masks1(const uint64_t (&G)[16], uint64_t (&OK)[16])
-{
-    static_assert(K >= 1 && K <= 16, "k <= 16 variant");
-    if constexpr (K >= 9) {
-        // 9 <= K <= 16: prefix / suffix ANDs instead of doubling (about 70 scalar ops instead of 110: the scalar unit is shared by
-        // the CU's four SIMDs and this kernel keeps it busy).  A window ending at byte j either reaches into the previous lane
-        // (j <= K-2: own prefix [0..j] AND the previous lane's suffix from byte 17+j-K, one lane shift) or lies inside the lane
-        // (j >= K-1); an inside window of >= 9 bytes straddles the middle of the 16, so it is (suffix of the first half from its
-        // start) AND (prefix of the second half up to j) - or simply a whole prefix / suffix when it touches byte 0 / 15.
-        uint64_t P[16], S[16], S8[8], P8[16];
-        P[0] = G[0] & ~3ull;   // halo lanes 0/1 emit nothing: cleared in every window that contains own byte 0 ...
-#pragma unroll
-        for (int j = 1; j < 16; j++) P[j] = P[j - 1] & G[j];
-        S[15] = G[15];
-#pragma unroll
-        for (int i = 14; i >= 0; i--) S[i] = S[i + 1] & G[i];
-        S8[7] = G[7];
-#pragma unroll
-        for (int i = 6; i >= 1; i--) S8[i] = S8[i + 1] & G[i];
-        P8[8] = G[8];
-#pragma unroll
-        for (int j = 9; j < 15; j++) P8[j] = P8[j - 1] & G[j];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int a = j - K + 1;   // first byte of the window (negative: in the previous lane)
-            uint64_t v;
-            if (a < 0) v = P[j] & (S[(16 + a) & 15] << 1);
-            else if (a == 0) v = P[j];
-            else if (j == 15) v = S[a & 15] & ~3ull;                       // ... and explicitly in the windows that do not
-            else v = (S8[a & 7] & P8[j & 15]) & ~3ull;
-            OK[j] = v;
-        }
-        return;
-    }
-    constexpr int P = K >= 16 ? 16 : (K >= 8 ? 8 : (K >= 4 ? 4 : (K >= 2 ? 2 : 1)));  // largest power of two <= K
-    uint64_t A[32];  // A[16 + i] = own byte i, A[i] = previous lane's byte i (a lane shift is a 1-bit shift of the mask)
-#pragma unroll
-    for (int i = 0; i < 16; i++) { A[16 + i] = G[i]; A[i] = G[i] << 1; }
-    A[16] &= ~3ull;  // halo lanes 0/1 emit nothing: cleared in own byte 0 ...
-#pragma unroll
-    for (int w = 1; w < P; w *= 2) {   // A[e] becomes the AND of the 2w entries ending at e
-#pragma unroll
-        for (int e = 31; e >= 2 * w - 1; e--) A[e] &= A[e - w];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        uint64_t v = A[16 + j];
-        if (K > P) v &= A[16 + j - (K - P)];
-        OK[j] = v;
-    }
-    // ... and, since own byte 0 is only part of windows ending at j <= K-1, in the remaining positions explicitly
-#pragma unroll
-    for (int j = K; j < 16; j++) OK[j] &= ~3ull;
-}
-
-// window_masks1 with the last AND left open (OK[j] = A[j] & B[j], see window_masks_ab): the scan2 builds form exec with it.
 template <int K>
 NTK_HD void window_masks1_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t (&B)[16], const uint64_t kNoHalo = ~3ull)
 {
@@ -1042,27 +897,9 @@ NTK_HD void window_masks_runtime(const uint64_t (&G)[16], uint64_t (&A)[16], uin
     }
 }
 
-template <bool CANON, bool TIE_RC, int K, class Sink, class XL, class MP>
-NTK_HD void lane_tile_sv1(Sink &sink, XL &xl, MP &mp, const EncSV &en)
-{
-    constexpr int S = 32 - 2 * K;
-    constexpr uint32_t mask = K == 16 ? 0xFFFFFFFFu : ((1u << ((2 * K) & 31)) - 1u);
-    const uint32_t c1 = xl.prev(kSlotCode, en.code);
-    const uint32_t r1 = xl.prev(kSlotRcode, en.rcode);
-    const uint32_t Q[2] = {S ? en.rcode >> S : en.rcode, alignbit(en.rcode, r1, S)};
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t fl = (j == 15 ? en.code : alignbit(c1, en.code, 30 - 2 * j)) & mask;
-        const uint32_t rl = win32(Q, 2 * (15 - j)) & mask;
-        bool take_fwd = true;
-        if (CANON) take_fwd = TIE_RC ? (fl < rl) : (fl <= rl);
-        mp.template emit1<K>(sink, j, take_fwd, take_fwd ? fl : rl);
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
-// "sv2": the scalar-validity reduce path, second generation (17 <= K <= 32, canonical).
+// "sv2": the scalar-validity reduce path (17 <= K <= 32, canonical).
 //
 // * No byte transpose: the four dwords are used as loaded (byte b of dword i = base 4i + b).  Two 8-entry LUTs
 //   (v_perm_b32, selector = the byte's low 3 bits) give the only letter with those bits and twice its 2-bit code; the

@@ -116,53 +116,6 @@ void run(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStat
     }
 }
 
-// Scalar-validity ("sv") variant: break flags as lane masks, window validity by mask algebra (ntk_tile.hpp).  On the device
-// the masks come from SDWA compares + SALU ops; here they are assembled from the same per-lane expected/actual bytes.
-struct EmuMP {
-    uint64_t V[16];
-    int lane = 0;
-    template <int K, class S>
-    void emit1(S &sink, int j, bool take_fwd, uint32_t v) { sink.emit(j, (V[j] >> lane) & 1, take_fwd, 0u, v); }  // k <= 16
-    template <int K, class S>
-    void emit(S &sink, int j, bool take_fwd, uint32_t t, uint32_t lo)  // (t, lo): top and low 32 bits of the value
-    {
-        sink.emit(j, (V[j] >> lane) & 1, take_fwd, K == 32 ? t : t >> (64 - 2 * K), lo);
-    }
-};
-
-template <bool CANON, bool TIE_RC, bool ACCEPT_U, int KFIX>
-void run_sv(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs a, HostStats *st)
-{
-    const uint64_t n_tiles = ((n + 15) / 16 + kTileSlots - 1) / kTileSlots;
-    HostSink<(KFIX >= 17 ? 2 : 1)> sink;
-    sink.st = st; sink.bin_shift = a.bin_shift; sink.values = nullptr; sink.valid16 = nullptr; sink.rc16 = nullptr; sink.n_bytes = n;
-    for (uint64_t t = 0; t < n_tiles; t++) {
-        const bool tail = (t + 1) * kTileStride > n;
-        EncSV en[64];
-        uint64_t G[16] = {0};
-        for (int l = 0; l < 64; l++) {
-            const int64_t lane_base = (int64_t)(t * kTileStride) - 32 + l * 16;
-            en[l] = encode16_sv<ACCEPT_U>(load16q(buf, n_padded, lane_base));
-            for (int i = 0; i < 16; i++) {
-                bool good = !sv_base_is_break(en[l], i);
-                if (tail && lane_base + i >= (int64_t)n) good = false;
-                if (good) G[i] |= 1ull << l;
-            }
-        }
-        EmuMP mp;
-        if constexpr (KFIX >= 17) window_masks<KFIX>(G, mp.V); else window_masks1<KFIX>(G, mp.V);
-        EmuXL xl;
-        for (int l = 0; l < 64; l++) {
-            xl.next_lane(l == 0);
-            mp.lane = l;
-            sink.skip = true;
-            if constexpr (KFIX >= 17) lane_tile_sv<CANON, TIE_RC, KFIX>(sink, xl, mp, en[l]);
-            else lane_tile_sv1<CANON, TIE_RC, KFIX>(sink, xl, mp, en[l]);
-        }
-    }
-}
-
-
 // "sv2" variant (ntk_tile.hpp lane_tile_sv2): same mask algebra; the digests are kept the way the device keeps them -
 // sum of (hi:lo) / xor words of (T, lo), or for K <= 22 ("light") only the lo words plus a per-block histogram from
 // which the high parts are rebuilt - so that the reconstruction arithmetic of scan2_kernel is what gets checked.
@@ -366,15 +319,14 @@ void run_min_generic(const uint8_t *buf, uint64_t n, uint64_t n_padded, ScanArgs
 
 }  // namespace
 
-// The window-mask algebra alone: OK[j] in its two forms (window_masks / window_masks1: the finished masks; *_ab: the masks with
-// their last AND left to the masked region) for window length k.  Returns -1 on bad k.
+// The window-mask algebra alone: OK[j] = A[j] & B[j] (window_masks_ab / window_masks1_ab: the masks with their last AND left to the
+// masked region) for window length k.  Returns -1 on bad k.
 template <int K>
 static void masks_both(const uint64_t (&G)[16], uint64_t *ok, uint64_t *ab)
 {
-    uint64_t V[16], A[16], B[16];
-    if constexpr (K >= 17) window_masks<K>(G, V); else window_masks1<K>(G, V);
+    uint64_t A[16], B[16];
     window_masks_ab_any<K>(G, A, B);
-    for (int j = 0; j < 16; j++) { ok[j] = V[j]; ab[j] = A[j] & B[j]; }
+    for (int j = 0; j < 16; j++) { ok[j] = A[j] & B[j]; ab[j] = A[j] & B[j]; }
 }
 
 extern "C" {
@@ -393,8 +345,7 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
     const int kw = k > 16 ? 2 : 1;
     // tiles_per_wave doubles as a switch in this emulation: an odd value selects the k-specialised build when one exists
     const bool fix = (tiles_per_wave & 1) && canon && (k == 21 || k == 31);
-    // bit 1 of tiles_per_wave: the scalar-validity variant (statistics only), built for every 17 <= k <= 32 like the product
-    const bool sv = (tiles_per_wave & 2) && canon && !values;
+    // (bit 1 of tiles_per_wave selected the first scalar-validity generation until round 6; it is ignored now)
     // bit 2 of tiles_per_wave: the second-generation scalar-validity variant (17 <= k <= 32); bit 3 picks its 14-bit histogram
     const bool sv2 = (tiles_per_wave & 4) && canon && !values && k >= 17;
     const bool hb14 = (tiles_per_wave & 8) != 0;
@@ -415,12 +366,6 @@ int emu_scan(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int 
 #define EMU_SV2W6(KF) EMU_SV2W(KF, false, false) EMU_SV2W(KF, false, true) EMU_SV2W(KF, true, false) EMU_SV2W(KF, true, true) EMU_SV2WF(KF, false) EMU_SV2WF(KF, true)
     EMU_SV2W6(1) EMU_SV2W6(2) EMU_SV2W6(3) EMU_SV2W6(4) EMU_SV2W6(5) EMU_SV2W6(6) EMU_SV2W6(7) EMU_SV2W6(8)
     EMU_SV2W6(9) EMU_SV2W6(10) EMU_SV2W6(11) EMU_SV2W6(12) EMU_SV2W6(13) EMU_SV2W6(14) EMU_SV2W6(15) EMU_SV2W6(16)
-#define EMU_SV(KF, T, U) if (sv && k == KF && !!tie_rc == T && !!accept_u == U) { run_sv<true, T, U, KF>(buf, n, n_padded, a, st); } else
-#define EMU_SV4(KF) EMU_SV(KF, false, false) EMU_SV(KF, false, true) EMU_SV(KF, true, false) EMU_SV(KF, true, true)
-    EMU_SV4(1) EMU_SV4(2) EMU_SV4(3) EMU_SV4(4) EMU_SV4(5) EMU_SV4(6) EMU_SV4(7) EMU_SV4(8)
-    EMU_SV4(9) EMU_SV4(10) EMU_SV4(11) EMU_SV4(12) EMU_SV4(13) EMU_SV4(14) EMU_SV4(15) EMU_SV4(16)
-    EMU_SV4(17) EMU_SV4(18) EMU_SV4(19) EMU_SV4(20) EMU_SV4(21) EMU_SV4(22) EMU_SV4(23) EMU_SV4(24)
-    EMU_SV4(25) EMU_SV4(26) EMU_SV4(27) EMU_SV4(28) EMU_SV4(29) EMU_SV4(30) EMU_SV4(31) EMU_SV4(32)
 #define EMU_FIX(KF, T, U) if (fix && k == KF && !!tie_rc == T && !!accept_u == U) { run<2, true, T, U, KF>(buf, n, n_padded, a, st, values, valid16, rc16); } else
     EMU_FIX(21, false, false) EMU_FIX(21, false, true) EMU_FIX(21, true, false) EMU_FIX(21, true, true)
     EMU_FIX(31, false, false) EMU_FIX(31, false, true) EMU_FIX(31, true, false) EMU_FIX(31, true, true)

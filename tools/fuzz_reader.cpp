@@ -2,6 +2,7 @@
 // Built and run by tests/test_parser.py::test_reader_under_sanitizers:
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -mavx2 tools/fuzz_reader.cpp -lz -ldl
 #include "../needletail_amd/csrc/ntk_fastx.cpp"
+#include "../needletail_amd/csrc/ntk_fastx_codecs.cpp"
 #include <random>
 #include <zlib.h>
 int main() {

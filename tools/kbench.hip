@@ -57,11 +57,6 @@ int main(int argc, char **argv)
         else
 #endif
 #ifdef NTK_KB_FIX
-#ifdef NTK_KB_SV
-        if (k == 21) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true, 21, true>), dim3(blocks), dim3(threads), 0, 0, a);
-        else if (k == 31) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true, 31, true>), dim3(blocks), dim3(threads), 0, 0, a);
-        else
-#endif
         if (k == 21) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true, 21>), dim3(blocks), dim3(threads), 0, 0, a);
         else if (k == 31) hipLaunchKernelGGL((scan_kernel<2, true, true, true, true, 31>), dim3(blocks), dim3(threads), 0, 0, a);
         else
