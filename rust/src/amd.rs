@@ -325,3 +325,62 @@ impl AmdComm {
     pub fn allreduce(&self) -> Result<(), AmdError> { check(unsafe { ntk_allreduce_accumulators(self.0) }) }
 }
 impl Drop for AmdComm { fn drop(&mut self) { unsafe { ntk_comm_destroy(self.0) } } }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The `Sequence`-trait face (reference src/sequence.rs:156-253), as code rather than as prose in INTEGRATION.md (missing 4).
+// The reference's trait hands out iterators per record (`seq.canonical_kmers(k, &rc)`, `seq.bit_kmers(k, canonical)`); a device call per record
+// would be launch-latency-bound, so the unit here is the reader's BATCH: `AmdRecords::scan` uploads every record of one `FastxReader` buffer
+// once (two bit planes per window start come back, + the dense values for the bit path) and `AmdRecords::record(i)` is a value with the trait's
+// method names whose iterators yield exactly the reference's items.  In the crate this file is `mod amd` under `cfg(feature = "amd")`, and
+// `impl<'a> Sequence<'a> for AmdRecord<'a>` below is what makes user code that is generic over `Sequence` run on it unchanged: `sequence()`
+// is the only required method (src/sequence.rs:158-160); `canonical_kmers` / `bit_kmers` are inherent methods that shadow the provided ones
+// for direct callers (the provided ones stay correct - they are the CPU iterators).
+// NOT compiled in this repository (no rustc in the image): kept in step with the header by tests/test_abi.py, which diffs the extern block.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+
+/// Every record of one reader batch, scanned once on the device for (k, bit-path canonical flag).
+pub struct AmdRecords<'b> {
+    seq: &'b [u8], offsets: &'b [u64], k: u8,
+    bytes: Option<AmdCanonicalKmersPlanes>,   // Sequence::canonical_kmers (byte path; raw-byte strand compare, ties -> rc: src/kmer.rs:121-128)
+    bits: Option<AmdBitKmersPlanes>,          // Sequence::bit_kmers (2-bit path; ties stay forward: src/bitkmer.rs:136-143)
+}
+impl<'b> AmdRecords<'b> {
+    /// `seq` + `offsets` (n + 1 entries): record i = seq[offsets[i]..offsets[i + 1]], e.g. the reader's own buffer (no copy is made).
+    /// `byte_path` / `bit_path`: which of the two k-mer methods the caller is going to use (each costs one device call for the batch).
+    pub fn scan(ctx: &AmdContext, seq: &'b [u8], offsets: &'b [u64], k: u8, byte_path: bool, bit_path: Option<bool>) -> Result<Self, AmdError> {
+        let bytes = if byte_path { Some(AmdCanonicalKmersPlanes::new(ctx, seq, offsets, k)?) } else { None };
+        let bits = match bit_path { Some(canonical) => Some(AmdBitKmersPlanes::new(ctx, seq, offsets, k, canonical)?), None => None };
+        Ok(Self { seq, offsets, k, bytes, bits })
+    }
+    pub fn len(&self) -> usize { self.offsets.len().saturating_sub(1) }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+    pub fn record(&'b self, i: usize) -> AmdRecord<'b> {
+        AmdRecord { batch: self, index: i, seq: &self.seq[self.offsets[i] as usize..self.offsets[i + 1] as usize] }
+    }
+}
+
+/// One record of the batch: the value user code calls the `Sequence` methods on.
+#[derive(Clone, Copy)]
+pub struct AmdRecord<'a> { batch: &'a AmdRecords<'a>, index: usize, seq: &'a [u8] }
+impl<'a> AmdRecord<'a> {
+    /// `Sequence::sequence` (src/sequence.rs:158-160)
+    pub fn sequence(&self) -> &'a [u8] { self.seq }
+    /// `Sequence::canonical_kmers(k, &rc)` (src/sequence.rs:237-239): the items of `CanonicalKmers` (src/kmer.rs:114-129), from the batch's
+    /// bit planes.  `reverse_complement` is the caller's buffer, as in the reference (the slices of reverse-strand items point into it).
+    /// Panics like the reference on k = 0 / k > len (src/kmer.rs:91) - here: when the batch was scanned for another k or without the byte path.
+    pub fn canonical_kmers(&self, k: u8, reverse_complement: &'a [u8]) -> impl Iterator<Item = (usize, &'a [u8], bool)> + 'a {
+        assert!(k == self.batch.k, "the batch was scanned for k = {}", self.batch.k);
+        self.batch.bytes.as_ref().expect("AmdRecords::scan(.., byte_path = true, ..)").iter(self.index, self.seq, reverse_complement)
+    }
+    /// `Sequence::bit_kmers(k, canonical)` (src/sequence.rs:250-252): the items of `BitNuclKmer` (src/bitkmer.rs:97-108).
+    pub fn bit_kmers(&self, k: u8, _canonical: bool) -> impl Iterator<Item = (usize, (u64, u8), bool)> + 'a {
+        assert!(k == self.batch.k, "the batch was scanned for k = {}", self.batch.k);
+        self.batch.bits.as_ref().expect("AmdRecords::scan(.., bit_path = Some(canonical))").iter(self.index)
+    }
+}
+/// In the crate (`src/amd.rs` next to `src/sequence.rs`), feature-gated; `normalize`, `strip_returns`, `reverse_complement`, `kmers` are the
+/// trait's provided methods - per-record byte maps that stay on the CPU (on the device they are fused into the scan).
+#[cfg(feature = "amd")]
+impl<'a> crate::sequence::Sequence<'a> for AmdRecord<'a> {
+    fn sequence(&'a self) -> &'a [u8] { self.seq }
+}
