@@ -273,6 +273,50 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
     out["bits_forward_k21"] = {"workload": "config-2 batch, k=21, BitNuclKmer canonical=false, reduce mode, resident", "kernel_ms": round(ms, 4),
                                "GB_s": round(k21_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(k21_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+    # round 6: the byte path on input nobody normalised (Sequence::canonical_kmers on a clean record: normalize returns None, reference
+    # src/sequence.rs:57-61): the speculative packed-value scan + the raw-byte kernel that returns at once when no lower-case byte was seen.
+    # The C2 batch is upper case with N: the result must equal the oracle's raw-byte chain (prefix) and the normalised run's (whole batch:
+    # no U, no lower case in it); hipEvents span both kernels of the pair.
+    ctx.accum_reset()
+    ctx.reduce_device(k21_seq, pre_r * (read_len + 1), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+    if not stats_equal(ctx.accum_read(), O.reduce_records(hs.split(b"\n")[:pre_r], 21, O.PATH_BYTES_CANONICAL, O.PRE_NONE)):
+        raise SystemExit("secondary: un-normalised byte-path prefix differs from the oracle's raw-byte chain")
+    ctx.accum_reset(); ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    want_norm = ctx.accum_read()
+    ctx.accum_reset(); ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+    if not stats_equal(ctx.accum_read(), want_norm):
+        raise SystemExit("secondary: the speculative scan of the un-normalised batch differs from the normalised run")
+    ms_n = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)), 20)
+    ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)), 20)
+    out["bytes_unnormalised_k21"] = {"workload": "config-2 batch as it is (upper case), NTK_PATH_BYTES_CANONICAL with pre = NONE: speculative packed-value scan, "
+                                                 "raw-byte kernel queued behind it (returns at once: no lower-case byte)",
+                                     "kernel_ms": round(ms, 4), "GB_s": round(k21_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(k21_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "normalised_run_same_loop_ms": round(ms_n, 4), "round5_raw_byte_kernel_ms": 5.1}
+    # k > 32 on the reduce face (CanonicalKmers takes k: u8): counters + histogram, no sum / xor; a prefix against the literal iterator
+    pre_w = 300
+    recs_w = hs.split(b"\n")[:pre_w]
+    ctx.accum_reset(); ctx.reduce_device(k21_seq, pre_w * (read_len + 1), 64, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)
+    got_w = ctx.accum_read()
+    code_w = {65: 0, 67: 1, 71: 2, 84: 3}
+    nt_w = nrc_w = 0
+    hist_w = np.zeros(4096, dtype=np.uint64)
+    for r_ in recs_w:
+        r_ = O.normalize(r_)[0]
+        rc_ = O.reverse_complement(r_)
+        pos_, flg_ = O.canonical_kmers_arrays(r_, rc_, 64)
+        for p_, f_ in zip(pos_.tolist(), flg_.tolist()):
+            sl = rc_[len(rc_) - p_ - 64: len(rc_) - p_] if f_ else r_[p_: p_ + 64]
+            b_ = 0
+            for ch in sl[:6]:
+                b_ = b_ * 4 + code_w[ch]
+            hist_w[b_] += 1
+        nt_w += len(pos_); nrc_w += int(flg_.sum())
+    if not (got_w["n_total"] == nt_w == got_w["n_undigested"] and got_w["n_rc"] == nrc_w and np.array_equal(got_w["hist"], hist_w) and got_w["sum"] == 0):
+        raise SystemExit("secondary: k = 64 reduce differs from the oracle's literal iterator on the prefix")
+    ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 64, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)), 6)
+    out["bytes_k64_counts"] = {"workload": "config-2 batch, CanonicalKmers k = 64 (33 <= k <= 255: counters + 6-base histogram, no sum / xor), resident",
+                               "kernel": "canonical_bytes_reduce_kernel<true>", "kernel_ms": round(ms, 4), "GB_s": round(k21_bytes / (ms * 1e-3) / 1e9, 1)}
+
     # materialise mode (dense u64 per window + two flag planes), config-2 batch
     vals = torch.empty((k21_bytes + 15) // 16 * 16, dtype=torch.int64, device="cuda")
     v16 = torch.empty((k21_bytes + 15) // 16, dtype=torch.int16, device="cuda")
