@@ -431,6 +431,7 @@ struct Chunk {
     // results
     int status = kOk;
     bool done = false, dropped = false;
+    uint32_t searching = 0;             // a worker is looking for the chunk's block boundary (read by the decoders of earlier chunks)
     bool deferred = false, in_flight = false;   // deferred: it outgrew the cap of a chunk that is not at the chain's head and waits to be decoded there
     bool at_end = false;                // the chunk decoded to the end of the file
     uint32_t end_chunk = 0;             // else: index of the chunk whose start_bit it stopped at
@@ -494,8 +495,14 @@ void decode_chunk(const uint8_t *in, uint64_t n, std::vector<Chunk> &chunks, uin
             const uint64_t here = b.bit_pos();
             uint32_t stop = 0;
             for (uint32_t j = next_chunk; j < chunks.size(); j++) {
-                const uint64_t sb = __atomic_load_n(&chunks[j].start_bit, __ATOMIC_ACQUIRE);
-                if (sb == kPending) { if (chunks[j].byte_begin * 8 > here) break; continue; }
+                uint64_t sb = __atomic_load_n(&chunks[j].start_bit, __ATOMIC_ACQUIRE);
+                if (sb == kPending) {
+                    if (chunks[j].byte_begin * 8 > here) break;
+                    // the boundary lies in the range chunk j is being searched in right now: the search's answer (milliseconds away, and it
+                    // always ends) decides whether this decoder stops here - running on would decode chunk j's text a second time
+                    if (!__atomic_load_n(&chunks[j].searching, __ATOMIC_ACQUIRE)) continue;   // nobody has taken chunk j yet: it cannot stop us
+                    while ((sb = __atomic_load_n(&chunks[j].start_bit, __ATOMIC_ACQUIRE)) == kPending) std::this_thread::yield();
+                }
                 if (sb == kNone || sb < here) { if (j == next_chunk) next_chunk++; continue; }
                 if (sb == here) stop = j;
                 break;
@@ -842,6 +849,25 @@ int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t lim
     };
     const auto tC = clk::now();
     std::atomic<uint64_t> search_ns{0};
+    auto search_chunk = [&](uint32_t i) -> uint64_t {
+        const auto s0 = clk::now();
+        uint64_t end = i + 1 < n_chunks ? chunks[i + 1].byte_begin : n;
+        if (end > chunks[i].byte_begin + (1u << 20)) end = chunks[i].byte_begin + (1u << 20);
+        const uint64_t sb = find_block(in, n, chunks[i].byte_begin, end, &pool);
+        search_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - s0).count();
+        return sb;
+    };
+    // the starts of the first chunks are found before anything is decoded (a few milliseconds, in parallel): chunk 0's decoder starts at once
+    // and would otherwise be past its successors' starts before their searches report; every later chunk is searched by the worker that takes
+    // it, far ahead of the decoder that will stop at it
+    {
+        const uint32_t first = n_chunks < max_ahead + 1 ? n_chunks : max_ahead + 1;
+        std::atomic<uint32_t> nx{1};
+        if (first > 1)
+            run_parallel(n_threads < first - 1 ? n_threads : first - 1, [&] {
+                for (uint32_t i; (i = nx.fetch_add(1)) < first;) __atomic_store_n(&chunks[i].start_bit, search_chunk(i), __ATOMIC_RELEASE);
+            });
+    }
     run_parallel(n_threads, [&] {
         std::unique_lock<std::mutex> lk(mu);
         try {
@@ -886,13 +912,12 @@ int inflate_impl(const uint8_t *in, uint64_t n, uint32_t n_threads, uint64_t lim
                     if (c.dropped) { c.done = true; continue; }
                     c.in_flight = true;
                     const bool is_head = i == chain_cur;
+                    const bool search = i > 0 && c.start_bit == kPending;
+                    if (search) __atomic_store_n(&c.searching, 1u, __ATOMIC_RELEASE);
+                    if (i > 0 && !search && c.start_bit == kNone) { c.done = true; c.dropped = true; c.in_flight = false; continue; }   // searched up front: no boundary
                     lk.unlock();
-                    if (i > 0) {
-                        const auto s0 = clk::now();
-                        uint64_t end = i + 1 < n_chunks ? chunks[i + 1].byte_begin : n;
-                        if (end > c.byte_begin + (1u << 20)) end = c.byte_begin + (1u << 20);
-                        const uint64_t sb = find_block(in, n, c.byte_begin, end, &pool);
-                        search_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - s0).count();
+                    if (search) {
+                        const uint64_t sb = search_chunk(i);
                         lk.lock();
                         __atomic_store_n(&c.start_bit, sb, __ATOMIC_RELEASE);   // (read by the decoders of earlier chunks at their block boundaries)
                         const bool skip = sb == kNone || c.dropped;
