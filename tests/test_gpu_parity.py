@@ -709,6 +709,17 @@ def test_gzip_file_streamed_through_the_parallel_producer(ctx, tmp_path):
             with pytest.raises(nt.NtkError) as e:
                 nt.scan_file_parallel(ctx, str(badf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=8, batch_bytes=1 << 20, streaming_fallback=False)
             assert e.value.status == 8, name
+        # the TEXT is bad (a FASTQ record without its quality line in the middle of a good stream): the parsers give up, the inflater is
+        # told to stop (it must not run on into memory nobody drains) and the call returns the parse error
+        cut_at = (n_reads // 2) * (len(text) // n_reads)
+        broken = text[:cut_at] + b"@broken\nACGT\n" + text[cut_at:]
+        badf = tmp_path / "badtext.fq.gz"
+        badf.write_bytes(gzip_member(broken, 1))
+        with pytest.raises(nt.NtkError) as e:
+            nt.scan_file_parallel(ctx, str(badf), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=8, batch_bytes=1 << 20, streaming_fallback=False)
+        assert e.value.status == 8
+        st = nt.scan_file_parallel(ctx, str(one), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=4, batch_bytes=1 << 18)   # and the ctx is fine afterwards
+        assert_stats_equal(st, small_want, "after a cancelled run")
         # a record longer than the window (a 20 MB contig against an 8 MiB window): the window grows instead of the run stalling
         rng = np.random.default_rng(9)
         contig = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20 << 20)].tobytes()
