@@ -426,6 +426,33 @@ def test_k_above_32_on_the_reduce_face(ctx, golden_dir):
         ctx.set_launch(0, 0)
 
 
+def test_ctx_options_round_trip(ctx):
+    """ntk_ctx_set_option / ntk_ctx_get_option (round 6: the producer reads its knobs through the getter; nothing reads the environment)."""
+    try:
+        assert ctx.get_option(NL.OPT_BATCH_WAIT_POLL_US) == 50 and ctx.get_option(NL.OPT_GZ_STREAM_WINDOW_BYTES) == 0
+        for opt, val, back in ((NL.OPT_BATCH_WAIT_POLL_US, 200, 200), (NL.OPT_BATCH_WAIT_POLL_US, NL.POLL_BLOCK, NL.POLL_BLOCK),
+                               (NL.OPT_BATCH_WAIT_POLL_US, 10**9, 10_000_000), (NL.OPT_GZ_STREAM_WINDOW_BYTES, 64 << 20, 64 << 20),
+                               (NL.OPT_GZ_INMEM_LIMIT_BYTES, 1 << 33, 1 << 33), (NL.OPT_PIPE_STATS, 1, 1),
+                               (NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_NO_SPECULATION | NL.ROUTE_NO_F64, NL.ROUTE_NO_SPECULATION | NL.ROUTE_NO_F64)):
+            ctx.set_option(opt, val)
+            assert ctx.get_option(opt) == back, (opt, val)
+        with pytest.raises(nt.NtkError):
+            ctx.get_option(99)
+        with pytest.raises(nt.NtkError):
+            ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 16)
+    finally:
+        for opt in (NL.OPT_BATCH_WAIT_POLL_US, NL.OPT_GZ_STREAM_WINDOW_BYTES, NL.OPT_GZ_INMEM_LIMIT_BYTES, NL.OPT_PIPE_STATS, NL.OPT_MINIMIZER_ROUTE):
+            ctx.set_option(opt, 0)
+    # a blocking wait (NTK_POLL_BLOCK) through the pinned-batch face gives the same result as the polling one
+    recs = [b"ACGTTGCAAGCTTGCATGCAAGTCGATCGATTAGC" * 3] * 50
+    want = O.reduce_records(recs, 21, O.PATH_BYTES_CANONICAL, O.PRE_NORMALIZE)
+    try:
+        ctx.set_option(NL.OPT_BATCH_WAIT_POLL_US, NL.POLL_BLOCK)
+        assert_stats_equal(_run_records(ctx, recs, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, batch_bytes=1 << 12), want, "blocking wait")
+    finally:
+        ctx.set_option(NL.OPT_BATCH_WAIT_POLL_US, 0)
+
+
 def test_unsupported_and_bad_args_are_errors(ctx):
     t = to_dev(b"ACGT" * 100)
     # un-normalised byte-path input: reduce mode has its raw-byte kernel (test_reduce_on_bytes_that_were_not_normalised); dense values and
