@@ -20,7 +20,7 @@
 // by design and measure what a class of the tile loop costs (profiles/r03c/ablation.txt, r04i/ablation.txt).  No product object may see one.
 #if !defined(NTK_KBENCH) && (defined(NTK_ABL_LOADSONLY) || defined(NTK_ABL_FLOOR) || defined(NTK_ABL_NOLDS) || defined(NTK_ABL_NODIGEST) || \
                              defined(NTK_ABL_NOEXEC) || defined(NTK_ABL_NOSDWA) || defined(NTK_ABL_NOMASKALG) || defined(NTK_V_CLOCKS) || \
-                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_ABL_HALFIMPORTS))
+                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_X_SELOUT) || defined(NTK_ABL_HALFIMPORTS))
 #error "NTK_ABL_* / NTK_X_* / NTK_V_CLOCKS are kernel-bench switches: build with -DNTK_KBENCH (tools/build_kbench.sh), never into the library"
 #endif
 
@@ -426,6 +426,38 @@ struct DevMasks2 {
                      : NTK_X_IN(0), NTK_X_IN(1), NTK_X_IN(2), NTK_X_IN(3), [one] "v"(one)
                      : "memory", "vcc", "scc");
 #undef NTK_X_IN
+#undef NTK_X_POS
+#elif defined(NTK_X_SELOUT)
+        // round-6 experiment (a''), profiles/r06j: compare AND select leave the region, as in the K >= 24 builds (emit_canon_wide) - under the
+        // full exec mask, scheduled by the compiler among the window words; the region keeps exec, the two digests, the atomic and the count
+        // (s_and of the compare's mask with exec + s_bcnt1 + s_add).  The k = 31 build, which has this shape, idles 41 cycles per tile where
+        // the k = 21 build idles 101.
+        uint64_t F[4], fm;
+        uint32_t ts[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool fwd = TIE_RC_ ? ft[i] < rt[i] : ft[i] <= rt[i];
+            F[i] = __builtin_amdgcn_ballot_w64(fwd);
+            ts[i] = fwd ? fl[i] : rl[i];
+        }
+#define NTK_X_POS(i, CNT)                                                   \
+        NTK_R_EXEC(i)                                                       \
+        NTK_R_SUM_##i("%[t" #i "]")                                         \
+        NTK_R_XOR("%[t" #i "]")                                             \
+        NTK_R_HIST(i)                                                       \
+        "s_and_b64 %[fm], exec, %[F" #i "]\n"                               \
+        CNT
+#define NTK_X_CNT_FIRST "s_bcnt1_i32_b64 %[nf], %[fm]\n"
+#define NTK_X_CNT "s_bcnt1_i32_b64 %[cn], %[fm]\n s_add_u32 %[nf], %[nf], %[cn]\n"
+#define NTK_X_IN(i) [o##i] "v"(off[i]), [t##i] "v"(ts[i]), [F##i] "s"(F[i]), NTK_R_MASKS(i)
+        asm volatile(NTK_X_POS(0, NTK_X_CNT_FIRST) NTK_X_POS(1, NTK_X_CNT) NTK_X_POS(2, NTK_X_CNT) NTK_X_POS(3, NTK_X_CNT) "s_mov_b64 exec, -1\n"
+                     : [sumA] "+v"(sum), [sumB] "+v"(sum2), [xlo] "+v"(xlo), [sd] "=&s"(sd), [nf] "=&s"(nf_grp), [cn] "=&s"(cn), [fm] "=&s"(fm)
+                     : NTK_X_IN(0), NTK_X_IN(1), NTK_X_IN(2), NTK_X_IN(3), [one] "v"(one)
+                     : "memory", "scc");
+        (void)t0; (void)t1; (void)t2; (void)t3;
+#undef NTK_X_IN
+#undef NTK_X_CNT
+#undef NTK_X_CNT_FIRST
 #undef NTK_X_POS
 #elif defined(NTK_X_TWOPHASE)
         // round-6 experiment (a'), profiles/r06a: the chain cut in two - first exec / compare / select / count of all four positions, then
