@@ -1016,7 +1016,8 @@ void pgz_stream_release(PgzStream *s)
     s->map = nullptr; s->base = nullptr; s->map_bytes = 0;
     // The range is address space (its pages went back behind the parsers); unmapping it means walking the page tables of everything the run
     // touched with the address space locked.  One range is kept for the next streamed run of the process instead.
-    {
+    // (DONTNEED gives pages back, not page tables: a range that has been written far - 2 MB of tables per GB of text - is not worth keeping)
+    if (s->ready <= ((uint64_t)8 << 30)) {
         std::lock_guard<std::mutex> g(g_text_mu);
         if (!g_text.p) { g_text = b; return; }
     }

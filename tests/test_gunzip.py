@@ -148,6 +148,26 @@ def test_truncated_literal_heavy_streams_end_at_once():
                 assert rc == NTK_ERR_PARSE and dt < 2.0, (name, cut, threads, rc, dt)
 
 
+def test_high_ratio_chunks_are_deferred_not_grown():
+    """a chunk that is not at the head of the chain decodes against a cap (96 M symbols) instead of the global limit; one
+    that outgrows it gives its buffers back and is decoded again when it is the head.  0.7 GB of one byte value at level 9 is ~0.7 MB of
+    deflate data - two chunks of 350 MB each: every speculative one is deferred, the result is still the input."""
+    n = 700_000_000
+    c = zlib.compressobj(9, zlib.DEFLATED, 31)
+    z = b"".join(c.compress(b"\x07" * (1 << 24)) for _ in range(n >> 24)) + c.compress(b"\x07" * (n & ((1 << 24) - 1))) + c.flush()
+    out, n_out, info = C.c_void_p(), C.c_uint64(0), L.GunzipInfo()
+    assert L.lib().ntk_gunzip(z, len(z), 4, C.byref(out), C.byref(n_out), C.byref(info)) == NTK_OK
+    try:
+        assert n_out.value == n and info.route == 2
+        got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n,))
+        assert int(got.min()) == 7 and int(got.max()) == 7
+        if info.chunks > 1:
+            assert info.chunks_deferred >= 1 or info.chunks_dropped >= info.chunks - 1, (info.chunks, info.chunks_deferred, info.chunks_dropped)
+    finally:
+        del got
+        L.lib().ntk_gunzip_free(out, n_out.value)
+
+
 def test_random_structured_inputs():
     """Data with long-range repeats, runs and incompressible stretches; random flush points make blocks of every size."""
     rng = np.random.default_rng(11)
