@@ -20,7 +20,7 @@
 // by design and measure what a class of the tile loop costs (profiles/r03c/ablation.txt, r04i/ablation.txt).  No product object may see one.
 #if !defined(NTK_KBENCH) && (defined(NTK_ABL_LOADSONLY) || defined(NTK_ABL_FLOOR) || defined(NTK_ABL_NOLDS) || defined(NTK_ABL_NODIGEST) || \
                              defined(NTK_ABL_NOEXEC) || defined(NTK_ABL_NOSDWA) || defined(NTK_ABL_NOMASKALG) || defined(NTK_V_CLOCKS) || \
-                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_X_SELOUT) || defined(NTK_ABL_HALFIMPORTS))
+                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_X_SELOUT) || defined(NTK_X_PREFETCH2) || defined(NTK_ABL_HALFIMPORTS))
 #error "NTK_ABL_* / NTK_X_* / NTK_V_CLOCKS are kernel-bench switches: build with -DNTK_KBENCH (tools/build_kbench.sh), never into the library"
 #endif
 
@@ -815,10 +815,21 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         // and 31, profiles/r03d/lateload_ab2.txt; two tiles per trip: 5 - 25 % slower, profiles/r02b, with the tile offset in the scalar
         // operand no gain, profiles/r03a/pp2_ab.txt; the first tile of the next chunk loaded during the last tile of this one: no gain,
         // profiles/r04b).
+#ifdef NTK_X_PREFETCH2
+        // round-6 experiment (profiles/r06k): TWO tiles in flight per wave (two register sets, the loop unrolled by two) - for the builds that
+        // are not held by VALU issue (forward-only: 110 VALU per tile, 27 % of the tile's cycles idle)
+        u32x4 tb = ta;
+        if (r0 + 1 < r1) tb = load_tile(voff + kStride);
+        for (uint32_t r = r0; r < r1; r += 2) {
+            process(ta, qa, r, [&] { if (r + 2 < r1) ta = load_tile(voff + 2 * kStride); });
+            if (r + 1 < r1) process(tb, qa, r + 1, [&] { if (r + 3 < r1) tb = load_tile(voff + 2 * kStride); });
+        }
+#else
         for (uint32_t r = r0; r < r1; r++)
             process(ta, qa, r, [&] {
                 if (r + 1 < r1) { ta = load_tile(voff + kStride); if constexpr (QM) qa = load_qual(voff + kStride); }
             });
+#endif
         next = __builtin_amdgcn_readfirstlane(next);
     }
 

@@ -51,6 +51,11 @@ int main(int argc, char **argv)
 #ifndef NTK_KB_HB
 #define NTK_KB_HB 12
 #endif
+        static const bool kb_fwd = getenv("KB_FWD") != nullptr;   // the forward-only builds (BitNuclKmer, canonical = false)
+        if (kb_fwd && k == 21) hipLaunchKernelGGL((scan2_kernel<21, false, false, false, NTK_KB_HB, 0, true>), dim3(blocks), dim3(threads), 0, 0, a);
+        else if (kb_fwd && k == 31) hipLaunchKernelGGL((scan2_kernel<31, false, false, false, NTK_KB_HB, 0, true>), dim3(blocks), dim3(threads), 0, 0, a);
+        else if (kb_fwd && k == 16) hipLaunchKernelGGL((scan2_kernel<16, false, false, false, NTK_KB_HB, 0, true>), dim3(blocks), dim3(threads), 0, 0, a);
+        else
         if (k == 21) hipLaunchKernelGGL((scan2_kernel<21, true, true, false, NTK_KB_HB>), dim3(blocks), dim3(threads), 0, 0, a);
         else if (k == 31) hipLaunchKernelGGL((scan2_kernel<31, true, true, false, NTK_KB_HB>), dim3(blocks), dim3(threads), 0, 0, a);
         else if (k == 23) hipLaunchKernelGGL((scan2_kernel<23, true, true, false, NTK_KB_HB>), dim3(blocks), dim3(threads), 0, 0, a);
