@@ -269,7 +269,8 @@ int get_event(ntk_ctx *c, hipEvent_t *e)
 // CanonicalKmers over raw (un-normalised) bytes into the accumulators: canonical_bytes_reduce_kernel + fold (ntk_kernels.hpp).
 int raw_bytes_blocks(const ntk_ctx *c, uint64_t n)
 {
-    const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile;
+    const uint64_t tile = (uint64_t)kPlThreads * 32;   // (canonical_bytes_reduce_kernel: 32 starts per thread)
+    const uint64_t n_tiles = (n + tile - 1) / tile;
     const uint64_t max_blocks = c->launch_blocks > 0 ? (uint64_t)c->launch_blocks : (uint64_t)c->n_cu * 8;
     return (int)(n_tiles < max_blocks ? n_tiles : max_blocks);
 }

@@ -1437,21 +1437,24 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
 {
     if (run_if && *run_if == 0u) return;
     const bool normalized = WIDE && normalized_arg;
-    __shared__ __align__(16) uint8_t s_b[kPlTile + 256 + 16];
+    // a thread walks PER starts + k - 1 bytes: 32 starts per thread (the plane kernels' 8 would be 3.5 byte steps per start at k = 21 and 9 at
+    // k = 64; 32: 1.6 and 3 - round 6: 5.0 -> 4.2 ms per 1.51 GB at k = 21 on mixed-case input, 13.6 -> 9.5 ms at k = 64, profiles/r06l)
+    constexpr uint32_t PER = 32u, TILE = (uint32_t)kPlThreads * PER;
+    __shared__ __align__(16) uint8_t s_b[TILE + 256 + 16];
     __shared__ uint32_t s_hist[kHistBins];
     __shared__ uint8_t s_comp[256];
     __shared__ uint64_t s_red[kPlThreads / 64][4];
     s_comp[threadIdx.x] = (uint8_t)comp_lut[threadIdx.x];
     for (int i = threadIdx.x; i < kHistBins; i += kPlThreads) s_hist[i] = 0;
-    const uint64_t n_tiles = (n + kPlTile - 1) / kPlTile;
-    const uint32_t need = kPlTile + k - 1;
+    const uint64_t n_tiles = (n + TILE - 1) / TILE;
+    const uint32_t need = TILE + k - 1;
     constexpr bool wide = WIDE;
     const uint64_t vmask_k = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t top = wide ? 0u : 2 * k - 2;
     uint64_t nv = 0, nf = 0, sum = 0, xr = 0;
     auto code_of = [](uint8_t c) -> uint32_t { const uint32_t x = (c >> 1) & 3u; return x ^ (x >> 1); };   // A0 C1 G2 T3 (U3), either case
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * kPlTile;
+        const uint64_t t0 = tile * TILE;
         __syncthreads();   // the previous tile's readers are done (and s_comp / s_hist are set up)
         for (uint32_t v = threadIdx.x; v * 16 < need; v += kPlThreads) {
             const uint64_t p = t0 + (uint64_t)v * 16;
@@ -1460,10 +1463,10 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
             *reinterpret_cast<u32x4 *>(&s_b[v * 16]) = x;
         }
         __syncthreads();
-        const uint32_t s = threadIdx.x * kPlPer;
+        const uint32_t s = threadIdx.x * PER;
         uint32_t run = 0;
         uint64_t fwd = 0, rc = 0;
-        for (uint32_t i = 0; i < kPlPer + k - 1; i++) {
+        for (uint32_t i = 0; i < PER + k - 1; i++) {
             const uint32_t idx = s + i;
             const uint8_t c = s_b[idx], cu = c & 0xDF;
             const bool good = t0 + idx < n && (cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || (normalized && cu == 'U'));
