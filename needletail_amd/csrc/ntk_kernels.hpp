@@ -20,7 +20,7 @@
 // by design and measure what a class of the tile loop costs (profiles/r03c/ablation.txt, r04i/ablation.txt).  No product object may see one.
 #if !defined(NTK_KBENCH) && (defined(NTK_ABL_LOADSONLY) || defined(NTK_ABL_FLOOR) || defined(NTK_ABL_NOLDS) || defined(NTK_ABL_NODIGEST) || \
                              defined(NTK_ABL_NOEXEC) || defined(NTK_ABL_NOSDWA) || defined(NTK_ABL_NOMASKALG) || defined(NTK_V_CLOCKS) || \
-                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_X_SELOUT) || defined(NTK_X_PREFETCH2) || defined(NTK_ABL_HALFIMPORTS))
+                             defined(NTK_X_CMPFIRST) || defined(NTK_X_TWOPHASE) || defined(NTK_X_MFMASUM) || defined(NTK_X_SELOUT) || defined(NTK_X_PREFETCH2) || defined(NTK_X_FASTSTART) || defined(NTK_ABL_HALFIMPORTS))
 #error "NTK_ABL_* / NTK_X_* / NTK_V_CLOCKS are kernel-bench switches: build with -DNTK_KBENCH (tools/build_kbench.sh), never into the library"
 #endif
 
@@ -709,11 +709,6 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
     uint32_t dbg_tiles = 0;
 #endif
-    if (a.zero_acc && blockIdx.x == 0)   // NTK_FLAG_RESET: the accumulators start from zero (see ScanArgs)
-        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
-    for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
-    __syncthreads();
-
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t shard = blockIdx.x % a.n_shards;
@@ -723,6 +718,20 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     if (shard_end > launch_tiles) shard_end = launch_tiles;
     uint32_t *ctr = a.work_counters + shard * 16;
     const uint32_t shard_tiles = shard_begin < shard_end ? shard_end - shard_begin : 0u;
+#ifdef NTK_X_FASTSTART
+    // round-6 experiment (profiles/r06o): the wave's first pull is in flight while the block zeroes its histogram (128-bit stores)
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+    if (a.zero_acc && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
+    for (int i = threadIdx.x; i < kCells / 4; i += blockDim.x) reinterpret_cast<u32x4 *>(s_hist)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+#else
+    if (a.zero_acc && blockIdx.x == 0)   // NTK_FLAG_RESET: the accumulators start from zero (see ScanArgs)
+        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
+    for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+#endif
     // SPEC: the byte path's tie rule on bytes nobody normalised (NTK_PATH_BYTES_CANONICAL with pre < NORMALIZE).  The reference compares RAW
     // bytes (src/kmer.rs:121-128), which is the 2-bit order as long as no base is lower case - what Sequence::normalize reports by returning
     // None on a clean read (src/sequence.rs:57-61).  The build ORs every byte it loads into `lc` (two full-rate ops per tile); a wave that saw
@@ -738,8 +747,10 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     { const int sel = 1 << (8 * (lane & 3)); mp.msel = {sel, sel, sel, sel}; }   // B[k][j] = [k % 4 == j % 4]: column j sums the bytes of significance j % 4
 #endif
 
+#ifndef NTK_X_FASTSTART
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+#endif
     next = __builtin_amdgcn_readfirstlane(next);
     while (next < shard_tiles) {
         const uint32_t r0 = shard_begin + next;
