@@ -709,6 +709,13 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
     uint32_t dbg_tiles = 0;
 #endif
+#ifndef NTK_X_FASTSTART
+    if (a.zero_acc && blockIdx.x == 0)   // NTK_FLAG_RESET: the accumulators start from zero (see ScanArgs)
+        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
+    for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t shard = blockIdx.x % a.n_shards;
@@ -725,11 +732,6 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     if (a.zero_acc && blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
     for (int i = threadIdx.x; i < kCells / 4; i += blockDim.x) reinterpret_cast<u32x4 *>(s_hist)[i] = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-#else
-    if (a.zero_acc && blockIdx.x == 0)   // NTK_FLAG_RESET: the accumulators start from zero (see ScanArgs)
-        for (uint32_t i = threadIdx.x; i < a.zero_words; i += blockDim.x) a.zero_acc[i] = 0;
-    for (int i = threadIdx.x; i < kCells; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
 #endif
     // SPEC: the byte path's tie rule on bytes nobody normalised (NTK_PATH_BYTES_CANONICAL with pre < NORMALIZE).  The reference compares RAW
