@@ -1047,6 +1047,58 @@ def test_specimen_corpus_through_the_pipeline(ctx):
     assert n_kmers > 10_000
 
 
+def test_specimen_corpus_gzipped_through_the_streamed_route(ctx, tmp_path):
+    """Round 6: the same corpus, every valid file gzip-compressed (one member; every third file as two members, every fifth as block gzip),
+    through ntk_scan_file_parallel's streamed route (inflater + parser threads side by side) - multi-line FASTA, DOS line ends, zero-length
+    records, files of a few bytes - against the literal per-record chain; then the shapes that must be errors: an empty member (EmptyFile,
+    reference src/parser/mod.rs:88-91), text that is neither FASTA nor FASTQ, a truncated record at the end of the text, garbage after the
+    last member."""
+    import gzip
+    import zlib
+    files = _specimen_files()
+    n_kmers = 0
+    for i, path in enumerate(files):
+        data = open(path, "rb").read()
+        recs = [r.raw_seq for r in nt.parse_fastx_file(path)]
+        if i % 5 == 4:
+            try:
+                import ctypes
+                ctypes.CDLL("libdeflate.so.0")
+                z = bgzf_compress(data, block=997)
+            except OSError:
+                z = gzip.compress(data)
+        elif i % 3 == 2 and len(data) > 40:
+            cut = data.rfind(b"\n", 0, len(data) // 2) + 1 or len(data) // 2     # (members need not end at record boundaries)
+            z = gzip.compress(data[:cut], 6) + gzip.compress(data[cut:], 1)
+        else:
+            z = gzip.compress(data, 9 if i % 2 else 1)
+        gz = tmp_path / "s.gz"
+        gz.write_bytes(z)
+        for k, p_, pre, threads in ((4, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, 3), (21, nt.PATH_BITS_CANONICAL, nt.PRE_STRIP_RETURNS, 2)):
+            if len(data) < 2:
+                continue
+            st = nt.scan_file_parallel(ctx, str(gz), k, p_, pre, threads=threads, batch_bytes=1 << 14, streaming_fallback=False)
+            assert st["gzip"]["streamed"] == 1 and st["gzip"]["text_bytes"] == len(data), path
+            assert st["n_records"] == len(recs), path
+            assert_stats_equal(st, O.reduce_records(recs, k, p_, pre), f"{os.path.basename(path)} k={k} gz")
+            n_kmers += st["n_total"]
+    assert n_kmers > 10_000
+    good = b"@r1\nACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIII\n"
+    for name, z in (("empty member", gzip.compress(b"")), ("one byte", gzip.compress(b"A")), ("not FASTA / FASTQ", gzip.compress(b"hello world\nACGT\n" * 50)),
+                    ("truncated last record", gzip.compress(good * 40 + b"@r2\nACGT\n+\n")),
+                    ("garbage after the last member", gzip.compress(good * 40) + b"\x00\x01garbage garbage garbage")):
+        bad = tmp_path / "bad.gz"
+        bad.write_bytes(z)
+        with pytest.raises(nt.NtkError) as e:
+            nt.scan_file_parallel(ctx, str(bad), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=3, batch_bytes=1 << 14, streaming_fallback=False)
+        assert e.value.status == 8, name
+    # trailing zero padding after the last member is tolerated (as zlib-based readers do), and the ctx works after the errors
+    ok = tmp_path / "padded.gz"
+    ok.write_bytes(gzip.compress(good * 40) + b"\0" * 512)
+    st = nt.scan_file_parallel(ctx, str(ok), 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, threads=3, batch_bytes=1 << 14, streaming_fallback=False)
+    assert st["n_records"] == 40 and st["n_total"] == 40 * 6
+
+
 # ---- quality masking fused into the scan (SURVEY.md 8f-4; reference src/sequence.rs:285-296) -----------------------
 
 def _qual_dev(qual: bytes):
