@@ -137,7 +137,7 @@ def main():
         if skip:
             # the draws of the branch this iteration took, without its device work
             if what < 5:
-                if path == nt.PATH_BYTES_CANONICAL: rng.random()
+                if path == nt.PATH_BYTES_CANONICAL and rng.random() < 0.3: rng.choice([0, 0, 0, 33, 48, 64, 255]); rng.integers(0, 2)
             elif what < 6 and n <= 400000:
                 pass
             elif what < 8 and canon and (path, pre) in ((nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE), (nt.PATH_BITS_CANONICAL, nt.PRE_NONE)):
@@ -173,6 +173,32 @@ def main():
             continue
         if what < 5:
             if path == nt.PATH_BYTES_CANONICAL and rng.random() < 0.3:
+                kw, norm = int(rng.choice([0, 0, 0, 33, 48, 64, 255])), int(rng.integers(0, 2))
+                if kw and n <= 60000:
+                    # round 6: CanonicalKmers with k > 32 on the reduce face (counters + histogram of the leading six bases; no sum / xor), input
+                    # normalised or not, against the literal iterator
+                    pre_w = nt.PRE_NORMALIZE if norm else nt.PRE_NONE
+                    ctx.accum_reset(); ctx.reduce_device(t, n, kw, path, pre_w)
+                    got = ctx.accum_read()
+                    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+                    nt_w = nrc_w = 0
+                    hist_w = np.zeros(4096, dtype=np.uint64)
+                    import re as _re
+                    for r_ in (_re.split(rb"[\n\r\t ]", buf) if norm else buf.split(b"\n")):   # (on the device face the deleted class is a break: the packer drops it, reduce_device does not)
+                        if norm: r_ = O.normalize(r_)[0]
+                        rc_ = O.reverse_complement(r_)
+                        pos_, flg_ = O.canonical_kmers_arrays(r_, rc_, kw)
+                        for p_, f_ in zip(pos_.tolist(), flg_.tolist()):
+                            sl = rc_[len(rc_) - p_ - kw: len(rc_) - p_] if f_ else r_[p_: p_ + kw]
+                            b_ = 0
+                            for ch in sl[:6]: b_ = b_ * 4 + code[ch]
+                            hist_w[b_] += 1
+                        nt_w += len(pos_); nrc_w += int(flg_.sum())
+                    if not (got["n_total"] == nt_w == got["n_undigested"] and got["n_rc"] == nrc_w and got["n_fwd"] == nt_w - nrc_w
+                            and np.array_equal(got["hist"], hist_w) and got["sum"] == 0 and got["xor"] == 0):
+                        print("MISMATCH wide-k reduce", tag, "k", kw, "normalised", norm); return 1
+                    counts["wide_k"] = counts.get("wide_k", 0) + 1
+                    continue
                 # the byte path on input that is NOT normalised: raw-byte strand compare (mixed case), against the literal chain per record
                 ctx.accum_reset(); ctx.reduce_device(t, n, k, path, nt.PRE_NONE)
                 if not stats_equal(ctx.accum_read(), O.reduce_records(buf.split(b"\n"), k, path, nt.PRE_NONE)):
