@@ -99,6 +99,8 @@ class Record:
         return f"Record(id={id_snippet}, seq={snippet(self.seq)}, qual={snippet(self.qual) if self.qual is not None else 'None'})"
 
 
+# (outside SURVEY.md section 8 - record writers / header and quality helpers of the reference's surface, SURVEY section 2 rows 5 and 11: host-side
+# conveniences kept for callers of the Python facade; nothing on the hot path uses them and no further surface of this kind is added)
 def write_fasta(id: bytes, seq: bytes, writer, line_ending: str = "\n") -> None:
     """reference src/parser/record.rs:207-220"""
     e = line_ending.encode()
@@ -191,6 +193,8 @@ def parse_fastx_file(path) -> FastxReader:
     return FastxReader(path=path)
 
 
+# (outside SURVEY.md section 8 - record writers / header and quality helpers of the reference's surface, SURVEY section 2 rows 5 and 11: host-side
+# conveniences kept for callers of the Python facade; nothing on the hot path uses them and no further surface of this kind is added)
 def decode_phred(qual: str, base_64: bool = False) -> tuple:
     """needletail.decode_phred (reference src/python.rs:416-427, src/quality.rs:10-28): quality characters minus the
     offset (33, or 64 with base_64); a character below the offset is a ValueError."""

@@ -292,6 +292,8 @@ def canonical(seq: bytes, ctx: Context = None) -> bytes:
     return out.raw[:len(seq)]
 
 
+# (outside SURVEY.md section 8 - record writers / header and quality helpers of the reference's surface, SURVEY section 2 rows 5 and 11: host-side
+# conveniences kept for callers of the Python facade; nothing on the hot path uses them and no further surface of this kind is added)
 def mask_header_tabs(id: bytes):
     """reference src/parser/record.rs:188-194: tabs -> '|'; None when there is nothing to mask."""
     return id.replace(b"\t", b"|") if b"\t" in id else None
