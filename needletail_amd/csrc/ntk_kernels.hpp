@@ -754,11 +754,27 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
     if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
 #endif
     next = __builtin_amdgcn_readfirstlane(next);
+#ifdef NTK_X_GUIDED   // kbench experiment (profiles/r06q): the pulls shrink over a shard's last stretch (remaining / (2 x the shard's waves), at least 2 tiles)
+    uint32_t c_cur = a.chunk_tiles;
+    const uint32_t shard_waves2 = 2u * ((gridDim.x + a.n_shards - 1) / a.n_shards) * (blockDim.x >> 6);
+#endif
     while (next < shard_tiles) {
         const uint32_t r0 = shard_begin + next;
+#ifdef NTK_X_GUIDED
+        uint32_t r1 = r0 + c_cur;
+        if (r1 > shard_end) r1 = shard_end;
+        {
+            const uint32_t done = next + c_cur < shard_tiles ? next + c_cur : shard_tiles;
+            uint32_t c = (shard_tiles - done) / shard_waves2;
+            c = c < 2u ? 2u : (c > a.chunk_tiles ? a.chunk_tiles : c);
+            c_cur = c;
+            if (lane == 0) next = atomicAdd(ctr, c);
+        }
+#else
         uint32_t r1 = r0 + a.chunk_tiles;
         if (r1 > shard_end) r1 = shard_end;
         if (lane == 0) next = atomicAdd(ctr, a.chunk_tiles);
+#endif
         const uint64_t t0 = a.tile_begin + r0;
         const uint64_t run_byte = t0 * kStride;
         const uint32_t halo = t0 ? kHaloB : 0u;

@@ -767,7 +767,11 @@ NTK_HD void window_masks_ab(const uint64_t (&G)[16], uint64_t (&A)[16], uint64_t
         if (c < 0) v &= S[(33 + j - K) & 15] << 2;
         B[j] = v;
     }
+#ifdef NTK_X_EXACTHALO   // the lane shifts of B already clear every window that reaches before lane 0: lane 0 always, lane 1 for j < K - 17
+    A[0] = G[0];
+#else
     A[0] = G[0] & ~3ull;  // halo lanes 0/1: cleared once here, inherited by every prefix
+#endif
 #pragma unroll
     for (int j = 1; j < 16; j++) A[j] = A[j - 1] & G[j];
 }
@@ -840,7 +844,11 @@ template <int KM> struct Sv2Geom {
     static_assert(KM >= 1 && KM <= 48, "window of at most 48 bytes");
     static constexpr int kHalo = KM <= 32 ? 2 : 3;
     static constexpr int kSlots = 64 - kHalo;
+#ifdef NTK_X_EXACTHALO   // kbench experiment (profiles/r06q): a tile advances by all the bytes whose windows lie inside it, 1024 - (k - 1) rounded down to a dword
+    static constexpr int kStride = (KM >= 17 && KM <= 32) ? ((1024 - (KM - 1)) & ~3) : kSlots * 16;
+#else
     static constexpr int kStride = kSlots * 16;
+#endif
     static constexpr int kHaloBytes = kHalo * 16;
     static constexpr uint64_t kKeep = ~((1ull << kHalo) - 1ull);   // lanes that emit
 };

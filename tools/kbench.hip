@@ -35,6 +35,15 @@ int main(int argc, char **argv)
     uint32_t *d_work; CHK(hipMalloc(&d_work, 65536));
     a.n_shards = argc > 8 ? atoi(argv[8]) : (blocks < 8 ? blocks : 8); a.tiles_per_shard = (uint32_t)((a.n_tiles + a.n_shards - 1) / a.n_shards);
     a.chunk_tiles = chunk; a.work_counters = d_work; a.tail_tile_rel = (uint32_t)(n / kTileStride);
+#ifdef NTK_X_EXACTHALO   // (profiles/r06q) tile t emits the windows ending in [S t - 32 + (k - 1), S (t + 1) - 32 + (k - 1)) and reads up to S t + 992
+    {
+        const uint64_t S = (uint64_t)Sv2Geom<21>::kStride, lead = 32 - (k - 1);
+        if (k != 21) { printf("NTK_X_EXACTHALO: kbench runs k = 21 only\n"); return 1; }
+        a.n_tiles = (n + lead + S - 1) / S; a.tile_end = a.n_tiles;
+        a.tiles_per_shard = (uint32_t)((a.n_tiles + a.n_shards - 1) / a.n_shards);
+        a.tail_tile_rel = (uint32_t)(n > 992 ? (n - 992) / S : 0);
+    }
+#endif
     CHK(hipMalloc(&d_ph, (size_t)blocks * kHistBins * 4)); CHK(hipMalloc(&d_ps, (size_t)blocks * 32)); CHK(hipMalloc(&d_acc, (8 + kHistBins + 64) * 8));
     a.part_hist = d_ph; a.part_scalars = d_ps;
 #ifdef NTK_V_CLOCKS
