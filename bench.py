@@ -315,7 +315,8 @@ def secondary_measurements(ctx, nt, torch, k21_seq, k21_bytes, reads, read_len):
         raise SystemExit("secondary: k = 64 reduce differs from the oracle's literal iterator on the prefix")
     ms = kernel_ms(lambda: (ctx.accum_reset(), ctx.reduce_device(k21_seq, k21_bytes, 64, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE)), 6)
     out["bytes_k64_counts"] = {"workload": "config-2 batch, CanonicalKmers k = 64 (33 <= k <= 255: counters + 6-base histogram, no sum / xor), resident",
-                               "kernel": "canonical_bytes_reduce_kernel<true>", "kernel_ms": round(ms, 4), "GB_s": round(k21_bytes / (ms * 1e-3) / 1e9, 1)}
+                               "kernel": "wide_canonical_reduce_kernel<true> (strand on the first 32 bases of the packed streams; canonical_bytes_reduce_kernel<true> "
+                                         "queued behind its flag, returns at once on this batch)", "kernel_ms": round(ms, 4), "GB_s": round(k21_bytes / (ms * 1e-3) / 1e9, 1)}
 
     # materialise mode (dense u64 per window + two flag planes), config-2 batch
     vals = torch.empty((k21_bytes + 15) // 16 * 16, dtype=torch.int64, device="cuda")

@@ -303,6 +303,44 @@ int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk
     return NTK_OK;
 }
 
+// CanonicalKmers with k = 33..255 (counters + histogram): wide_canonical_reduce_kernel decides the strand on the first 32 bases of the packed
+// 2-bit streams; canonical_bytes_reduce_kernel<true> is queued behind it and returns at once unless that launch raised its flag (two k-mers
+// equal over 32 bases, or - on input that was not normalised - a byte with bit 5 set), and the fold takes whichever partials are valid.  No
+// host round trip; 0.8 ms instead of 9.5 per 1.5 GB at k = 64 (profiles/r06r).  The direct route under NTK_ROUTE_NO_SPECULATION.
+int run_wide_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, bool zero_first, bool normalized)
+{
+    if (c->route_off & NTK_ROUTE_NO_SPECULATION) return run_raw_bytes_reduce(c, d_seq, n, p, zero_first, normalized);
+    if (zero_first) HIPCHK(hipMemsetAsync(c->d_acc, 0, NTK_ACC_WORDS * sizeof(uint64_t), c->stream));
+    const uint64_t n_tiles = (n + kWkTile - 1) / kWkTile;
+    const uint64_t max_blocks = c->launch_blocks > 0 ? (uint64_t)c->launch_blocks : (uint64_t)c->n_cu * 8;
+    const int blocks = (int)(n_tiles < max_blocks ? n_tiles : max_blocks), blocks_raw = raw_bytes_blocks(c, n);
+    int rc = ensure_partials(c, blocks > blocks_raw ? blocks : blocks_raw);
+    if (rc) return rc;
+    uint32_t *flag = c->d_lower + c->lower_idx;
+    c->lower_idx = (c->lower_idx + 1) % kLowerRing;
+    uint32_t *flag_next = c->d_lower + c->lower_idx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        rc = get_event(c, &e0); if (rc) return rc;
+        rc = get_event(c, &e1); if (rc) { c->ev_free.push_back(e0); return rc; }
+        HIPCHK(hipEventRecord(e0, c->stream));
+    }
+    if (normalized)
+        hipLaunchKernelGGL(wide_canonical_reduce_kernel<true>, dim3(blocks), dim3(kWkThreads), 0, c->stream, d_seq, n, p->k, c->d_part_hist, c->d_part_scalars, flag, flag_next);
+    else
+        hipLaunchKernelGGL(wide_canonical_reduce_kernel<false>, dim3(blocks), dim3(kWkThreads), 0, c->stream, d_seq, n, p->k, c->d_part_hist, c->d_part_scalars, flag, flag_next);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(canonical_bytes_reduce_kernel<true>, dim3(blocks_raw), dim3(kPlThreads), 0, c->stream, d_seq, n, (n + 15) & ~(uint64_t)15, p->k,
+                       2u * (p->k - 6u), (const uint16_t *)(c->d_lut + 768), c->d_part_hist, c->d_part_scalars, (const uint32_t *)flag, normalized ? 1u : 0u);
+    HIPCHK(hipGetLastError());
+    if (c->timing) { HIPCHK(hipEventRecord(e1, c->stream)); c->ev_used.emplace_back(e0, e1); }
+    hipLaunchKernelGGL(fold_kernel, dim3(kFoldBlocks), dim3(kFoldThreads), 0, c->stream,
+                       (const uint32_t *)c->d_part_hist, (const uint64_t *)c->d_part_scalars, blocks, c->d_acc, (uint32_t *)nullptr, 0,
+                       (const uint32_t *)flag, blocks_raw, 1);
+    HIPCHK(hipGetLastError());
+    return NTK_OK;
+}
+
 // One scan over d_seq[0, n): launches cover at most kMaxTilesPerLaunch tiles each so that per-block u32
 // histogram cells and 32-bit buffer offsets cannot overflow.
 int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, const Mode &m, bool reduce,
@@ -331,7 +369,8 @@ int run_scan(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, 
         // window starts, the scan on window ends: their launch ranges do not line up), the direct route otherwise and under NTK_ROUTE_NO_SPECULATION.
         const uint64_t tiles_all = ((n + 15) / 16 + tile_slots - 1) / tile_slots;
         speculate = p->k <= 32 && tiles_all <= kMaxTilesPerLaunch && !(c->route_off & NTK_ROUTE_NO_SPECULATION);
-        if (!speculate) return run_raw_bytes_reduce(c, d_seq, n, p, zero_first, p->k > 32 && m.accept_u);
+        if (p->k > 32) return run_wide_reduce(c, d_seq, n, p, zero_first, m.accept_u);
+        if (!speculate) return run_raw_bytes_reduce(c, d_seq, n, p, zero_first, false);
     }
     // materialise mode stages 8.7 KiB per wave through LDS: 256-thread blocks, 4 per CU
     const void *fn = fused_min_fn ? fused_min_fn

@@ -1547,6 +1547,128 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CanonicalKmers with 33 <= k <= 255 (reference src/kmer.rs:48-82: k is a u8) on the reduce face, from the packed 2-bit streams: what
+// canonical_bytes_reduce_kernel<true> produces (counters + histogram of the chosen strand's leading six bases; such k-mers have no 64-bit
+// value, so no sum / xor) at a twelfth of its time - that kernel walks PER + k - 1 bytes per thread and compares byte by byte.
+//   * A block stages 4096 window ENDS + the 256 bytes before them (k - 1 <= 254) as 272 slots of 16 bases: the scan2 encode gives each
+//     slot its forward code word, its reverse-complement word and its break mask (ntk_tile.hpp encode16_sv2, bad16_from_letters).
+//   * Validity: a window is emitted iff no break lies in its k bytes.  Per slot the position of its last break; an inclusive max-scan
+//     over the slots (wave shuffles + one LDS round) hands every thread the last break before its own slot, and with the own mask that
+//     is a 16-bit window mask in a dozen scalar-free ops - no per-position lane masks (the window may span sixteen lanes).
+//   * Strand: the k-mer's first 32 bases against its reverse complement's first 32 (the complement of its LAST 32, reversed): two
+//     funnel shifts each from three realigned forward words (the window starts k - 1 bases back: a wave-uniform word offset and bit
+//     offset) and from the own and the two previous reverse-complement words; `<` on the (hi, lo) pair as the reference's slice compare
+//     gives it (src/kmer.rs:124-128: ties report the reverse complement).  k >= 33, so 32 bases are a proper prefix; two k-mers that
+//     agree on them (4^-32 per position on random text, but every window of a long inverted repeat) raise *redo_flag, and so does a byte
+//     with bit 5 set when the input was not normalised (lower case: the raw-byte order is then not the 2-bit order) - the host has queued
+//     canonical_bytes_reduce_kernel<true> behind this launch, which then redoes it (run_wide_reduce in ntk_api.hip; the fold takes
+//     whichever partials are valid).  ACCEPT_U: the batch is read as Sequence::normalize leaves it (U / u are T, src/sequence.rs:24-51).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWkThreads = 256, kWkTile = kWkThreads * 16, kWkHaloSlots = 16, kWkSlots = kWkThreads + kWkHaloSlots;
+__device__ __forceinline__ uint32_t wk_take32(uint32_t hi, uint32_t lo, uint32_t bits)   // 32 bits of the stream (hi : lo) starting `bits` (0..30) after hi's top bit
+{
+    return bits ? alignbit(hi, lo, 32u - bits) : hi;
+}
+template <bool ACCEPT_U>
+__global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const uint8_t *seq, uint64_t n, uint32_t k, uint32_t *part_hist,
+                                                                           uint64_t *part_scalars, uint32_t *redo_flag, uint32_t *redo_flag_next)
+{
+    __shared__ uint32_t s_code[kWkSlots + 2], s_rcode[kWkSlots];
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ int32_t s_wmax[kWkThreads / 64 + 1];
+    __shared__ uint64_t s_red[kWkThreads / 64][2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (int i = tid; i < kHistBins; i += kWkThreads) s_hist[i] = 0;
+    if (tid < 2) s_code[kWkSlots + tid] = 0;   // read as the far half of a funnel shift whose bits are not used (see R2 below)
+    if (redo_flag_next && blockIdx.x == 0 && tid == 0) *redo_flag_next = 0;   // the next launch's flag (a ring, as the scan's lower_flag)
+    const uint64_t n_tiles = (n + kWkTile - 1) / kWkTile, n_readable = (n + 15) & ~(uint64_t)15;
+    // the window ending at byte 0 of slot s starts k - 1 bases earlier: in code word s - back, base_off bases below its top
+    const uint32_t back = (k - 1u + 15u) >> 4, base_bits = 2u * ((16u - ((k - 1u) & 15u)) & 15u);
+    const int32_t s_own = (int32_t)tid + kWkHaloSlots;
+    uint32_t nv = 0, nf = 0, redo = 0, lc = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t t0 = (int64_t)(tile * kWkTile) - 16 * kWkHaloSlots;   // byte of staged slot 0 (negative in the first tile)
+        __syncthreads();   // the previous tile's readers are done (first trip: s_hist is zero)
+        auto stage = [&](int32_t s, uint32_t &bad) -> int32_t {   // encodes slot s; returns the staged position of its last break (-1: none)
+            const int64_t p = t0 + 16 * (int64_t)s;
+            u32x4 x = {0u, 0u, 0u, 0u};
+            if (p >= 0 && (uint64_t)p + 16 <= n_readable) x = *reinterpret_cast<const u32x4 *>(seq + p);
+            if (!ACCEPT_U) lc |= x.x | x.y | x.z | x.w;
+            const EncSV2 en = encode16_sv2<ACCEPT_U>(Raw16{x.x, x.y, x.z, x.w});
+            bad = bad16_from_letters(en.ex, en.uu);   // base i at bit 15 - i
+            const int64_t keep = (int64_t)n - p;      // bytes of the slot that belong to the input: the rest are breaks
+            if (p < 0 || keep <= 0) bad = 0xFFFFu;
+            else if (keep < 16) bad |= 0xFFFFu >> (uint32_t)keep;
+            s_code[s] = en.code; s_rcode[s] = en.rcode;
+            return bad ? 16 * s + 15 - (int32_t)__builtin_ctz(bad) : -1;
+        };
+        uint32_t bad_own, bad_halo;
+        int32_t inc = stage(s_own, bad_own);
+        int32_t halo = -1;
+        if (tid < kWkHaloSlots) halo = stage((int32_t)tid, bad_halo);
+        if (wave == 0) {   // last break of the halo slots (lanes 0..15 of wave 0)
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { const int32_t y = __shfl_xor(halo, o, 64); halo = y > halo ? y : halo; }
+            if (lane == 0) s_wmax[kWkThreads / 64] = halo;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {   // inclusive max-scan over the wave's slots
+            const int32_t y = __shfl_up(inc, o, 64);
+            if ((int)lane >= o && y > inc) inc = y;
+        }
+        if (lane == 63) s_wmax[wave] = inc;
+        int32_t before = __shfl_up(inc, 1, 64);   // last break before the own slot, within the wave
+        if (lane == 0) before = -1;
+        __syncthreads();
+        {
+            const int32_t h = s_wmax[kWkThreads / 64];
+            before = h > before ? h : before;
+            for (uint32_t w = 0; w < wave; w++) { const int32_t y = s_wmax[w]; before = y > before ? y : before; }
+        }
+        // the window ending at own byte j is emitted iff j is below the own first break and at least k bytes behind the last break before the slot
+        const uint32_t first_bad = bad_own ? (uint32_t)__builtin_clz(bad_own) - 16u : 16u;
+        const uint32_t mask_own = first_bad >= 16u ? 0xFFFFu : ((0xFFFFu << (16u - first_bad)) & 0xFFFFu);
+        const int32_t thr = before + (int32_t)k - 16 * s_own;
+        const uint32_t mask_inh = thr <= 0 ? 0xFFFFu : (thr >= 16 ? 0u : (0xFFFFu >> (uint32_t)thr));
+        const uint32_t valid = mask_own & mask_inh;   // position j at bit 15 - j
+        const uint32_t i0 = (uint32_t)s_own - back;
+        const uint32_t w0 = s_code[i0], w1 = s_code[i0 + 1], w2 = s_code[i0 + 2], w3 = s_code[i0 + 3];
+        // three words realigned to the first window's first base (bases a0 .. a0 + 47; the last one is never used, so w3 may be a word nobody staged)
+        const uint32_t R0 = wk_take32(w0, w1, base_bits), R1 = wk_take32(w1, w2, base_bits), R2 = wk_take32(w2, w3, base_bits);
+        const uint32_t rc0 = s_rcode[s_own], rc1 = s_rcode[s_own - 1], rc2 = s_rcode[s_own - 2];
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t F1 = j ? alignbit(R0, R1, 32 - 2 * j) : R0, F2 = j ? alignbit(R1, R2, 32 - 2 * j) : R1;
+                const uint32_t V1 = j < 15 ? alignbit(rc0, rc1, 2 * j + 2) : rc0, V2 = j < 15 ? alignbit(rc1, rc2, 2 * j + 2) : rc1;
+                if ((valid >> (15 - j)) & 1u) {   // (the strand bits gathered branch-free and counted once per slot: 10 % slower, profiles/r06r)
+                    const bool lt = F1 < V1 || (F1 == V1 && F2 < V2);
+                    redo |= (F1 == V1 && F2 == V2) ? 1u : 0u;
+                    atomicAdd(&s_hist[(lt ? F1 : V1) >> 20], 1u);
+                    nv++; nf += lt ? 1u : 0u;
+                }
+            }
+        }
+    }
+    if (!ACCEPT_U && (lc & 0x20202020u)) redo = 1;
+    if (redo_flag && __builtin_amdgcn_ballot_w64(redo != 0u) != 0ull && lane == 0) atomicOr(redo_flag, 1u);
+    __syncthreads();
+    uint32_t *ph = part_hist + (size_t)blockIdx.x * kHistBins;
+    for (int i = tid; i < kHistBins; i += kWkThreads) ph[i] = s_hist[i];
+    uint64_t nv64 = nv, nf64 = nf;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nv64 += __shfl_xor(nv64, o, 64); nf64 += __shfl_xor(nf64, o, 64); }
+    if (lane == 0) { s_red[wave][0] = nv64; s_red[wave][1] = nf64; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t tv = 0, tf = 0;
+        for (int w = 0; w < kWkThreads / 64; w++) { tv += s_red[w][0]; tf += s_red[w][1]; }
+        uint64_t *ps = part_scalars + (size_t)blockIdx.x * 4;
+        ps[0] = tv; ps[1] = tf; ps[2] = 0; ps[3] = 0;
+    }
+}
+
 // BitNuclKmer (reference src/bitkmer.rs:39-109, Sequence::bit_kmers src/sequence.rs:250-252) in the same bit-plane form, for
 // ntk_bit_kmers_batch_planes: per window START "emitted" and "was_rc", plus (optionally) the item's packed value as a dense u64 per window
 // start (0 where nothing is emitted).  Same staging as above; a thread walks the 8 + k - 1 bytes of its 8 starts once with the run length of

@@ -388,8 +388,15 @@ def test_k_above_32_on_the_reduce_face(ctx, golden_dir):
         a[m > 0.997] = np.frombuffer(b"NnUu-", dtype=np.uint8)[rng.integers(0, 5, int((m > 0.997).sum()))]
         rnd.append(a.tobytes())
     pal = [b"ACGT" * 80, b"acgt" * 80, b"AT" * 40 + b"at" * 40, b"A" * 300 + b"T" * 300]   # reverse-complement palindromes: ties -> rc
+    # upper case only: the input on which the packed-stream kernel's result stands (no lower case, no k-mer equal to its reverse complement
+    # over 32 bases) - record lengths around k and around the 16-byte slots / 4096-byte tiles of wide_canonical_reduce_kernel, breaks anywhere
+    clean = []
+    for n in [0, 1, 31, 32, 33, 34, 47, 48, 49, 63, 64, 65, 254, 255, 256, 257, 271, 272, 4095, 4096, 4097, 4351, 4352, 9000, 20000] + [int(x) for x in rng.integers(0, 1500, 40)]:
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+        a[rng.random(n) > 0.9985] = ord("N")
+        clean.append(a.tobytes())
     try:
-        for name, recs in (("28S", recs28), ("random", rnd), ("palindromes", pal)):
+        for name, recs in (("28S", recs28), ("random", rnd), ("palindromes", pal), ("clean", clean)):
             buf = b"\n".join(r.replace(b"\n", b"").replace(b"\r", b"") for r in recs) + b"\n"
             flat = [r.replace(b"\n", b"").replace(b"\r", b"") for r in recs]
             t = to_dev(buf)
@@ -402,6 +409,17 @@ def test_k_above_32_on_the_reduce_face(ctx, golden_dir):
                         got = ctx.accum_read()
                         assert_stats_equal(got, want, ("k > 32", name, k, pre, geometry))
                         assert got["n_undigested"] == got["n_total"]
+                    if name in ("clean", "palindromes"):   # the byte-walking kernel alone (the route the pair falls back to) says the same
+                        try:
+                            ctx.set_option(NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_NO_SPECULATION)
+                            ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, pre, reset=True)
+                            assert_stats_equal(ctx.accum_read(), want, ("k > 32, direct route", name, k, pre))
+                        finally:
+                            ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 0)
+            for k in (40, 49, 97, 128, 200):   # other word / bit offsets of the window's start
+                want = _wide_reference(flat, k, True)
+                ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE, reset=True)
+                assert_stats_equal(ctx.accum_read(), want, ("k > 32", name, k))
         ctx.set_launch(0, 0)
         # a k <= 32 scan after it: digests again, nothing undigested
         buf = b"\n".join(rnd) + b"\n"
