@@ -306,7 +306,7 @@ int run_raw_bytes_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk
 // CanonicalKmers with k = 33..255 (counters + histogram): wide_canonical_reduce_kernel decides the strand on the first 32 bases of the packed
 // 2-bit streams; canonical_bytes_reduce_kernel<true> is queued behind it and returns at once unless that launch raised its flag (two k-mers
 // equal over 32 bases, or - on input that was not normalised - a byte with bit 5 set), and the fold takes whichever partials are valid.  No
-// host round trip; 0.8 ms instead of 9.5 per 1.5 GB at k = 64 (profiles/r06r).  The direct route under NTK_ROUTE_NO_SPECULATION.
+// host round trip; 0.9 ms instead of 9.5 per 1.5 GB at k = 64 (profiles/r06r).  The direct route under NTK_ROUTE_NO_SPECULATION.
 int run_wide_reduce(ntk_ctx *c, const uint8_t *d_seq, uint64_t n, const ntk_params *p, bool zero_first, bool normalized)
 {
     if (c->route_off & NTK_ROUTE_NO_SPECULATION) return run_raw_bytes_reduce(c, d_seq, n, p, zero_first, normalized);

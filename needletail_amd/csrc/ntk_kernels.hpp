@@ -1566,6 +1566,24 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
 //     whichever partials are valid).  ACCEPT_U: the batch is read as Sequence::normalize leaves it (U / u are T, src/sequence.rs:24-51).
 // ---------------------------------------------------------------------------------------------
 constexpr int kWkThreads = 256, kWkTile = kWkThreads * 16, kWkHaloSlots = 16, kWkSlots = kWkThreads + kWkHaloSlots;
+// max of x and the value a DPP pattern brings from another lane (lanes the pattern does not reach keep x; every x here is >= -1)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int32_t wk_dpp_max(int32_t x)
+{
+    const int32_t y = __builtin_amdgcn_update_dpp(-1, x, CTRL, ROW_MASK, 0xF, false);
+    return y > x ? y : x;
+}
+// inclusive max-scan over the rows of 16 lanes (row_shr:1, 2, 4, 8), and on to the whole wave (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int32_t wk_row_scan_max(int32_t x)
+{
+    x = wk_dpp_max<0x111, 0xF>(x); x = wk_dpp_max<0x112, 0xF>(x); x = wk_dpp_max<0x114, 0xF>(x); return wk_dpp_max<0x118, 0xF>(x);
+}
+__device__ __forceinline__ int32_t wk_wave_scan_max(int32_t x)
+{
+    x = wk_row_scan_max(x);
+    x = wk_dpp_max<0x142, 0xA>(x);
+    return wk_dpp_max<0x143, 0xC>(x);
+}
 __device__ __forceinline__ uint32_t wk_take32(uint32_t hi, uint32_t lo, uint32_t bits)   // 32 bits of the stream (hi : lo) starting `bits` (0..30) after hi's top bit
 {
     return bits ? alignbit(hi, lo, 32u - bits) : hi;
@@ -1607,19 +1625,13 @@ __global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const
         int32_t inc = stage(s_own, bad_own);
         int32_t halo = -1;
         if (tid < kWkHaloSlots) halo = stage((int32_t)tid, bad_halo);
-        if (wave == 0) {   // last break of the halo slots (lanes 0..15 of wave 0)
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) { const int32_t y = __shfl_xor(halo, o, 64); halo = y > halo ? y : halo; }
-            if (lane == 0) s_wmax[kWkThreads / 64] = halo;
+        if (wave == 0) {   // last break of the halo slots (lanes 0..15 of wave 0: the scan of row 0 ends in lane 15)
+            halo = wk_row_scan_max(halo);
+            if (lane == 15) s_wmax[kWkThreads / 64] = halo;
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {   // inclusive max-scan over the wave's slots
-            const int32_t y = __shfl_up(inc, o, 64);
-            if ((int)lane >= o && y > inc) inc = y;
-        }
+        inc = wk_wave_scan_max(inc);   // inclusive max-scan over the wave's slots (DPP: the LDS pipe is the histogram's)
         if (lane == 63) s_wmax[wave] = inc;
-        int32_t before = __shfl_up(inc, 1, 64);   // last break before the own slot, within the wave
-        if (lane == 0) before = -1;
+        int32_t before = __builtin_amdgcn_update_dpp(-1, inc, 0x138, 0xF, 0xF, false);   // wave_shr:1 - the last break before the own slot, within the wave
         __syncthreads();
         {
             const int32_t h = s_wmax[kWkThreads / 64];
@@ -1640,11 +1652,15 @@ __global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const
         if (valid) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const uint32_t F1 = j ? alignbit(R0, R1, 32 - 2 * j) : R0, F2 = j ? alignbit(R1, R2, 32 - 2 * j) : R1;
-                const uint32_t V1 = j < 15 ? alignbit(rc0, rc1, 2 * j + 2) : rc0, V2 = j < 15 ? alignbit(rc1, rc2, 2 * j + 2) : rc1;
+                const uint32_t F1 = j ? alignbit(R0, R1, 32 - 2 * j) : R0, V1 = j < 15 ? alignbit(rc0, rc1, 2 * j + 2) : rc0;
                 if ((valid >> (15 - j)) & 1u) {   // (the strand bits gathered branch-free and counted once per slot: 10 % slower, profiles/r06r)
-                    const bool lt = F1 < V1 || (F1 == V1 && F2 < V2);
-                    redo |= (F1 == V1 && F2 == V2) ? 1u : 0u;
+                    bool lt = F1 < V1;
+                    if (F1 == V1) {   // 4^-16 per position on random text: the second 16 bases are looked at only here
+                        asm volatile("" ::: "memory");   // (keeps the branch: if-converted, the two funnel shifts and compares run for every position)
+                        const uint32_t F2 = j ? alignbit(R1, R2, 32 - 2 * j) : R1, V2 = j < 15 ? alignbit(rc1, rc2, 2 * j + 2) : rc1;
+                        lt = F2 < V2;
+                        redo |= F2 == V2 ? 1u : 0u;
+                    }
                     atomicAdd(&s_hist[(lt ? F1 : V1) >> 20], 1u);
                     nv++; nf += lt ? 1u : 0u;
                 }
