@@ -973,6 +973,53 @@ def test_full_size_properties_config2(ctx):
     assert rcst["sum"] == whole["sum"] and rcst["xor"] == whole["xor"] and np.array_equal(rcst["hist"], whole["hist"])
 
 
+def test_full_size_properties_k_above_32(ctx):
+    """CanonicalKmers with k = 51 / 127 on the whole config-2 batch (10 M x 150 bp) - sizes the literal iterator does not finish in seconds, so
+    size-independent properties: (1) the packed-stream kernel and the byte-walking kernel (NTK_ROUTE_NO_SPECULATION) agree on counters and
+    histogram, normalised input or not; (2) linearity over unequal record-aligned parts; (3) reverse-complementing every read swaps n_fwd and
+    n_rc (k odd: no k-mer is its own reverse complement) and leaves the histogram alone; (4) n_total against the window count the host derives
+    from the positions of the breaks (runs of bases of length r hold r - k + 1 windows)."""
+    n_reads, L = 10_000_000, 150
+    stride = L + 1
+    nbytes = n_reads * stride
+    t = torch.empty(nbytes + 1024, dtype=torch.uint8, device="cuda")
+    ctx.synth_reads_device(0x5EED0002, 0, n_reads, L, 1, t)
+    path = nt.PATH_BYTES_CANONICAL
+    # runs of bases: every byte that is not ACGT ends one (the synthetic batch holds ACGT, N and the record separator)
+    bases = (t[:nbytes] == 65) | (t[:nbytes] == 67) | (t[:nbytes] == 71) | (t[:nbytes] == 84)
+    brk = torch.nonzero(~bases).flatten()
+    runs = torch.diff(brk, prepend=torch.tensor([-1], device="cuda")) - 1   # the batch ends with a separator: every run is closed
+    try:
+        for k in (51, 127):
+            want_total = int(torch.clamp(runs - k + 1, min=0).sum())
+            got = {}
+            for pre in (nt.PRE_NORMALIZE, nt.PRE_NONE):
+                for route in (0, NL.ROUTE_NO_SPECULATION):
+                    ctx.set_option(NL.OPT_MINIMIZER_ROUTE, route)
+                    ctx.reduce_device(t, nbytes, k, path, pre, reset=True)
+                    got[(pre, route)] = ctx.accum_read()
+            ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 0)
+            whole = got[(nt.PRE_NORMALIZE, 0)]
+            assert whole["n_total"] == want_total == whole["n_undigested"] and whole["n_total"] == whole["n_fwd"] + whole["n_rc"] == int(whole["hist"].sum())
+            assert whole["sum"] == 0 and whole["xor"] == 0
+            for key, st in got.items():   # (1)
+                assert_stats_equal(st, whole, ("k > 32, routes", k, key))
+            a, b = 16 * 100_003, 16 * 400_001   # (2): a * stride is a multiple of 16
+            ctx.accum_reset()
+            for lo, hi in ((0, a), (a, b), (b, n_reads)):
+                ctx.reduce_device(t.data_ptr() + lo * stride, (hi - lo) * stride, k, path, nt.PRE_NORMALIZE)
+            assert_stats_equal(ctx.accum_read(), whole, ("k > 32, linearity", k))
+            t2 = torch.empty_like(t)   # (3)
+            ctx.reverse_complement_records_device(t, t2, n_reads, L, stride)
+            ctx.reduce_device(t2, nbytes, k, path, nt.PRE_NORMALIZE, reset=True)
+            rcst = ctx.accum_read()
+            assert rcst["n_total"] == whole["n_total"] and rcst["n_fwd"] == whole["n_rc"] and rcst["n_rc"] == whole["n_fwd"]
+            assert np.array_equal(rcst["hist"], whole["hist"])
+            del t2
+    finally:
+        ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 0)
+
+
 # ---- property-based differential test on the GPU (hypothesis) ---------------------------------------------------------
 from hypothesis import given, settings, strategies as st_  # noqa: E402
 
