@@ -140,7 +140,9 @@ int ntk_ctx_set_launch(ntk_ctx *ctx, int blocks, int threads_per_block);
  *                                  generic kernel (k <= 25 then runs the general keys) - so that each route can be checked against
  *                                  the others on the same input; NTK_ROUTE_NO_SPECULATION: un-normalised byte-path input
  *                                  (NTK_PATH_BYTES_CANONICAL, pre < NORMALIZE) goes straight to the raw-byte kernel instead of the
- *                                  packed-value scan that watches for lower case and is redone by that kernel only if it saw any
+ *                                  packed-value scan that watches for lower case and is redone by that kernel only if it saw any;
+ *                                  k = 33..255 likewise goes straight to the byte-walking kernel instead of the packed-stream one
+ *                                  that decides the strand on 32 bases and is redone only for an inverted repeat or lower case
  *   NTK_OPT_COMPAT_PACK_THREADS    host threads that pack a chunk of the item-array compat faces (default 8)
  *   NTK_OPT_COPY_STREAMS           HIP streams that take the pinned batches' H2D copies in turn (1 or 2; default 2: the next batch's copy is
  *                                  queued while one runs - measured +14 % on the H2D-inclusive FASTQ pipeline with 4 MiB batches)
