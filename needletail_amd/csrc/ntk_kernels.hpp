@@ -809,7 +809,10 @@ __global__ __launch_bounds__(1024, NTK_SV2_MINWAVES) void scan2_kernel(ScanArgs 
         auto process = [&](const u32x4 &t, const u32x4 &q, uint32_t r, auto &&after_encode) {
             const bool tail = r >= a.tail_tile_rel;
             Raw16 raw{t.x, t.y, t.z, t.w};
-            if constexpr (SPEC) lc = bitop3<0xFE>(bitop3<0xFE>(lc, t.x, t.y), t.z, t.w);
+            if constexpr (SPEC) {
+                if (tail) lc |= or_of_input_bytes(raw, (int64_t)a.n_bytes - ((int64_t)tile_byte - (int64_t)kHaloB + lane * 16));   // (wave-uniform: the last 16-byte line's padding is nobody's base)
+                else lc = bitop3<0xFE>(bitop3<0xFE>(lc, t.x, t.y), t.z, t.w);
+            }
             if constexpr (QM) raw = quality_break16(raw, Raw16{q.x, q.y, q.z, q.w}, a.q_add, a.q_sel);
 #ifdef NTK_ABL_LOADSONLY
             mp.xlo ^= raw.x ^ raw.y ^ raw.z ^ raw.w; (void)tail;
@@ -1565,7 +1568,6 @@ __global__ __launch_bounds__(kPlThreads) void canonical_bytes_reduce_kernel(cons
 //     canonical_bytes_reduce_kernel<true> behind this launch, which then redoes it (run_wide_reduce in ntk_api.hip; the fold takes
 //     whichever partials are valid).  ACCEPT_U: the batch is read as Sequence::normalize leaves it (U / u are T, src/sequence.rs:24-51).
 // ---------------------------------------------------------------------------------------------
-constexpr int kWkThreads = 256, kWkTile = kWkThreads * 16, kWkHaloSlots = 16, kWkSlots = kWkThreads + kWkHaloSlots;
 // max of x and the value a DPP pattern brings from another lane (lanes the pattern does not reach keep x; every x here is >= -1)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int32_t wk_dpp_max(int32_t x)
@@ -1584,10 +1586,6 @@ __device__ __forceinline__ int32_t wk_wave_scan_max(int32_t x)
     x = wk_dpp_max<0x142, 0xA>(x);
     return wk_dpp_max<0x143, 0xC>(x);
 }
-__device__ __forceinline__ uint32_t wk_take32(uint32_t hi, uint32_t lo, uint32_t bits)   // 32 bits of the stream (hi : lo) starting `bits` (0..30) after hi's top bit
-{
-    return bits ? alignbit(hi, lo, 32u - bits) : hi;
-}
 template <bool ACCEPT_U>
 __global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const uint8_t *seq, uint64_t n, uint32_t k, uint32_t *part_hist,
                                                                            uint64_t *part_scalars, uint32_t *redo_flag, uint32_t *redo_flag_next)
@@ -1602,7 +1600,7 @@ __global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const
     if (redo_flag_next && blockIdx.x == 0 && tid == 0) *redo_flag_next = 0;   // the next launch's flag (a ring, as the scan's lower_flag)
     const uint64_t n_tiles = (n + kWkTile - 1) / kWkTile, n_readable = (n + 15) & ~(uint64_t)15;
     // the window ending at byte 0 of slot s starts k - 1 bases earlier: in code word s - back, base_off bases below its top
-    const uint32_t back = (k - 1u + 15u) >> 4, base_bits = 2u * ((16u - ((k - 1u) & 15u)) & 15u);
+    const uint32_t back = wk_back_words(k), base_bits = wk_base_bits(k);
     const int32_t s_own = (int32_t)tid + kWkHaloSlots;
     uint32_t nv = 0, nf = 0, redo = 0, lc = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -1612,14 +1610,11 @@ __global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const
             const int64_t p = t0 + 16 * (int64_t)s;
             u32x4 x = {0u, 0u, 0u, 0u};
             if (p >= 0 && (uint64_t)p + 16 <= n_readable) x = *reinterpret_cast<const u32x4 *>(seq + p);
-            if (!ACCEPT_U) lc |= x.x | x.y | x.z | x.w;
-            const EncSV2 en = encode16_sv2<ACCEPT_U>(Raw16{x.x, x.y, x.z, x.w});
-            bad = bad16_from_letters(en.ex, en.uu);   // base i at bit 15 - i
-            const int64_t keep = (int64_t)n - p;      // bytes of the slot that belong to the input: the rest are breaks
-            if (p < 0 || keep <= 0) bad = 0xFFFFu;
-            else if (keep < 16) bad |= 0xFFFFu >> (uint32_t)keep;
-            s_code[s] = en.code; s_rcode[s] = en.rcode;
-            return bad ? 16 * s + 15 - (int32_t)__builtin_ctz(bad) : -1;
+            const WkSlot sl = wk_stage_slot<ACCEPT_U>(Raw16{x.x, x.y, x.z, x.w}, s, p < 0 ? 0 : (int64_t)n - p);   // bytes before the input or at / beyond n are breaks
+            if (!ACCEPT_U) lc |= sl.or_bytes;
+            bad = sl.bad;
+            s_code[s] = sl.code; s_rcode[s] = sl.rcode;
+            return sl.last_break;
         };
         uint32_t bad_own, bad_halo;
         int32_t inc = stage(s_own, bad_own);
@@ -1638,33 +1633,27 @@ __global__ __launch_bounds__(kWkThreads) void wide_canonical_reduce_kernel(const
             before = h > before ? h : before;
             for (uint32_t w = 0; w < wave; w++) { const int32_t y = s_wmax[w]; before = y > before ? y : before; }
         }
-        // the window ending at own byte j is emitted iff j is below the own first break and at least k bytes behind the last break before the slot
-        const uint32_t first_bad = bad_own ? (uint32_t)__builtin_clz(bad_own) - 16u : 16u;
-        const uint32_t mask_own = first_bad >= 16u ? 0xFFFFu : ((0xFFFFu << (16u - first_bad)) & 0xFFFFu);
-        const int32_t thr = before + (int32_t)k - 16 * s_own;
-        const uint32_t mask_inh = thr <= 0 ? 0xFFFFu : (thr >= 16 ? 0u : (0xFFFFu >> (uint32_t)thr));
-        const uint32_t valid = mask_own & mask_inh;   // position j at bit 15 - j
+        const uint32_t valid = wk_valid16(bad_own, before, k, s_own);   // position j at bit 15 - j
         const uint32_t i0 = (uint32_t)s_own - back;
         const uint32_t w0 = s_code[i0], w1 = s_code[i0 + 1], w2 = s_code[i0 + 2], w3 = s_code[i0 + 3];
         // three words realigned to the first window's first base (bases a0 .. a0 + 47; the last one is never used, so w3 may be a word nobody staged)
-        const uint32_t R0 = wk_take32(w0, w1, base_bits), R1 = wk_take32(w1, w2, base_bits), R2 = wk_take32(w2, w3, base_bits);
-        const uint32_t rc0 = s_rcode[s_own], rc1 = s_rcode[s_own - 1], rc2 = s_rcode[s_own - 2];
+        const WkWords ww = {wk_take32(w0, w1, base_bits), wk_take32(w1, w2, base_bits), wk_take32(w2, w3, base_bits),
+                            s_rcode[s_own], s_rcode[s_own - 1], s_rcode[s_own - 2]};
         if (valid) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t F1 = j ? alignbit(R0, R1, 32 - 2 * j) : R0, V1 = j < 15 ? alignbit(rc0, rc1, 2 * j + 2) : rc0;
-                if ((valid >> (15 - j)) & 1u) {   // (the strand bits gathered branch-free and counted once per slot: 10 % slower, profiles/r06r)
-                    bool lt = F1 < V1;
-                    if (F1 == V1) {   // 4^-16 per position on random text: the second 16 bases are looked at only here
-                        asm volatile("" ::: "memory");   // (keeps the branch: if-converted, the two funnel shifts and compares run for every position)
-                        const uint32_t F2 = j ? alignbit(R1, R2, 32 - 2 * j) : R1, V2 = j < 15 ? alignbit(rc1, rc2, 2 * j + 2) : rc1;
-                        lt = F2 < V2;
-                        redo |= F2 == V2 ? 1u : 0u;
-                    }
-                    atomicAdd(&s_hist[(lt ? F1 : V1) >> 20], 1u);
+            auto position = [&](auto jc) {   // (the strand bits gathered branch-free and counted once per slot: 10 % slower, profiles/r06r)
+                constexpr int J = decltype(jc)::value;
+                if ((valid >> (15 - J)) & 1u) {
+                    bool lt, tie; uint32_t top;
+                    wk_strand<J>(ww, lt, tie, top);
+                    redo |= tie ? 1u : 0u;
+                    atomicAdd(&s_hist[top >> 20], 1u);
                     nv++; nf += lt ? 1u : 0u;
                 }
-            }
+            };
+#define NTK_WK_POS(J) position(std::integral_constant<int, J>{});
+            NTK_WK_POS(0) NTK_WK_POS(1) NTK_WK_POS(2) NTK_WK_POS(3) NTK_WK_POS(4) NTK_WK_POS(5) NTK_WK_POS(6) NTK_WK_POS(7)
+            NTK_WK_POS(8) NTK_WK_POS(9) NTK_WK_POS(10) NTK_WK_POS(11) NTK_WK_POS(12) NTK_WK_POS(13) NTK_WK_POS(14) NTK_WK_POS(15)
+#undef NTK_WK_POS
         }
     }
     if (!ACCEPT_U && (lc & 0x20202020u)) redo = 1;

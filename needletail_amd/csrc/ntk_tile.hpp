@@ -1261,4 +1261,82 @@ NTK_HD void minimizer_lane(const ScanArgs &a, XL &xl, Sink &sink, Raw16 raw, int
     minimizer_slide(a, xl, M, sink);
 }
 
+// ---------------------------------------------------------------------------------------------
+// CanonicalKmers with 33 <= k <= 255 on the reduce face (wide_canonical_reduce_kernel in ntk_kernels.hpp; tests/emu runs the same functions
+// on the host): a block stages kWkThreads slots of 16 window ENDS + kWkHaloSlots slots before them (k - 1 <= 254 bytes) as code word,
+// reverse-complement word and break mask per slot.  Positions are "staged": 16 x slot + byte.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWkThreads = 256, kWkTile = kWkThreads * 16, kWkHaloSlots = 16, kWkSlots = kWkThreads + kWkHaloSlots;
+
+// OR of the first `keep` bytes of a 16-byte line (keep <= 0: none, >= 16: all): what the speculative kernels watch for bit 5 - the padding
+// behind the input's last byte is nobody's base and must not send a launch to the byte-walking kernel.
+NTK_HD uint32_t or_of_input_bytes(Raw16 raw, int64_t keep)
+{
+    if (keep >= 16) return raw.x | raw.y | raw.z | raw.w;
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t r = 0;
+    for (int d = 0; d < 4; d++) {
+        const int64_t nb = keep - 4 * d;
+        if (nb > 0) r |= nb >= 4 ? w[d] : (w[d] & ((1u << (8 * (uint32_t)nb)) - 1u));
+    }
+    return r;
+}
+
+// One slot: `keep` = how many of its 16 bytes belong to the input (<= 0: none - before the input's start or beyond its end; >= 16: all).
+// Returns the staged position of the slot's last break, -1 if it holds none.
+struct WkSlot { uint32_t code, rcode, bad, or_bytes; int32_t last_break; };   // bad: base i at bit 15 - i; or_bytes: OR of the slot's input bytes
+template <bool ACCEPT_U>
+NTK_HD WkSlot wk_stage_slot(Raw16 raw, int32_t slot, int64_t keep)
+{
+    const EncSV2 en = encode16_sv2<ACCEPT_U>(raw);
+    WkSlot r;
+    r.code = en.code; r.rcode = en.rcode;
+    r.or_bytes = or_of_input_bytes(raw, keep);
+    r.bad = bad16_from_letters(en.ex, en.uu);
+    if (keep <= 0) r.bad = 0xFFFFu;
+    else if (keep < 16) r.bad |= 0xFFFFu >> (uint32_t)keep;
+    r.last_break = r.bad ? 16 * slot + 15 - (int32_t)__builtin_ctz(r.bad) : -1;
+    return r;
+}
+
+// The window ending at byte j of slot `slot` is emitted iff j lies below the slot's own first break and at least k bytes behind the last
+// break before the slot (`before`: staged position, -1 if the staged bytes before the slot hold none): position j at bit 15 - j.
+NTK_HD uint32_t wk_valid16(uint32_t bad_own, int32_t before, uint32_t k, int32_t slot)
+{
+    const uint32_t first_bad = bad_own ? (uint32_t)__builtin_clz(bad_own) - 16u : 16u;
+    const uint32_t mask_own = first_bad >= 16u ? 0xFFFFu : ((0xFFFFu << (16u - first_bad)) & 0xFFFFu);
+    const int32_t thr = before + (int32_t)k - 16 * slot;
+    const uint32_t mask_inh = thr <= 0 ? 0xFFFFu : (thr >= 16 ? 0u : (0xFFFFu >> (uint32_t)thr));
+    return mask_own & mask_inh;
+}
+
+// Where the window ending at byte 0 of a slot starts: `back` code words before the slot's own, `bits` bits below that word's top.
+NTK_HD uint32_t wk_back_words(uint32_t k) { return (k - 1u + 15u) >> 4; }
+NTK_HD uint32_t wk_base_bits(uint32_t k) { return 2u * ((16u - ((k - 1u) & 15u)) & 15u); }
+NTK_HD uint32_t wk_take32(uint32_t hi, uint32_t lo, uint32_t bits)   // 32 bits of the stream (hi : lo) starting `bits` (0..30) after hi's top bit
+{
+    return bits ? alignbit(hi, lo, 32u - bits) : hi;
+}
+
+// The strand of the window ending at byte J: the k-mer's first 16 bases (F1, from the three code words R realigned to the first window's first
+// base) against its reverse complement's first 16 (V1: the complement of its last 16, reversed - from the own and the previous slot's
+// reverse-complement words); the second 16 only where the first tie.  lt: the forward k-mer is the smaller slice (reference src/kmer.rs:124-128:
+// ties report the reverse complement); tie: equal over 32 bases - the caller's launch is redone by the byte-walking kernel; top: the chosen
+// strand's first 16 bases (its leading six are the histogram bin).
+struct WkWords { uint32_t R0, R1, R2, rc0, rc1, rc2; };
+template <int J>
+NTK_HD void wk_strand(const WkWords &w, bool &lt, bool &tie, uint32_t &top)
+{
+    const uint32_t F1 = J ? alignbit(w.R0, w.R1, 32 - 2 * J) : w.R0, V1 = J < 15 ? alignbit(w.rc0, w.rc1, 2 * J + 2) : w.rc0;
+    lt = F1 < V1; tie = false;
+    if (F1 == V1) {   // 4^-16 per position on random text: the second 16 bases are looked at only here
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");   // (keeps the branch: if-converted, the two funnel shifts and compares run for every position)
+#endif
+        const uint32_t F2 = J ? alignbit(w.R1, w.R2, 32 - 2 * J) : w.R1, V2 = J < 15 ? alignbit(w.rc1, w.rc2, 2 * J + 2) : w.rc1;
+        lt = F2 < V2; tie = F2 == V2;
+    }
+    top = lt ? F1 : V1;
+}
+
 }  // namespace ntk

@@ -329,7 +329,62 @@ static void masks_both(const uint64_t (&G)[16], uint64_t *ok, uint64_t *ab)
     for (int j = 0; j < 16; j++) { ok[j] = A[j] & B[j]; ab[j] = A[j] & B[j]; }
 }
 
+// CanonicalKmers with 33 <= k <= 255 as wide_canonical_reduce_kernel runs it (ntk_kernels.hpp): the same per-slot functions of ntk_tile.hpp,
+// tile by tile, with the block's max-scan of break positions as a running maximum.  out: [n_total, n_fwd, windows equal to their reverse
+// complement over 32 bases (the kernel raises its redo flag), a byte with bit 5 set was loaded (ditto, when the input is not normalised),
+// hist[4096]].
+template <int J>
+static void wide_position(const WkWords &ww, uint32_t valid, uint64_t *out)
+{
+    if (!((valid >> (15 - J)) & 1u)) return;
+    bool lt, tie; uint32_t top;
+    wk_strand<J>(ww, lt, tie, top);
+    out[0]++; out[1] += lt ? 1 : 0; out[2] += tie ? 1 : 0; out[4 + (top >> 20)]++;
+}
+template <bool ACCEPT_U>
+static void wide_reduce(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, uint64_t *out)
+{
+    const uint64_t n_tiles = (n + kWkTile - 1) / kWkTile;
+    const uint32_t back = wk_back_words(k), base_bits = wk_base_bits(k);
+    std::vector<uint32_t> code(kWkSlots + 2, 0u), rcode(kWkSlots, 0u), bad(kWkSlots, 0u);
+    std::vector<int32_t> last(kWkSlots, -1);
+    for (uint64_t tile = 0; tile < n_tiles; tile++) {
+        const int64_t t0 = (int64_t)(tile * kWkTile) - 16 * kWkHaloSlots;
+        for (int32_t s = 0; s < kWkSlots; s++) {
+            const int64_t p = t0 + 16 * (int64_t)s;
+            uint32_t x[4] = {0u, 0u, 0u, 0u};
+            if (p >= 0 && (uint64_t)p + 16 <= n_padded) memcpy(x, buf + p, 16);
+            const WkSlot sl = wk_stage_slot<ACCEPT_U>(Raw16{x[0], x[1], x[2], x[3]}, s, p < 0 ? 0 : (int64_t)n - p);
+            if (sl.or_bytes & 0x20202020u) out[3] = 1;
+            code[s] = sl.code; rcode[s] = sl.rcode; bad[s] = sl.bad; last[s] = sl.last_break;
+        }
+        int32_t before = -1;
+        for (int32_t s = 0; s < kWkSlots; s++) {
+            if (s >= kWkHaloSlots) {
+                const uint32_t valid = wk_valid16(bad[s], before, k, s);
+                const uint32_t i0 = (uint32_t)s - back;
+                const WkWords ww = {wk_take32(code[i0], code[i0 + 1], base_bits), wk_take32(code[i0 + 1], code[i0 + 2], base_bits),
+                                    wk_take32(code[i0 + 2], code[i0 + 3], base_bits), rcode[s], rcode[s - 1], rcode[s - 2]};
+                wide_position<0>(ww, valid, out); wide_position<1>(ww, valid, out); wide_position<2>(ww, valid, out); wide_position<3>(ww, valid, out);
+                wide_position<4>(ww, valid, out); wide_position<5>(ww, valid, out); wide_position<6>(ww, valid, out); wide_position<7>(ww, valid, out);
+                wide_position<8>(ww, valid, out); wide_position<9>(ww, valid, out); wide_position<10>(ww, valid, out); wide_position<11>(ww, valid, out);
+                wide_position<12>(ww, valid, out); wide_position<13>(ww, valid, out); wide_position<14>(ww, valid, out); wide_position<15>(ww, valid, out);
+            }
+            if (last[s] > before) before = last[s];
+        }
+    }
+}
+
 extern "C" {
+
+// see wide_reduce above; returns 0, -1 on bad k
+int emu_wide_reduce(const uint8_t *buf, uint64_t n, uint64_t n_padded, uint32_t k, int accept_u, uint64_t *out)
+{
+    if (k < 33 || k > 255) return -1;
+    for (int i = 0; i < 4 + 4096; i++) out[i] = 0;
+    if (accept_u) wide_reduce<true>(buf, n, n_padded, k, out); else wide_reduce<false>(buf, n, n_padded, k, out);
+    return 0;
+}
 
 // out: [n_total, n_fwd, sum, xor, hist[4096]].  canon/tie_rc/accept_u as the kernel's template flags.
 // values/valid16/rc16 may be null.  Returns 0, -1 on bad k.

@@ -443,3 +443,69 @@ def test_emu_window_masks_at_run_time(emu):
             for j in range(16):
                 want = sum(1 << l for l in range(halo, 64) if run[16 * l + j] >= L)
                 assert int(ok[j]) == want, (trial, L, j, hex(int(ok[j])), hex(want))
+
+
+def _wide_reference(recs, k, normalized):
+    """CanonicalKmers with 33 <= k <= 255 per record through the oracle's literal iterator: counters + the histogram of the leading six bases
+    of every emitted slice (as tests/test_gpu_parity.py holds it for the GPU)."""
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i; code[ch | 0x20] = i
+    st = {"n_total": 0, "n_fwd": 0, "hist": np.zeros(4096, dtype=np.uint64)}
+    for r in recs:
+        if normalized:
+            r = O.normalize(r)[0]
+        rc = O.reverse_complement(r)
+        pos, flg = O.canonical_kmers_arrays(r, rc, k)
+        for p, f in zip(pos.tolist(), flg.tolist()):
+            sl = rc[len(rc) - p - k: len(rc) - p] if f else r[p: p + k]
+            b = 0
+            for ch in sl[:6]:
+                b = b * 4 + int(code[ch])
+            st["hist"][b] += 1
+        st["n_total"] += len(pos); st["n_fwd"] += len(pos) - int(flg.sum())
+    return st
+
+
+def test_emu_wide_k_reduce(emu):
+    """Round 6: CanonicalKmers with k = 33..255 from the packed 2-bit streams (wide_canonical_reduce_kernel): the per-slot functions of
+    ntk_tile.hpp - break mask and last break per slot, the 16-bit window mask from the last break before the slot, the word / bit offset of the
+    window's start, the strand on the first 32 bases - run tile by tile on the host against the literal iterator: upper-case records with
+    lengths around k, the 16-byte slots and the 4096-byte tiles, breaks anywhere, every k mod 16.  Inverted repeats and lower case must raise
+    the flags on which the kernel's launch is redone by the byte-walking kernel."""
+    emu.emu_wide_reduce.restype = C.c_int
+    emu.emu_wide_reduce.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
+
+    def run(buf, k, accept_u):
+        n = len(buf)
+        npad = (n + 15) // 16 * 16
+        arr = np.frombuffer(buf + b"\xAA" * (npad - n), dtype=np.uint8).copy()   # garbage in the 16-byte padding: beyond n everything is a break
+        out = np.zeros(4 + 4096, dtype=np.uint64)
+        assert emu.emu_wide_reduce(arr.ctypes.data, n, npad, k, int(accept_u), out.ctypes.data) == 0
+        return {"n_total": int(out[0]), "n_fwd": int(out[1]), "ties": int(out[2]), "bit5": int(out[3]), "hist": out[4:].copy()}
+
+    rng = np.random.default_rng(3356)
+    recs = []
+    for n in [0, 1, 32, 33, 34, 47, 48, 49, 64, 65, 254, 255, 256, 257, 271, 272, 4095, 4096, 4097, 4351, 4352, 9000] + [int(x) for x in rng.integers(0, 1200, 30)]:
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+        a[rng.random(n) > 0.998] = ord("N")
+        recs.append(a.tobytes())
+    buf = b"\n".join(recs) + b"\n"
+    for k in list(range(33, 50)) + [63, 64, 65, 97, 128, 200, 254, 255]:
+        want = _wide_reference(recs, k, False)
+        for accept_u in (False, True):
+            got = run(buf, k, accept_u)
+            assert got["ties"] == 0
+            assert (got["n_total"], got["n_fwd"]) == (want["n_total"], want["n_fwd"]) and np.array_equal(got["hist"], want["hist"]), (k, accept_u)
+    # U is a base only on input read as normalised (reference src/sequence.rs:30); lower case reads the same there
+    recs_u = [np.frombuffer(b"ACGUacgutT", dtype=np.uint8)[rng.integers(0, 10, n)].tobytes() for n in (20, 33, 120, 300, 700)]
+    buf_u = b"\n".join(recs_u) + b"\n"
+    for k in (33, 50, 77):
+        want = _wide_reference(recs_u, k, True)
+        got = run(buf_u, k, True)
+        assert got["ties"] == 0 and (got["n_total"], got["n_fwd"]) == (want["n_total"], want["n_fwd"]) and np.array_equal(got["hist"], want["hist"]), k
+    assert run(buf_u, 33, False)["bit5"] == 1 and run(buf, 33, False)["bit5"] == 0   # (un-normalised input with bit 5 anywhere: the launch is redone)
+    # windows equal to their reverse complement over 32 bases: counted, so that the kernel can hand the launch to the byte-walking kernel
+    for rec in (b"ACGT" * 80, b"AT" * 100, b"A" * 300 + b"T" * 300):
+        assert run(rec + b"\n", 34, True)["ties"] > 0
+    assert run(b"A" * 300 + b"T" * 300 + b"\n", 255, True)["ties"] > 0
