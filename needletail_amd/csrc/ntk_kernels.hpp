@@ -287,6 +287,17 @@ struct DevMasks2 {
     __device__ __forceinline__ void compute(const Enc &en, bool tail_tile, int64_t lane_base, uint64_t n_bytes)
     {
         uint64_t B[16];
+#ifdef NTK_X_CLEANTILE   // kbench experiment (profiles/r06v): a tile that holds no break at all (long contigs) needs no byte compares and no mask algebra
+        {
+            const uint32_t dif = (en.ex[0] ^ en.uu[0]) | (en.ex[1] ^ en.uu[1]) | (en.ex[2] ^ en.uu[2]) | (en.ex[3] ^ en.uu[3]);
+            if (!tail_tile && __builtin_amdgcn_ballot_w64(dif != 0u) == 0ull) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) { VA[i] = Sv2Geom<KM>::kKeep; VB[i] = ~0ull; }
+                asm volatile("" ::: "memory");
+                return;
+            }
+        }
+#endif
 #ifdef NTK_ABL_NOSDWA
 #pragma unroll
         for (int i = 0; i < 16; i++) B[i] = __builtin_amdgcn_ballot_w64(en.ex[i & 3] != (uint32_t)i);

@@ -21,7 +21,7 @@ int main(int argc, char **argv)
     const int threads = argc > 4 ? atoi(argv[4]) : 1024;
     const int iters = argc > 5 ? atoi(argv[5]) : 10;
     const char *tag = argc > 6 ? argv[6] : "kbench";
-    const uint32_t L = 150;
+    const uint32_t L = getenv("KB_READ_LEN") ? (uint32_t)atoi(getenv("KB_READ_LEN")) : 150;   // KB_READ_LEN=10000: contigs (config 3's shape)
     const uint64_t n = reads * (L + 1);
     uint8_t *d_seq; uint32_t *d_ph; uint64_t *d_ps, *d_acc;
     CHK(hipMalloc(&d_seq, n + 4096));
