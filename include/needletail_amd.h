@@ -113,6 +113,9 @@ typedef struct ntk_result {
 #define NTK_ACC_SUM 3
 #define NTK_ACC_XOR 4   /* NOT summable: combine with xor (or use the bit counters below) */
 #define NTK_ACC_UNDIGESTED 5 /* ntk_result.n_undigested */
+#define NTK_ACC_REDONE 6 /* diagnostic, not part of ntk_result: speculative launches since the reset (un-normalised byte-path input,
+                            k > 32) whose result came from the byte-walking kernel queued behind them - lower case, or two k-mers
+                            equal over 32 bases.  Summable; read through ntk_accum_device_ptr / a bound buffer                   */
 #define NTK_ACC_HIST 8  /* 4096 words follow */
 #define NTK_ACC_XOR_BITS (8 + NTK_HIST_BINS) /* 64 words: how many folded partial xors had bit i set; summable
                                                 across GPUs with one ncclSum all-reduce, xor bit i = parity */

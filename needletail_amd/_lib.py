@@ -15,6 +15,7 @@ PATH_BYTES_CANONICAL, PATH_BITS, PATH_BITS_CANONICAL = 0, 1, 2
 PRE_NONE, PRE_STRIP_RETURNS, PRE_NORMALIZE, PRE_NORMALIZE_IUPAC = 0, 1, 2, 3
 HIST_BINS = 4096
 ACC_N_TOTAL, ACC_N_FWD, ACC_N_RC, ACC_SUM, ACC_XOR, ACC_HIST = 0, 1, 2, 3, 4, 8
+ACC_UNDIGESTED, ACC_REDONE = 5, 6   # REDONE: diagnostic - speculative launches whose result came from the byte-walking kernel
 ACC_XOR_BITS, ACC_WORDS = 8 + 4096, 8 + 4096 + 64
 # ntk_ctx_set_option (test / A-B support)
 OPT_COMPAT_CHUNK_BYTES, OPT_MINIMIZER_CHUNK_BYTES, OPT_MINIMIZER_ROUTE, OPT_COMPAT_PACK_THREADS, OPT_COPY_STREAMS = 1, 2, 3, 4, 5

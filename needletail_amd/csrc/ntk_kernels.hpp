@@ -1224,7 +1224,11 @@ __global__ __launch_bounds__(kFoldThreads) void fold_kernel(const uint32_t *part
     if (threadIdx.x < 64) {
         tv = tf = ts = tx = 0;
         for (int w = 0; w < kFoldThreads / 64; w++) { tv += s_red[w][0]; tf += s_red[w][1]; ts += s_red[w][2]; tx ^= s_red[w][3]; }
-        if (threadIdx.x == 0) { acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx; if (undigested) acc[5] += tv; }
+        if (threadIdx.x == 0) {
+            acc[0] += tv; acc[1] += tf; acc[2] += tv - tf; acc[3] += ts; acc[4] ^= tx;
+            if (undigested) acc[5] += tv;
+            if (select && *select) acc[6] += 1;   // NTK_ACC_REDONE: this launch's result is the byte-walking kernel's
+        }
         acc[8 + kHistBins + threadIdx.x] += (tx >> threadIdx.x) & 1;  // summable form of the xor (one bit counter per lane)
     }
 }

@@ -31,6 +31,22 @@ def to_dev(buf: bytes):
     return t
 
 
+class redone_launches:
+    """Context manager: binds an accumulator buffer of the test's own and reports NTK_ACC_REDONE (speculative launches since the last reset whose
+    result came from the byte-walking kernel queued behind them) - the route a launch took is otherwise invisible in its (equal) result."""
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.acc = torch.zeros(NL.ACC_WORDS, dtype=torch.int64, device="cuda")
+    def __enter__(self):
+        self.ctx.accum_bind_device(self.acc)
+        return self
+    def __exit__(self, *exc):
+        self.ctx.accum_bind_device(None)
+    def count(self):
+        self.ctx.synchronize()
+        return int(self.acc[NL.ACC_REDONE])
+
+
 def gpu_reduce(ctx, buf: bytes, k, path, pre):
     t = to_dev(buf)
     ctx.accum_reset()
@@ -294,13 +310,22 @@ def test_reduce_on_bytes_that_were_not_normalised(ctx):
         if b"U" not in up:
             assert_stats_equal(b, nou, "upper case, packed-value scan")
         # lower case in the padding behind the input's last byte is nobody's base (the speculative kernels keep it out of their bit-5 watch)
-        for n_cut in (len(up), len(up) - 3, len(up) - 18):
-            t = to_dev(up[:n_cut]); t[n_cut:] = 0x61
-            recs_cut = up[:n_cut].split(b"\n")
+        cl = b"\n".join(records(120, 0, 400, 0.0, 0.0)) + b"\n"   # ACGT and the separator only: no byte of the input has bit 5 set
+        for n_cut in (len(cl), len(cl) - 3, len(cl) - 18):
+            t = to_dev(cl[:n_cut]); t[n_cut:] = 0x61
+            recs_cut = cl[:n_cut].split(b"\n")
             ctx.reduce_device(t, n_cut, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, reset=True)
             assert_stats_equal(ctx.accum_read(), O.reduce_records(recs_cut, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE), ("padding", n_cut))
             ctx.reduce_device(t, n_cut, 40, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, reset=True)
             assert_stats_equal(ctx.accum_read(), _wide_reference(recs_cut, 40, False), ("padding, k = 40", n_cut))
+            with redone_launches(ctx) as rl:   # ... and neither launch was handed to the byte-walking kernel
+                ctx.reduce_device(t, n_cut, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, reset=True)
+                ctx.reduce_device(t, n_cut, 40, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+                assert rl.count() == 0, n_cut
+                t[n_cut - 2] |= 0x20   # one lower-case base INSIDE the input: both are
+                ctx.reduce_device(t, n_cut, 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE, reset=True)
+                ctx.reduce_device(t, n_cut, 40, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
+                assert rl.count() == 2, n_cut
         # the pinned-batch face with the reset flag
         st = _run_records(ctx, sets[0], 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE)
         assert_stats_equal(st, O.reduce_records(sets[0], 21, nt.PATH_BYTES_CANONICAL, nt.PRE_NONE), "batch face")
@@ -417,6 +442,13 @@ def test_k_above_32_on_the_reduce_face(ctx, golden_dir):
                         got = ctx.accum_read()
                         assert_stats_equal(got, want, ("k > 32", name, k, pre, geometry))
                         assert got["n_undigested"] == got["n_total"]
+                    with redone_launches(ctx) as rl:   # which kernel's result it was: the packed-stream one unless the batch holds lower case (input not normalised) or an inverted repeat
+                        ctx.reduce_device(t, len(buf), k, nt.PATH_BYTES_CANONICAL, pre, reset=True)
+                        bit5 = any(c & 0x20 for c in set(buf)) and not normalized   # (the watch is on every byte of the input, base or not)
+                        # (ACGT)n, (AT)n: an even-length window can equal its reverse complement, an odd one cannot; A..AT..T: a window with >= 32 of each
+                        # agrees with its reverse complement over the first 32 bases whatever its length
+                        tie32 = name == "palindromes" and (k % 2 == 0 or k >= 65)
+                        assert rl.count() == (1 if bit5 or tie32 else 0), (name, k, pre)
                     if name in ("clean", "palindromes"):   # the byte-walking kernel alone (the route the pair falls back to) says the same
                         try:
                             ctx.set_option(NL.OPT_MINIMIZER_ROUTE, NL.ROUTE_NO_SPECULATION)
@@ -1007,6 +1039,11 @@ def test_full_size_properties_k_above_32(ctx):
                     ctx.reduce_device(t, nbytes, k, path, pre, reset=True)
                     got[(pre, route)] = ctx.accum_read()
             ctx.set_option(NL.OPT_MINIMIZER_ROUTE, 0)
+            with redone_launches(ctx) as rl:   # the synthetic batch (upper case, random) leaves the packed-stream kernel's result standing
+                ctx.reduce_device(t, nbytes, k, path, nt.PRE_NORMALIZE, reset=True)
+                ctx.reduce_device(t, nbytes, k, path, nt.PRE_NONE)
+                ctx.reduce_device(t, nbytes, 21, path, nt.PRE_NONE)
+                assert rl.count() == 0, k
             whole = got[(nt.PRE_NORMALIZE, 0)]
             assert whole["n_total"] == want_total == whole["n_undigested"] and whole["n_total"] == whole["n_fwd"] + whole["n_rc"] == int(whole["hist"].sum())
             assert whole["sum"] == 0 and whole["xor"] == 0
