@@ -1082,6 +1082,27 @@ def test_reduce_matches_oracle_property(data, k, mode):
     assert_stats_equal(gpu_reduce(_HCTX[0], data, k, path, pre), O.reduce_fused(data, k, canon, tie, u), (k, path, pre, len(data)))
 
 
+_ALPHABET_W = b"ACGT" * 80 + b"acgt" + b"NnUu-. \t\r\n\x00\xff"   # mostly bases: windows of 33+ bases have to exist
+
+
+@settings(max_examples=40, deadline=None)
+@given(data=st_.lists(st_.sampled_from(list(_ALPHABET_W)), min_size=0, max_size=6000).map(bytes), k=st_.integers(33, 255), normalized=st_.booleans())
+def test_wide_k_matches_oracle_property(data, k, normalized):
+    """CanonicalKmers with k = 33..255 on the reduce face (the packed-stream kernel, or the byte-walking one behind its flag) against the
+    literal iterator.  On the device face every byte that is not a base breaks the windows - the whitespace class too, which the packer would
+    have deleted - so the reference sees the pieces between them."""
+    import re
+    if not _HCTX:
+        _HCTX.append(nt.Context(0, stream=torch.cuda.current_stream().cuda_stream))
+    recs = re.split(rb"[\n\r\t ]", data) if normalized else data.split(b"\n")
+    want = _wide_reference(recs, k, normalized)
+    ctx = _HCTX[0]
+    ctx.reduce_device(to_dev(data), len(data), k, nt.PATH_BYTES_CANONICAL, nt.PRE_NORMALIZE if normalized else nt.PRE_NONE, reset=True)
+    got = ctx.accum_read()
+    assert_stats_equal(got, want, (k, normalized, len(data)))
+    assert got["n_undigested"] == got["n_total"]
+
+
 # ---- lifecycle / concurrency smoke ----------------------------------------------------------------------------------------
 
 def test_context_lifecycle_and_independent_contexts():
